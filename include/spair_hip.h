@@ -1,0 +1,102 @@
+/* libspair_hip.so -- C ABI of the MI355X-native SPAIR training step.
+ *
+ * This is the drop-in boundary beneath the Python surface `spair_pytorch_amd.models.SPAIR`
+ * (which mirrors /root/reference/spair/models.py:15-131).  The reference has no FFI layer of
+ * its own: what these entry points replace is the ATen/cuDNN/cuBLAS work its forward/backward
+ * dispatches (SURVEY.md §2 "Library-op inventory").  Conventions:
+ *   - every pointer is a DEVICE pointer into caller-owned memory; nothing is allocated or freed,
+ *     scratch is passed in explicitly (`workspace`, zero-initialised ONCE by the caller: the
+ *     library relies on never-written pad columns staying zero);
+ *   - work is enqueued on `stream` (a hipStream_t) and never synchronises;
+ *   - return 0 on success, a negative SPAIR_ERR_* code otherwise (shape / dtype / launch);
+ *   - stateless and re-entrant: all state lives in the buffers the caller passes.
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPAIR_DTYPE_F32 0   /* GEMM/conv operands fp32 (v_mfma_f32_16x16x4_f32), exact */
+#define SPAIR_DTYPE_BF16 1  /* GEMM/conv operands bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+
+/* Hyper-parameters = /root/reference/spair/config.py:3-76 plus the batch geometry. */
+typedef struct SpairDims {
+    int B, C, I, G;            /* batch, image channels, image side, grid side */
+    int P, A, F, NP;           /* OBJECT_SHAPE[0], N_ATTRIBUTES, N_BACKBONE_FEATURES, N_PASSTHROUGH_FEATURES */
+    int n_conv;                /* backbone conv layers before conv_out (config.py:7-14) */
+    int conv_k[8], conv_s[8], conv_c[8];
+    int pad_pre, pad_post, cell_px;   /* receptive-field padding (modules.py:68-105) */
+    int dtype;                 /* SPAIR_DTYPE_* */
+    int align_corners;         /* 0 = torch>=1.3 default (the pinned oracle), 1 = torch 1.0 era */
+    float anchor;              /* ANCHORBOX_SHAPE[0] */
+    float max_yx, min_yx, max_hw, min_hw;
+    float obj_logit_scale, alpha_logit_scale, alpha_logit_bias;
+    float vae_beta;            /* VAE_BETA (config.py:55) */
+    float prior_mean[6], prior_std[6];   /* cy, cx, height, width, attr, depth (config.py:45-52) */
+} SpairDims;
+
+/* Per-step scalars (host side evaluates the two schedules, modules.py:191-213). */
+typedef struct SpairStep {
+    float wheel;               /* LATENT_VAR_TRAINING_WHEEL value */
+    float count_prior_prob;    /* 1/(1+exp(-log(v+1e-6))), models.py:186-188 */
+    float kl_scale;            /* 1/(B*world_size): batch-mean of the KL terms (models.py:553) */
+    int train;                 /* 1: keep what backward needs */
+} SpairStep;
+
+/* ---- parameter / workspace layout -------------------------------------------------------- */
+/* Flat fp32 parameter buffer; tensor i of the reference state_dict (same key, same shape). */
+int spair_param_count(const SpairDims* d);
+int spair_param_info(const SpairDims* d, int idx, char* name, int name_cap, int64_t* offset, int64_t* shape4, int* ndim);
+int64_t spair_param_total(const SpairDims* d);
+int64_t spair_workspace_bytes(const SpairDims* d);
+
+/* ---- the training step ---------------------------------------------------------------------
+ * forward  == SPAIR.forward (models.py:35-131): backbone -> per-cell loop -> KL -> render -> loss.
+ *   loss_out[0]=total, [1]=BCE sum, [2..8]=KL cy,cx,height,width,attr,depth,pres (batch means).
+ * backward == loss.backward() (train.py:66): accumulates into `grads` (same layout as params).
+ * Noise maps are NCHW: eps_box[B,4,G,G] (cy,cx,height,width), eps_attr[B,A,G,G],
+ * eps_depth[B,1,G,G], u_pres[B,1,G,G]. */
+int spair_forward(const SpairDims* d, const SpairStep* st, const float* params, const float* x,
+                  const float* eps_box, const float* eps_attr, const float* eps_depth, const float* u_pres,
+                  void* workspace, float* loss_out, float* recon, float* z_where, float* z_pres, void* stream);
+int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x,
+                   const float* eps_box, const float* eps_attr, const float* eps_depth, const float* u_pres,
+                   void* workspace, const float* grad_loss, float* grads, void* stream);
+/* torch.optim.Adam(lr) defaults (train.py:44) on flat buffers, one launch. */
+int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+               float beta1, float beta2, float eps, int step, void* stream);
+/* Copy a per-row quantity of the last forward into an NCHW map [B,ch,G,G].
+ * which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 their sigma, 14 count-prior p_z */
+int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream);
+int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
+
+/* ---- unit-level entry points (each kernel can be parity-checked alone) --------------------- */
+int spair_gemm_nt(const float* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                  const float* bias, const float* relu_mask, int ldmask, int relu, int accumulate, int dtype,
+                  void* stream);
+int spair_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
+                  void* stream);
+int spair_gemm_nt_conv(const float* In, const int* conv13, const void* B, int ldb, float* C, int ldc, int M,
+                       int N, int K, const float* bias, const float* relu_mask, int ldmask, int relu,
+                       int accumulate, const int* cmap8, int dtype, void* stream);
+int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
+                       int N, int R, void* stream);
+int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
+/* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);
+ * row r samples image x[r % B], nbox[r] = (xt,yt,xs,ys) */
+int spair_stn_glimpse_fwd(const float* x, const float* nbox, int B, float* glimpse, int ld_gl, int R, int C,
+                          int I, int P, int align_corners, void* stream);
+int spair_stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dglimpse, int ld_gl,
+                          float* dnbox, int R, int C, int I, int P, int align_corners, void* stream);
+/* renderer: inverse STN + importance-weighted composite + BCE (models.py:485-547) */
+int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
+                     const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P,
+                     int align_corners, void* stream);
+int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
+                     const float* aux, const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth,
+                     int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
+#ifdef __cplusplus
+}
+#endif

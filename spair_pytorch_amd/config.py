@@ -1,0 +1,80 @@
+"""Hyper-parameter surface of the SPAIR step.
+
+Same module-level constant names (and default values) as the reference's flag system,
+/root/reference/spair/config.py:3-81, so code written against ``spair.config`` keeps
+working with ``from spair_pytorch_amd import config as cfg``.  Additions (GEMM operand
+dtype, align_corners) are at the bottom and clearly marked.
+"""
+import os
+
+BATCH_SIZE = 32
+INPUT_IMAGE_SHAPE = [1, 128, 128]
+
+DEFAULT_MLP_TOPOLOGY = [100, 100]
+DEFAULT_BACKBONE_TOPOLOGY = [
+    dict(filters=128, kernel_size=4, stride=3),
+    dict(filters=128, kernel_size=4, stride=2),
+    dict(filters=128, kernel_size=4, stride=2),
+    dict(filters=128, kernel_size=1, stride=1),
+    dict(filters=128, kernel_size=1, stride=1),
+    dict(filters=128, kernel_size=1, stride=1),
+]
+# The reference's conv object encoder/decoder built from this is non-functional
+# (models.py:606-665); kept for name parity only.
+CONV_OBJECT_ENCODER_TOPOLOGY = [
+    dict(filters=32, kernel_size=4, stride=2),
+    dict(filters=32, kernel_size=3, stride=2),
+    dict(filters=32, kernel_size=3, stride=2),
+    dict(filters=32, kernel_size=1, stride=1),
+]
+
+N_BACKBONE_FEATURES = 100
+N_PASSTHROUGH_FEATURES = 100
+
+N_ATTRIBUTES = 50
+N_CONTEXT_DIM = 4 + N_ATTRIBUTES + 1 + 1
+
+N_LOOKBACK = 1
+
+OBJECT_SHAPE = [28, 28]
+ANCHORBOX_SHAPE = [48, 48]
+
+MAX_YX = 1.5
+MIN_YX = -0.5
+MAX_HW = 1.0
+MIN_HW = 0.0
+
+PRIORS = {
+    'cy_logit': [0., 1.],
+    'cx_logit': [0., 1.],
+    'height_logit': [7.00, 0.5],
+    'width_logit': [7.00, 0.5],
+    'attr': [0., 1.],
+    'depth_logit': [0., 1.],
+}
+
+VAE_BETA = 1
+
+LATENT_VAR_TRAINING_WHEEL_PARAM = dict(start=1.0, end=0.0, decay_rate=0.0, decay_step=1000., staircase=True)
+
+OBJ_PRES_COUNT_LOG_PRIOR = dict(start=1000000.0, end=0.0125, decay_rate=0.1, decay_step=1000., log_space=True)
+
+OBJ_LOGIT_SCALE = 2.0
+ALPHA_LOGIT_SCALE = 0.1
+ALPHA_LOGIT_BIAS = 5.0
+
+IS_LOCAL = 'LOCAL' in os.environ
+
+# ---- additions of this implementation (not in the reference) ---------------------------------
+# GEMM / conv operand type on the MI355X: 'bf16' (MFMA bf16 inputs, fp32 accumulate) or 'f32'
+# (exact fp32 MFMA).  Everything else (sampling, STN, compositing, KL, loss, Adam) is fp32.
+COMPUTE_DTYPE = os.environ.get('SPAIR_DTYPE', 'bf16')
+# torch>=1.3 semantics (what the CPU oracle is pinned to); True reproduces the torch-1.0 era.
+ALIGN_CORNERS = False
+
+
+def set_grid(image_side, strides):
+    """Convenience for non-default geometries (e.g. 8-px cells: strides [2,2,2,1,1,1])."""
+    INPUT_IMAGE_SHAPE[1] = INPUT_IMAGE_SHAPE[2] = int(image_side)
+    for layer, s in zip(DEFAULT_BACKBONE_TOPOLOGY, strides):
+        layer['stride'] = int(s)

@@ -1,0 +1,602 @@
+// Host orchestration of the SPAIR training step behind the C ABI (include/spair_hip.h):
+// workspace carving, per-step weight preparation, the backbone, the dependency-wavefront loop of
+// the per-cell encoder (3G-2 dependent steps instead of the reference's G^2),
+// decoder + renderer + KL, and the hand-written backward of all of it.
+// Nothing here synchronises or allocates: every launch goes to the caller's stream.
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+
+#include "cells.h"
+#include "gemm.h"
+#include "misc.h"
+
+// kernels in other translation units
+int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, hipStream_t s);
+int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, int ld, float* dnbox, int r0, int R, int C, int I, int P, int ac, hipStream_t s);
+int render_sprite_act(float* S, int ld, int N, int per, int CH, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);
+int render_num_blocks(int B, int I);
+int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s);
+int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, hipStream_t s);
+int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
+int loss_gauss_kl_blocks(const CellLayout& L);
+int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
+int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale, float beta, float* loss_out, hipStream_t s);
+
+#define TRY(expr)                      \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != SPAIR_OK) return rc__; \
+    } while (0)
+
+static int validate(const SpairDims& d) {
+    if (d.B <= 0 || d.I <= 0 || d.G <= 0 || d.P <= 0 || d.A <= 0 || d.F <= 0 || d.NP <= 0) return SPAIR_ERR_SHAPE;
+    if (d.C != 1) return SPAIR_ERR_UNSUPPORTED;            // renderer / sprites: greyscale only for now
+    if (d.n_conv < 1 || d.n_conv > SP_MAX_CONV) return SPAIR_ERR_SHAPE;
+    if (d.dtype != SPAIR_F32 && d.dtype != SPAIR_BF16) return SPAIR_ERR_DTYPE;
+    if ((d.F & 3) || (d.NP & 3)) return SPAIR_ERR_ALIGN;
+    int h = d.I + d.pad_pre + d.pad_post;
+    for (int i = 0; i < d.n_conv; ++i) {
+        if (d.conv_k[i] < 1 || d.conv_s[i] < 1 || (d.conv_c[i] & 7)) return SPAIR_ERR_SHAPE;
+        if (i > 0 && d.conv_k[i] > 1 && (d.conv_k[i] % d.conv_s[i] != 0 || d.conv_s[i] > 2)) return SPAIR_ERR_UNSUPPORTED;
+        if (i > 0 && d.conv_k[i] == 1 && d.conv_s[i] != 1) return SPAIR_ERR_UNSUPPORTED;
+        h = (h - d.conv_k[i]) / d.conv_s[i] + 1;
+    }
+    if (h != d.G) return SPAIR_ERR_SHAPE;
+    if (d.G * d.G + 1 > 1025) return SPAIR_ERR_UNSUPPORTED;
+    return SPAIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+struct Ws {
+    int *cell_h, *cell_w, *cidx, *nbr, *cons, *diag_start;
+    void* conv_wf[SP_MAX_CONV + 1];
+    void* conv_wd[SP_MAX_CONV + 1][4];
+    void* lin_wf[LIN_COUNT];     // heads: BOXH1 / ZH1 slots hold the concatenated [pass | lat] matrix
+    void* lin_wt[LIN_COUNT];
+    float *bias_boxh, *bias_zh;
+    float* xpad;
+    float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
+    float *feat, *dfeat;
+    CellBufs cb;
+    float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;
+    float *aux, *bce_partial, *kl_partial, *klp;
+    int ld_feat, ld_s;
+    size_t total;
+};
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <class T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+    void* take_bytes(size_t n) { return take<char>(n); }
+};
+
+static Ws carve(const SpairDims& d, void* base) {
+    Ws w;
+    memset(&w, 0, sizeof(w));
+    const CellLayout L = make_cell_layout(d);
+    const ParamLayout PL = make_param_layout(d);
+    Carver c{reinterpret_cast<char*>(base), 0};
+    const size_t es = d.dtype == SPAIR_BF16 ? 2 : 4;
+    const size_t N = (size_t)L.N;
+    w.cell_h = c.take<int>(L.HW); w.cell_w = c.take<int>(L.HW); w.cidx = c.take<int>(L.HW);
+    w.nbr = c.take<int>(4 * L.HW); w.cons = c.take<int>(4 * L.HW); w.diag_start = c.take<int>(3 * L.G + 2);
+    // prepared weights
+    for (int i = 1; i < PL.n_conv; ++i) {
+        const ConvSpec& cs = PL.conv[i];
+        const size_t K = (size_t)cs.k * cs.k * cs.cin;
+        w.conv_wf[i] = c.take_bytes((size_t)cs.cout * round_up((int)K, 8) * es);
+        if (cs.k == 1) w.conv_wd[i][0] = c.take_bytes((size_t)cs.cin * round_up(cs.cout, 8) * es);
+        else for (int q = 0; q < cs.s * cs.s; ++q) {
+            const int T = cs.k / cs.s;
+            w.conv_wd[i][q] = c.take_bytes((size_t)cs.cin * T * T * cs.cout * es);
+        }
+    }
+    auto lin_alloc = [&](int id, int rows_total) {
+        w.lin_wf[id] = c.take_bytes((size_t)rows_total * round_up(PL.lin[id].in, 8) * es);
+        w.lin_wt[id] = c.take_bytes((size_t)PL.lin[id].in * round_up(rows_total, 8) * es);
+    };
+    for (int id = 0; id < LIN_COUNT; ++id) {
+        if (id == LIN_BOXH0 || id == LIN_ZH0) continue;
+        int rows = PL.lin[id].out;
+        if (id == LIN_BOXH1) rows += PL.lin[LIN_BOXH0].out;
+        if (id == LIN_ZH1) rows += PL.lin[LIN_ZH0].out;
+        lin_alloc(id, rows);
+    }
+    w.bias_boxh = c.take<float>(L.NP + 8);
+    w.bias_zh = c.take<float>(L.NP + 8);
+    // backbone
+    const int Ip = d.I + d.pad_pre + d.pad_post;
+    w.xpad = c.take<float>((size_t)d.B * Ip * Ip * d.C);
+    for (int i = 0; i < d.n_conv; ++i) {
+        const ConvSpec& cs = PL.conv[i];
+        const size_t n = (size_t)d.B * cs.hout * cs.hout * cs.cout;
+        w.act[i] = c.take<float>(n);
+        w.dact[i] = c.take<float>(n);
+    }
+    w.ld_feat = round_up(d.F, 8);
+    w.feat = c.take<float>(N * w.ld_feat);
+    w.dfeat = c.take<float>(N * w.ld_feat);
+    // per-cell chain
+    CellBufs& b = w.cb;
+    b.cell_h = w.cell_h; b.cell_w = w.cell_w; b.cidx = w.cidx; b.nbr = w.nbr; b.cons = w.cons; b.diag_start = w.diag_start;
+    b.feat = w.feat; b.ld_feat = w.ld_feat; b.dfeat = w.dfeat;
+    b.Xb = c.take<float>(N * L.ld_xb); b.Hb1 = c.take<float>(N * SP_LDH); b.Hb2 = c.take<float>(N * SP_LDH); b.Ob = c.take<float>(N * L.ld_ob);
+    b.glimpse = c.take<float>(N * L.ld_gl); b.He1 = c.take<float>(N * SP_ENC_H1); b.He2 = c.take<float>(N * SP_ENC_H2); b.Oe = c.take<float>(N * L.ld_oe);
+    b.Xz = c.take<float>(N * L.ld_x); b.Hz1 = c.take<float>(N * SP_LDH); b.Hz2 = c.take<float>(N * SP_LDH); b.Oz = c.take<float>(N * L.ld_oz);
+    b.Xo = c.take<float>(N * L.ld_x); b.Ho1 = c.take<float>(N * SP_LDH); b.Ho2 = c.take<float>(N * SP_LDH); b.Oo = c.take<float>(N * L.ld_oo);
+    b.rec = c.take<float>(N * L.ld_rec); b.sd_attr = c.take<float>(N * L.ld_rec); b.nbox = c.take<float>(N * 4); b.stat = c.take<float>(N * SP_LDSTAT);
+    b.dXb = c.take<float>(N * L.ld_xb); b.dHb1 = c.take<float>(N * SP_LDH); b.dHb2 = c.take<float>(N * SP_LDH); b.dOb = c.take<float>(N * L.ld_ob);
+    b.dGl = c.take<float>(N * L.ld_gl); b.dHe1 = c.take<float>(N * SP_ENC_H1); b.dHe2 = c.take<float>(N * SP_ENC_H2); b.dOe = c.take<float>(N * L.ld_oe);
+    b.dXz = c.take<float>(N * L.ld_x); b.dHz1 = c.take<float>(N * SP_LDH); b.dHz2 = c.take<float>(N * SP_LDH); b.dOz = c.take<float>(N * L.ld_oz);
+    b.dXo = c.take<float>(N * L.ld_x); b.dHo1 = c.take<float>(N * SP_LDH); b.dHo2 = c.take<float>(N * SP_LDH); b.dOo = c.take<float>(N * L.ld_oo);
+    b.grec = c.take<float>(N * L.ld_rec); b.g_nbox_stn = c.take<float>(N * 4);
+    b.g_nbox_r = c.take<float>(N * 4); b.g_pres_r = c.take<float>(N); b.g_depth_r = c.take<float>(N); b.g_attr_r = c.take<float>(N * L.ld_rec);
+    // decoder / renderer / loss
+    w.ld_s = round_up(d.P * d.P * (d.C + 1), 8);
+    w.Za = c.take<float>(N * L.ld_rec);
+    b.Za = w.Za;
+    w.Hd1 = c.take<float>(N * SP_DEC_H1); w.Hd2 = c.take<float>(N * SP_DEC_H2); w.S = c.take<float>(N * w.ld_s);
+    w.dLog = c.take<float>(N * w.ld_s); w.dHd2 = c.take<float>(N * SP_DEC_H2); w.dHd1 = c.take<float>(N * SP_DEC_H1);
+    w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
+    w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
+    w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
+    w.klp = c.take<float>(d.B);
+    w.total = (c.off + 255) & ~(size_t)255;
+    return w;
+}
+
+extern "C" int64_t spair_workspace_bytes(const SpairDims* d) {
+    if (!d || validate(*d) != SPAIR_OK) return -1;
+    return (int64_t)carve(*d, nullptr).total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter naming (reference state_dict keys)
+// ---------------------------------------------------------------------------------------------
+struct PInfo { char name[96]; int64_t off; int64_t shape[4]; int ndim; };
+
+static std::vector<PInfo> param_infos(const SpairDims& d) {
+    const ParamLayout P = make_param_layout(d);
+    const CellLayout L = make_cell_layout(d);
+    std::vector<PInfo> v;
+    auto add = [&](const char* nm, int64_t off, int nd, int64_t s0, int64_t s1 = 1, int64_t s2 = 1, int64_t s3 = 1) {
+        PInfo p;
+        snprintf(p.name, sizeof(p.name), "%s", nm);
+        p.off = off; p.ndim = nd; p.shape[0] = s0; p.shape[1] = s1; p.shape[2] = s2; p.shape[3] = s3;
+        v.push_back(p);
+    };
+    char buf[96];
+    add("virtual_edge_element", P.edge, 1, L.REC);
+    for (int i = 0; i < d.n_conv; ++i) {
+        const ConvSpec& c = P.conv[i];
+        snprintf(buf, sizeof(buf), "backbone.net.conv_%d.weight", i); add(buf, c.w, 4, c.cout, c.cin, c.k, c.k);
+        snprintf(buf, sizeof(buf), "backbone.net.conv_%d.bias", i); add(buf, c.b, 1, c.cout);
+    }
+    {
+        const ConvSpec& c = P.conv[d.n_conv];
+        add("backbone.net.conv_out.weight", c.w, 4, c.cout, c.cin, 1, 1);
+        add("backbone.net.conv_out.bias", c.b, 1, c.cout);
+    }
+    auto lin = [&](const char* nm, int id) {
+        snprintf(buf, sizeof(buf), "%s.weight", nm); add(buf, P.lin[id].w, 2, P.lin[id].out, P.lin[id].in);
+        snprintf(buf, sizeof(buf), "%s.bias", nm); add(buf, P.lin[id].b, 1, P.lin[id].out);
+    };
+    lin("box_network.body.dense0", LIN_BOX0); lin("box_network.body.dense1", LIN_BOX1);
+    lin("box_network.output_layers.0", LIN_BOXH0); lin("box_network.output_layers.1", LIN_BOXH1);
+    lin("object_encoder.dense0", LIN_ENC0); lin("object_encoder.dense1", LIN_ENC1); lin("object_encoder.out", LIN_ENC2);
+    lin("z_network.body.dense0", LIN_Z0); lin("z_network.body.dense1", LIN_Z1);
+    lin("z_network.output_layers.0", LIN_ZH0); lin("z_network.output_layers.1", LIN_ZH1);
+    lin("obj_network.dense0", LIN_OBJ0); lin("obj_network.dense1", LIN_OBJ1); lin("obj_network.out", LIN_OBJ2);
+    lin("object_decoder.dense0", LIN_DEC0); lin("object_decoder.dense1", LIN_DEC1); lin("object_decoder.out", LIN_DEC2);
+    const int ad = 4 + d.A + 1;
+    add("attn.gamma", P.attn_gamma, 1, 1);
+    add("attn.query_conv.weight", P.attn_q_w, 4, ad / 8, ad, 1, 1); add("attn.query_conv.bias", P.attn_q_b, 1, ad / 8);
+    add("attn.key_conv.weight", P.attn_k_w, 4, ad / 8, ad, 1, 1); add("attn.key_conv.bias", P.attn_k_b, 1, ad / 8);
+    add("attn.value_conv.weight", P.attn_v_w, 4, ad, ad, 1, 1); add("attn.value_conv.bias", P.attn_v_b, 1, ad);
+    return v;
+}
+
+extern "C" int spair_param_count(const SpairDims* d) { return d ? (int)param_infos(*d).size() : -1; }
+extern "C" int64_t spair_param_total(const SpairDims* d) { return d ? make_param_layout(*d).total : -1; }
+extern "C" int spair_param_info(const SpairDims* d, int idx, char* name, int name_cap, int64_t* offset, int64_t* shape4, int* ndim) {
+    if (!d) return SPAIR_ERR_SHAPE;
+    const std::vector<PInfo> v = param_infos(*d);
+    if (idx < 0 || idx >= (int)v.size()) return SPAIR_ERR_SHAPE;
+    snprintf(name, name_cap, "%s", v[idx].name);
+    *offset = v[idx].off;
+    for (int i = 0; i < 4; ++i) shape4[i] = v[idx].shape[i];
+    *ndim = v[idx].ndim;
+    return SPAIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step context
+// ---------------------------------------------------------------------------------------------
+struct Ctx {
+    SpairDims d;
+    SpairStep st;
+    CellLayout L;
+    ParamLayout PL;
+    Ws w;
+    CellHyper H;
+    const float* params;
+    const float* x;
+    hipStream_t s;
+    int T;                 // number of wavefront diagonals
+    std::vector<int> dstart;
+};
+
+static void fill_diag(Ctx& c) {
+    const int G = c.d.G;
+    c.T = 3 * G - 2;
+    c.dstart.assign(c.T + 1, 0);
+    int n = 0;
+    for (int t = 0; t < c.T; ++t) {
+        c.dstart[t] = n;
+        for (int h = 0; h < G; ++h) {
+            const int w = t - 2 * h;
+            if (w >= 0 && w < G) ++n;
+        }
+    }
+    c.dstart[c.T] = n;
+}
+
+static int make_ctx(Ctx& c, const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
+                    const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace, void* stream) {
+    if (!d || !st || !params || !x || !workspace) return SPAIR_ERR_SHAPE;
+    TRY(validate(*d));
+    c.d = *d; c.st = *st;
+    c.L = make_cell_layout(*d);
+    c.PL = make_param_layout(*d);
+    c.w = carve(*d, workspace);
+    c.params = params; c.x = x; c.s = (hipStream_t)stream;
+    CellHyper& H = c.H;
+    H.wheel = st->wheel; H.kl_scale = st->kl_scale * d->vae_beta; H.img = (float)d->I; H.anchor = d->anchor;
+    H.cell_over_img = (float)((double)d->cell_px / (double)d->I);
+    H.max_yx = d->max_yx; H.min_yx = d->min_yx; H.max_hw = d->max_hw; H.min_hw = d->min_hw;
+    for (int i = 0; i < 6; ++i) { H.prior_mean[i] = d->prior_mean[i]; H.prior_std[i] = d->prior_std[i]; }
+    H.count_prior_prob = st->count_prior_prob;
+    c.w.cb.edge = params + c.PL.edge;
+    c.w.cb.eps_box = eps_box; c.w.cb.eps_attr = eps_attr; c.w.cb.eps_depth = eps_depth; c.w.cb.u_pres = u_pres;
+    fill_diag(c);
+    return SPAIR_OK;
+}
+
+// ---- GEMM helpers ---------------------------------------------------------------------------------
+static int nt(Ctx& c, const float* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
+              const float* mask, int ldmask, int relu) {
+    GemmNT g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.relu = relu;
+    return spair_gemm_nt_impl(g, false, c.d.dtype, c.s);
+}
+static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, int R) {
+    GemmTN g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R;
+    return spair_gemm_tn_impl(g, false, c.s);
+}
+static const void* bptr(const void* base, size_t elem_off, int dtype) {
+    return reinterpret_cast<const char*>(base) + elem_off * (dtype == SPAIR_BF16 ? 2 : 4);
+}
+
+// ---- weight preparation ----------------------------------------------------------------------------
+static int prep_weights(Ctx& c, bool need_dgrad) {
+    std::vector<PrepEntry> es;
+    const int bf = c.d.dtype == SPAIR_BF16;
+    auto push = [&](const float* src, void* dst, int rows, int cols, int ld, int mode, int bf16, int cin = 0, int cout = 0, int k = 0,
+                    int py = 0, int px = 0, int T = 0, int s = 0) {
+        PrepEntry e;
+        e.src = src; e.dst = dst; e.rows = rows; e.cols = cols; e.ld = ld; e.mode = mode; e.bf16 = bf16;
+        e.cin = cin; e.cout = cout; e.k = k; e.py = py; e.px = px; e.T = T; e.s = s;
+        es.push_back(e);
+    };
+    for (int i = 1; i < c.PL.n_conv; ++i) {
+        const ConvSpec& cs = c.PL.conv[i];
+        const float* w = c.params + cs.w;
+        const int K = cs.k * cs.k * cs.cin;
+        if (cs.k == 1) {
+            push(w, c.w.conv_wf[i], cs.cout, cs.cin, round_up(K, 8), 0, bf);
+            if (need_dgrad) push(w, c.w.conv_wd[i][0], cs.cin, cs.cout, round_up(cs.cout, 8), 1, bf);
+        } else {
+            push(w, c.w.conv_wf[i], cs.cout, K, round_up(K, 8), 2, bf, cs.cin, cs.cout, cs.k);
+            if (need_dgrad) {
+                const int T = cs.k / cs.s;
+                for (int py = 0; py < cs.s; ++py)
+                    for (int px = 0; px < cs.s; ++px)
+                        push(w, c.w.conv_wd[i][py * cs.s + px], cs.cin, T * T * cs.cout, T * T * cs.cout, 3, bf, cs.cin, cs.cout, cs.k, py, px, T, cs.s);
+            }
+        }
+    }
+    for (int id = 0; id < LIN_COUNT; ++id) {
+        if (id == LIN_BOXH0 || id == LIN_ZH0) continue;
+        const LinSpec& l = c.PL.lin[id];
+        const int ldf = round_up(l.in, 8);
+        int head0 = -1;
+        if (id == LIN_BOXH1) head0 = LIN_BOXH0;
+        if (id == LIN_ZH1) head0 = LIN_ZH0;
+        const int rows_total = l.out + (head0 >= 0 ? c.PL.lin[head0].out : 0);
+        const int ldt = round_up(rows_total, 8);
+        push(c.params + l.w, c.w.lin_wf[id], l.out, l.in, ldf, 0, bf);
+        if (need_dgrad) push(c.params + l.w, c.w.lin_wt[id], l.in, l.out, ldt, 1, bf);
+        if (head0 >= 0) {
+            const LinSpec& h = c.PL.lin[head0];
+            push(c.params + h.w, const_cast<void*>(bptr(c.w.lin_wf[id], (size_t)l.out * ldf, c.d.dtype)), h.out, h.in, ldf, 0, bf);
+            if (need_dgrad) push(c.params + h.w, const_cast<void*>(bptr(c.w.lin_wt[id], (size_t)l.out, c.d.dtype)), h.in, h.out, ldt, 1, bf);
+        }
+    }
+    push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
+    push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
+    push(c.params + c.PL.lin[LIN_ZH1].b, c.w.bias_zh, 1, c.L.NP, c.L.NP + 8, 0, 0);
+    push(c.params + c.PL.lin[LIN_ZH0].b, c.w.bias_zh + c.L.NP, 1, 2, 8, 0, 0);
+    for (size_t i = 0; i < es.size(); i += SP_MAX_PREP) {
+        PrepTable T;
+        T.n = (int)std::min((size_t)SP_MAX_PREP, es.size() - i);
+        for (int j = 0; j < T.n; ++j) T.e[j] = es[i + j];
+        TRY(misc_prep(T, c.s));
+    }
+    return SPAIR_OK;
+}
+
+// ---- backbone ------------------------------------------------------------------------------------------
+static ConvDesc fwd_desc(const ConvSpec& cs) {
+    ConvDesc cd;
+    cd.Hin = cs.hin; cd.Win = cs.hin; cd.Cin = cs.cin; cd.Hout = cs.hout; cd.Wout = cs.hout; cd.kh = cs.k; cd.kw = cs.k;
+    cd.sy = cs.s; cd.sx = cs.s; cd.dky = 1; cd.dkx = 1; cd.oy = 0; cd.ox = 0;
+    return cd;
+}
+
+static int backbone_fwd(Ctx& c) {
+    const SpairDims& d = c.d;
+    const int Ip = d.I + d.pad_pre + d.pad_post;
+    TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, Ip, c.s));
+    const ConvSpec& c0 = c.PL.conv[0];
+    TRY(misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, c.s));
+    for (int i = 1; i < c.PL.n_conv; ++i) {
+        const ConvSpec& cs = c.PL.conv[i];
+        const bool last = (i == c.PL.n_conv - 1);
+        const int M = d.B * cs.hout * cs.hout, K = cs.k * cs.k * cs.cin;
+        float* out = last ? c.w.feat : c.w.act[i];
+        const int ldc = last ? c.w.ld_feat : cs.cout;
+        if (cs.k == 1) {
+            TRY(nt(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, M, cs.cout, round_up(K, 8), c.params + cs.b, nullptr, 0, last ? 0 : 1));
+        } else {
+            GemmNT g;
+            memset(&g, 0, sizeof(g));
+            g.A = c.w.act[i - 1]; g.B = c.w.conv_wf[i]; g.ldb = round_up(K, 8); g.C = out; g.ldc = ldc; g.M = M; g.N = cs.cout; g.K = K;
+            g.bias = c.params + cs.b; g.relu = last ? 0 : 1; g.conv = fwd_desc(cs);
+            TRY(spair_gemm_nt_impl(g, true, d.dtype, c.s));
+        }
+    }
+    return SPAIR_OK;
+}
+
+static int backbone_bwd(Ctx& c, float* grads) {
+    const SpairDims& d = c.d;
+    const int last = c.PL.n_conv - 1;
+    for (int i = last; i >= 1; --i) {
+        const ConvSpec& cs = c.PL.conv[i];
+        const int M = d.B * cs.hout * cs.hout;
+        const float* dout = (i == last) ? c.w.dfeat : c.w.dact[i];
+        const int ldd = (i == last) ? c.w.ld_feat : cs.cout;
+        const float* in = c.w.act[i - 1];
+        // weight + bias gradients
+        if (cs.k == 1) {
+            TRY(tn(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, grads + cs.w, cs.cin, M));
+        } else {
+            GemmTN g;
+            memset(&g, 0, sizeof(g));
+            const int K = cs.k * cs.k * cs.cin;
+            g.A = dout; g.lda = ldd; g.B = in; g.C = grads + cs.w; g.ldc = K; g.M = round_up(cs.cout, 4); g.N = K; g.Mstore = cs.cout; g.Nstore = K;
+            g.R = M; g.cw_cin = cs.cin; g.cw_taps = cs.k * cs.k; g.conv = fwd_desc(cs);
+            TRY(spair_gemm_tn_impl(g, true, c.s));
+        }
+        TRY(spair_colsum_impl(dout, ldd, M, cs.cout, grads + cs.b, c.s));
+        // data gradient into dact[i-1] (masked by relu of act[i-1])
+        if (cs.k == 1) {
+            const int Kd = round_up(cs.cout, 8);
+            TRY(nt(c, dout, ldd, c.w.conv_wd[i][0], Kd, c.w.dact[i - 1], cs.cin, M, cs.cin, Kd, nullptr, in, cs.cin, 0));
+        } else {
+            const int T = cs.k / cs.s;
+            for (int py = 0; py < cs.s; ++py)
+                for (int px = 0; px < cs.s; ++px) {
+                    const int Hc = (cs.hin - py + cs.s - 1) / cs.s, Wc = (cs.hin - px + cs.s - 1) / cs.s;
+                    if (Hc <= 0 || Wc <= 0) continue;
+                    GemmNT g;
+                    memset(&g, 0, sizeof(g));
+                    g.A = dout; g.B = c.w.conv_wd[i][py * cs.s + px]; g.ldb = T * T * cs.cout; g.C = c.w.dact[i - 1]; g.ldc = cs.cin;
+                    g.M = d.B * Hc * Wc; g.N = cs.cin; g.K = T * T * cs.cout; g.mask = in; g.ldmask = cs.cin;
+                    g.conv.Hin = cs.hout; g.conv.Win = cs.hout; g.conv.Cin = cs.cout; g.conv.Hout = Hc; g.conv.Wout = Wc;
+                    g.conv.kh = T; g.conv.kw = T; g.conv.sy = 1; g.conv.sx = 1; g.conv.dky = -1; g.conv.dkx = -1; g.conv.oy = 0; g.conv.ox = 0;
+                    g.use_cmap = 1;
+                    g.cmap.Hout = Hc; g.cmap.Wout = Wc; g.cmap.Hc = cs.hin; g.cmap.Wc = cs.hin; g.cmap.osy = cs.s; g.cmap.osx = cs.s;
+                    g.cmap.ooy = py; g.cmap.oox = px;
+                    TRY(spair_gemm_nt_impl(g, true, d.dtype, c.s));
+                }
+        }
+    }
+    const ConvSpec& c0 = c.PL.conv[0];
+    TRY(misc_conv0_wgrad(c.w.xpad, c.w.dact[0], grads + c0.w, d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, c.s));
+    TRY(spair_colsum_impl(c.w.dact[0], c0.cout, d.B * c0.hout * c0.hout, c0.cout, grads + c0.b, c.s));
+    return SPAIR_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+static int fwd_lin(Ctx& c, int id, const float* A, int lda, float* C, int ldc, int r0, int R, const float* bias, int N, int relu) {
+    const int K = round_up(c.PL.lin[id].in, 8);
+    return nt(c, A + (size_t)r0 * lda, lda, c.w.lin_wf[id], K, C + (size_t)r0 * ldc, ldc, R, N, K, bias, nullptr, 0, relu);
+}
+
+static int cells_fwd(Ctx& c) {
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const ParamLayout& PL = c.PL;
+    const float* pr = c.params;
+    for (int t = 0; t < c.T; ++t) {
+        const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
+        TRY(cells_ctx_gather(L, P, r0, R, c.s));
+        // z_where
+        TRY(fwd_lin(c, LIN_BOX0, P.Xb, L.ld_xb, P.Hb1, SP_LDH, r0, R, pr + PL.lin[LIN_BOX0].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_BOX1, P.Hb1, SP_LDH, P.Hb2, SP_LDH, r0, R, pr + PL.lin[LIN_BOX1].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_BOXH1, P.Hb2, SP_LDH, P.Ob, L.ld_ob, r0, R, c.w.bias_boxh, L.NP + 8, 0));
+        TRY(cells_box_sample(L, P, c.H, r0, R, c.s));
+        // z_what
+        TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, c.s));
+        TRY(fwd_lin(c, LIN_ENC0, P.glimpse, L.ld_gl, P.He1, SP_ENC_H1, r0, R, pr + PL.lin[LIN_ENC0].b, SP_ENC_H1, 1));
+        TRY(fwd_lin(c, LIN_ENC1, P.He1, SP_ENC_H1, P.He2, SP_ENC_H2, r0, R, pr + PL.lin[LIN_ENC1].b, SP_ENC_H2, 1));
+        TRY(fwd_lin(c, LIN_ENC2, P.He2, SP_ENC_H2, P.Oe, L.ld_oe, r0, R, pr + PL.lin[LIN_ENC2].b, 2 * L.A, 0));
+        TRY(cells_attr_sample(L, P, r0, R, c.s));
+        // z_depth
+        TRY(fwd_lin(c, LIN_Z0, P.Xz, L.ld_x, P.Hz1, SP_LDH, r0, R, pr + PL.lin[LIN_Z0].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_Z1, P.Hz1, SP_LDH, P.Hz2, SP_LDH, r0, R, pr + PL.lin[LIN_Z1].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_ZH1, P.Hz2, SP_LDH, P.Oz, L.ld_oz, r0, R, c.w.bias_zh, L.NP + 2, 0));
+        TRY(cells_depth_sample(L, P, c.H, r0, R, c.s));
+        // z_pres
+        TRY(fwd_lin(c, LIN_OBJ0, P.Xo, L.ld_x, P.Ho1, SP_LDH, r0, R, pr + PL.lin[LIN_OBJ0].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_OBJ1, P.Ho1, SP_LDH, P.Ho2, SP_LDH, r0, R, pr + PL.lin[LIN_OBJ1].b, SP_H, 1));
+        TRY(fwd_lin(c, LIN_OBJ2, P.Ho2, SP_LDH, P.Oo, L.ld_oo, r0, R, pr + PL.lin[LIN_OBJ2].b, 1, 0));
+        TRY(cells_pres_sample(L, P, c.H, r0, R, c.s));
+    }
+    return SPAIR_OK;
+}
+
+extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
+                             const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace, float* loss_out,
+                             float* recon, float* z_where, float* z_pres, void* stream) {
+    Ctx c;
+    TRY(make_ctx(c, d, st, params, x, eps_box, eps_attr, eps_depth, u_pres, workspace, stream));
+    if (!loss_out || !recon || !z_where || !z_pres || !eps_box || !eps_attr || !eps_depth || !u_pres) return SPAIR_ERR_SHAPE;
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    P.z_where = z_where; P.z_pres = z_pres;
+    TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
+    TRY(prep_weights(c, st->train != 0));
+    TRY(backbone_fwd(c));
+    TRY(cells_fwd(c));
+    // decoder (models.py:474-492)
+    const ParamLayout& PL = c.PL;
+    const int N = L.N;
+    TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
+    TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
+    const int per = d->P * d->P * (d->C + 1);
+    TRY(fwd_lin(c, LIN_DEC2, c.w.Hd2, SP_DEC_H2, c.w.S, c.w.ld_s, 0, N, params + PL.lin[LIN_DEC2].b, per, 0));
+    TRY(render_sprite_act(c.w.S, c.w.ld_s, N, per, d->C + 1, d->obj_logit_scale, d->alpha_logit_scale, d->alpha_logit_bias, c.s));
+    // KL + render + loss
+    TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, c.s));
+    TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
+                   c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s));
+    TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, c.s));
+    TRY(loss_finalize(c.w.bce_partial, render_num_blocks(d->B, d->I), c.w.kl_partial, loss_gauss_kl_blocks(L), c.w.klp, d->B,
+                      st->kl_scale, d->vae_beta, loss_out, c.s));
+    return SPAIR_OK;
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------
+// dX[R, in] = dOut[R, out] . W   (+ relu mask of the layer below)
+static int bwd_lin(Ctx& c, int id, int out_total, const float* dOut, int ldo, float* dX, int ldx, int r0, int R, const float* mask, int ldmask) {
+    const int K = round_up(out_total, 8);
+    return nt(c, dOut + (size_t)r0 * ldo, ldo, c.w.lin_wt[id], K, dX + (size_t)r0 * ldx, ldx, R, c.PL.lin[id].in, K, nullptr,
+              mask ? mask + (size_t)r0 * ldmask : nullptr, ldmask, 0);
+}
+static int wgrad_lin(Ctx& c, int id, const float* dOut, int ldo, const float* In, int ldi, float* grads, int R) {
+    const LinSpec& l = c.PL.lin[id];
+    TRY(tn(c, dOut, ldo, l.out, In, ldi, l.in, grads + l.w, l.in, R));
+    return spair_colsum_impl(dOut, ldo, R, l.out, grads + l.b, c.s);
+}
+
+extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
+                              const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace,
+                              const float* grad_loss, float* grads, void* stream) {
+    Ctx c;
+    TRY(make_ctx(c, d, st, params, x, eps_box, eps_attr, eps_depth, u_pres, workspace, stream));
+    if (!grad_loss || !grads) return SPAIR_ERR_SHAPE;
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const ParamLayout& PL = c.PL;
+    P.gloss = grad_loss;
+    const int N = L.N;
+    const int per = d->P * d->P * (d->C + 1);
+    // renderer -> d logits, d z_where, d z_pres, d z_depth
+    TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
+                   P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
+                   d->alpha_logit_scale, c.s));
+    // decoder
+    TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N));
+    TRY(bwd_lin(c, LIN_DEC2, per, c.w.dLog, c.w.ld_s, c.w.dHd2, SP_DEC_H2, 0, N, c.w.Hd2, SP_DEC_H2));
+    TRY(wgrad_lin(c, LIN_DEC1, c.w.dHd2, SP_DEC_H2, c.w.Hd1, SP_DEC_H1, grads, N));
+    TRY(bwd_lin(c, LIN_DEC1, SP_DEC_H2, c.w.dHd2, SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 0, N, c.w.Hd1, SP_DEC_H1));
+    TRY(wgrad_lin(c, LIN_DEC0, c.w.dHd1, SP_DEC_H1, c.w.Za, L.ld_rec, grads, N));
+    TRY(bwd_lin(c, LIN_DEC0, SP_DEC_H1, c.w.dHd1, SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, nullptr, 0));
+    // per-cell chain, reverse wavefront order
+    for (int t = c.T - 1; t >= 0; --t) {
+        const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
+        TRY(cells_bwd_pres(L, P, c.H, r0, R, c.s));
+        TRY(bwd_lin(c, LIN_OBJ2, 1, P.dOo, L.ld_oo, P.dHo2, SP_LDH, r0, R, P.Ho2, SP_LDH));
+        TRY(bwd_lin(c, LIN_OBJ1, SP_H, P.dHo2, SP_LDH, P.dHo1, SP_LDH, r0, R, P.Ho1, SP_LDH));
+        TRY(bwd_lin(c, LIN_OBJ0, SP_H, P.dHo1, SP_LDH, P.dXo, L.ld_x, r0, R, nullptr, 0));
+        TRY(cells_bwd_depth(L, P, c.H, r0, R, c.s));
+        TRY(bwd_lin(c, LIN_ZH1, L.NP + 2, P.dOz, L.ld_oz, P.dHz2, SP_LDH, r0, R, P.Hz2, SP_LDH));
+        TRY(bwd_lin(c, LIN_Z1, SP_H, P.dHz2, SP_LDH, P.dHz1, SP_LDH, r0, R, P.Hz1, SP_LDH));
+        TRY(bwd_lin(c, LIN_Z0, SP_H, P.dHz1, SP_LDH, P.dXz, L.ld_x, r0, R, nullptr, 0));
+        TRY(cells_bwd_attr(L, P, c.H, r0, R, c.s));
+        TRY(bwd_lin(c, LIN_ENC2, 2 * L.A, P.dOe, L.ld_oe, P.dHe2, SP_ENC_H2, r0, R, P.He2, SP_ENC_H2));
+        TRY(bwd_lin(c, LIN_ENC1, SP_ENC_H2, P.dHe2, SP_ENC_H2, P.dHe1, SP_ENC_H1, r0, R, P.He1, SP_ENC_H1));
+        TRY(bwd_lin(c, LIN_ENC0, SP_ENC_H1, P.dHe1, SP_ENC_H1, P.dGl, L.ld_gl, r0, R, nullptr, 0));
+        TRY(stn_glimpse_bwd(x, P.nbox, L.B, P.dGl, L.ld_gl, P.g_nbox_stn, r0, R, d->C, d->I, d->P, d->align_corners, c.s));
+        TRY(cells_bwd_box(L, P, c.H, r0, R, c.s));
+        TRY(bwd_lin(c, LIN_BOXH1, L.NP + 8, P.dOb, L.ld_ob, P.dHb2, SP_LDH, r0, R, P.Hb2, SP_LDH));
+        TRY(bwd_lin(c, LIN_BOX1, SP_H, P.dHb2, SP_LDH, P.dHb1, SP_LDH, r0, R, P.Hb1, SP_LDH));
+        TRY(bwd_lin(c, LIN_BOX0, SP_H, P.dHb1, SP_LDH, P.dXb, L.ld_xb, r0, R, nullptr, 0));
+    }
+    TRY(cells_dfeat_edge(L, P, grads + PL.edge, c.s));
+    // weight gradients of the per-cell nets: one long-K GEMM per layer over all N rows
+    TRY(wgrad_lin(c, LIN_BOX0, P.dHb1, SP_LDH, P.Xb, L.ld_xb, grads, N));
+    TRY(wgrad_lin(c, LIN_BOX1, P.dHb2, SP_LDH, P.Hb1, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_BOXH1, P.dOb, L.ld_ob, P.Hb2, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_BOXH0, P.dOb + L.ob_lat, L.ld_ob, P.Hb2, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_ENC0, P.dHe1, SP_ENC_H1, P.glimpse, L.ld_gl, grads, N));
+    TRY(wgrad_lin(c, LIN_ENC1, P.dHe2, SP_ENC_H2, P.He1, SP_ENC_H1, grads, N));
+    TRY(wgrad_lin(c, LIN_ENC2, P.dOe, L.ld_oe, P.He2, SP_ENC_H2, grads, N));
+    TRY(wgrad_lin(c, LIN_Z0, P.dHz1, SP_LDH, P.Xz, L.ld_x, grads, N));
+    TRY(wgrad_lin(c, LIN_Z1, P.dHz2, SP_LDH, P.Hz1, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_ZH1, P.dOz, L.ld_oz, P.Hz2, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_ZH0, P.dOz + L.oz_lat, L.ld_oz, P.Hz2, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_OBJ0, P.dHo1, SP_LDH, P.Xo, L.ld_x, grads, N));
+    TRY(wgrad_lin(c, LIN_OBJ1, P.dHo2, SP_LDH, P.Ho1, SP_LDH, grads, N));
+    TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
+    TRY(backbone_bwd(c, grads));
+    return SPAIR_OK;
+}
+
+// which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 sigma, 14 count-prior p_z
+extern "C" int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream) {
+    if (!d || !workspace || !out) return SPAIR_ERR_SHAPE;
+    TRY(validate(*d));
+    const CellLayout L = make_cell_layout(*d);
+    const Ws w = carve(*d, const_cast<void*>(workspace));
+    const CellBufs& P = w.cb;
+    hipStream_t s = (hipStream_t)stream;
+    const float* src; int ld, col0, ch;
+    if (which == 0) { src = P.rec; ld = L.ld_rec; col0 = 4; ch = L.A; }
+    else if (which == 1) { src = P.rec; ld = L.ld_rec; col0 = 4 + L.A; ch = 1; }
+    else if (which >= 2 && which <= 5) { src = P.stat; ld = SP_LDSTAT; col0 = ST_MU_BOX + (which - 2); ch = 1; }
+    else if (which == 6) { src = P.Oe; ld = L.ld_oe; col0 = 0; ch = L.A; }
+    else if (which == 7) { src = P.stat; ld = SP_LDSTAT; col0 = ST_MU_DEPTH; ch = 1; }
+    else if (which >= 8 && which <= 11) { src = P.stat; ld = SP_LDSTAT; col0 = ST_SD_BOX + (which - 8); ch = 1; }
+    else if (which == 12) { src = P.sd_attr; ld = L.ld_rec; col0 = 0; ch = L.A; }
+    else if (which == 13) { src = P.stat; ld = SP_LDSTAT; col0 = ST_SD_DEPTH; ch = 1; }
+    else if (which == 14) { src = P.stat; ld = SP_LDSTAT; col0 = ST_PZ; ch = 1; }
+    else return SPAIR_ERR_SHAPE;
+    return misc_export(src, ld, col0, ch, w.cell_h, w.cell_w, d->B, d->G, out, s);
+}

@@ -1,0 +1,27 @@
+#pragma once
+#include "common.h"
+
+struct GemmNT {
+    const float* A; int lda;
+    const void* B; int ldb;
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const float* mask; int ldmask;
+    int relu, accumulate;
+    ConvDesc conv;
+    RowMap cmap; int use_cmap;
+};
+struct GemmTN {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int M, N, R;            // M, N: load extents (multiples of 4, may run into zero pad columns)
+    int Mstore, Nstore;     // store extents (<= M, N)
+    int cw_cin, cw_taps;    // if cw_cin > 0: n = tap*cin + ci is stored at column ci*taps + tap (OIHW conv weights)
+    int rows_per_split;
+    ConvDesc conv;
+};
+int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);
+int spair_gemm_tn_impl(GemmTN g, bool conv, hipStream_t s);
+int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s);

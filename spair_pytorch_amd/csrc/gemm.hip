@@ -1,0 +1,440 @@
+// MFMA GEMM core for the SPAIR hot path (gfx950 / CDNA4, wave64).
+//
+// Everything matmul-shaped in the step goes through the two kernels here:
+//   gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)   forward Linear / conv (implicit GEMM), data-grad
+//             (with a pre-transposed weight copy).  A may be a conv gather (ConvDesc).
+//   gemm_tn : C[M,N] += sum_r A[r,M] . B[r,N]      weight-grad, split over the long row dimension,
+//             fp32 atomics into a zeroed staging buffer.  B may be a conv gather.
+// Operands live in HBM as fp32 (weights optionally as bf16 copies); the MFMA type is chosen per
+// call: exact fp32 (v_mfma_f32_16x16x4_f32) or bf16 inputs / fp32 accumulate
+// (v_mfma_f32_16x16x32_bf16), conversion happening in registers on the way into LDS.
+// Fragment maps follow /opt/skills/guides/cdna_hip_programming.md §3:
+//   A: lane l holds A[row l&15][k-group l>>4], B: B[k-group l>>4][col l&15],
+//   C/D: lane l, reg r -> row (l>>4)*4 + r, col l&15.
+#include "common.h"
+#include "spair_hip.h"
+#include "gemm.h"
+
+template <int MMA> struct MmaTraits;
+template <> struct MmaTraits<SPAIR_F32> {
+    static constexpr int BK = 16, PAD = 4;
+    using lds_t = float;
+};
+template <> struct MmaTraits<SPAIR_BF16> {
+    static constexpr int BK = 32, PAD = 8;
+    using lds_t = __bf16;
+};
+
+
+__device__ __forceinline__ void conv_row_decode(const ConvDesc& c, int m, int& b, int& ybase, int& xbase) {
+    const int hw = c.Hout * c.Wout;
+    b = m / hw;
+    const int rem = m - b * hw;
+    const int y = rem / c.Wout;
+    const int x = rem - y * c.Wout;
+    ybase = y * c.sy + c.oy;
+    xbase = x * c.sx + c.ox;
+}
+
+// Load 4 consecutive k-elements (same tap: Cin % 4 == 0) of implicit-GEMM row (b,ybase,xbase).
+__device__ __forceinline__ float4 conv_load4(const float* __restrict__ In, const ConvDesc& c, int b, int ybase,
+                                             int xbase, int k) {
+    const int tap = k / c.Cin;
+    const int ci = k - tap * c.Cin;
+    const int ky = tap / c.kw;
+    const int kx = tap - ky * c.kw;
+    const int sy = ybase + ky * c.dky;
+    const int sx = xbase + kx * c.dkx;
+    if (sy < 0 || sy >= c.Hin || sx < 0 || sx >= c.Win) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t off = (((size_t)b * c.Hin + sy) * c.Win + sx) * c.Cin + ci;
+    return *reinterpret_cast<const float4*>(In + off);
+}
+
+template <int MMA, int BM, int BN, bool ACONV>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
+    using T = MmaTraits<MMA>;
+    using lds_t = typename T::lds_t;
+    constexpr int BK = T::BK, LD = BK + T::PAD;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int KQ = BK / 4;                    // float4 chunks per A row
+    constexpr int NA = BM * KQ / 256;             // float4 loads per thread for A
+    constexpr bool BF = (MMA == SPAIR_BF16);
+    constexpr int BQ = BF ? BK / 8 : BK / 4;      // 16-byte chunks per B row
+    constexpr int NB = BN * BQ / 256;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) lds_t As[BM * LD];
+    __shared__ __attribute__((aligned(16))) lds_t Bs[BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // per-thread staging coordinates
+    int a_row[NA], a_kq[NA], a_b[NA], a_y[NA], a_x[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * 256;
+        a_row[i] = f / KQ;
+        a_kq[i] = f - a_row[i] * KQ;
+        const int gm = m0 + a_row[i];
+        a_ok[i] = gm < g.M;
+        a_b[i] = a_y[i] = a_x[i] = 0;
+        if (ACONV && a_ok[i]) conv_row_decode(g.conv, gm, a_b[i], a_y[i], a_x[i]);
+    }
+    int b_row[NB], b_q[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + i * 256;
+        b_row[i] = f / BQ;
+        b_q[i] = f - b_row[i] * BQ;
+        b_ok[i] = (n0 + b_row[i]) < g.N;
+    }
+
+    float4 ra[NA];
+    uint4 rb[NB];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = k0 + a_kq[i] * 4;
+            if (a_ok[i] && k < g.K) {
+                if (ACONV) ra[i] = conv_load4(g.A, g.conv, a_b[i], a_y[i], a_x[i], k);
+                else ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + a_row[i]) * g.lda + k);
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = k0 + b_q[i] * (BF ? 8 : 4);
+            if (b_ok[i] && k < g.K) {
+                if (BF) rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(g.B) + (size_t)(n0 + b_row[i]) * g.ldb + k);
+                else rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(g.B) + (size_t)(n0 + b_row[i]) * g.ldb + k);
+            } else {
+                rb[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            lds_t* dst = &As[a_row[i] * LD + a_kq[i] * 4];
+            if constexpr (BF) {
+                bf16x4 v;
+                v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+                *reinterpret_cast<bf16x4*>(dst) = v;
+            } else {
+                *reinterpret_cast<float4*>(dst) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            lds_t* dst = &Bs[b_row[i] * LD + b_q[i] * (BF ? 8 : 4)];
+            *reinterpret_cast<uint4*>(dst) = rb[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = lane >> 4;
+        if constexpr (BF) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + kg * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + kg * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(arow + i * 16) * LD + kk * 4 + kg];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = Bs[(brow + j * 16) * LD + kk * 4 + kg];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // epilogue
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + rgrp + r;
+            if (m >= g.M) continue;
+            size_t crow;
+            if (g.use_cmap) {
+                const int hw = g.cmap.Hout * g.cmap.Wout;
+                const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
+                crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + g.cmap.ooy)) * g.cmap.Wc + (x * g.cmap.osx + g.cmap.oox);
+            } else {
+                crow = (size_t)m;
+            }
+            float* cptr = g.C + crow * g.ldc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n >= g.N) continue;
+                float v = acc[i][j][r];
+                if (g.bias) v += g.bias[n];
+                if (g.accumulate) v += cptr[n];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) v = (g.mask[crow * g.ldmask + n] > 0.f) ? v : 0.f;
+                cptr[n] = v;
+            }
+        }
+    }
+}
+
+template <int MMA, int BM, int BN>
+static int launch_nt(const GemmNT& g, bool conv, hipStream_t s) {
+    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN));
+    if (conv) hipLaunchKernelGGL((gemm_nt_kernel<MMA, BM, BN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<MMA, BM, BN, false>), grid, dim3(256), 0, s, g);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return SPAIR_ERR_SHAPE;
+    if ((g.K & 3) || (!conv && (g.lda & 3))) return SPAIR_ERR_ALIGN;
+    if (dtype == SPAIR_BF16 && ((g.K & 7) || (g.ldb & 7))) return SPAIR_ERR_ALIGN;
+    if (dtype == SPAIR_F32 && (g.ldb & 3)) return SPAIR_ERR_ALIGN;
+    if (conv && (g.conv.Cin & 3)) return SPAIR_ERR_ALIGN;
+    const bool big = (g.M >= 8192 && g.N >= 96);
+    if (dtype == SPAIR_BF16) return big ? launch_nt<SPAIR_BF16, 128, 128>(g, conv, s) : launch_nt<SPAIR_BF16, 64, 64>(g, conv, s);
+    if (dtype == SPAIR_F32) return big ? launch_nt<SPAIR_F32, 128, 128>(g, conv, s) : launch_nt<SPAIR_F32, 64, 64>(g, conv, s);
+    return SPAIR_ERR_DTYPE;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[M,N] += sum_r A[r, m] * B[r, n]   (weight gradients; fp32 MFMA, split over r, atomics)
+// ---------------------------------------------------------------------------------------------
+
+template <int BM, int BN, bool BCONV>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+    constexpr int BK = 16, LDA = BM + 16, LDB = BN + 16;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int NA = BK * BM / 4 / 256, NB = BK * BN / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int r_begin = blockIdx.z * g.rows_per_split;
+    const int r_end = min(g.R, r_begin + g.rows_per_split);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[NA], rb[NB];
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256, kr = f / (BM / 4), mq = f - kr * (BM / 4);
+            const int r = r0 + kr, m = m0 + mq * 4;
+            ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)r * g.lda + m)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            const int r = r0 + kr, n = n0 + nq * 4;
+            if (r < r_end && n < g.N) {
+                if (BCONV) {
+                    int b, yb, xb;
+                    conv_row_decode(g.conv, r, b, yb, xb);
+                    rb[i] = conv_load4(g.B, g.conv, b, yb, xb, n);
+                } else {
+                    rb[i] = *reinterpret_cast<const float4*>(g.B + (size_t)r * g.ldb + n);
+                }
+            } else {
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256, kr = f / (BM / 4), mq = f - kr * (BM / 4);
+            *reinterpret_cast<float4*>(&As[kr * LDA + mq * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            *reinterpret_cast<float4*>(&Bs[kr * LDB + nq * 4]) = rb[i];
+        }
+    };
+
+    if (r_begin < r_end) {
+        load_tiles(r_begin);
+        store_tiles();
+        __syncthreads();
+        for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+            const bool more = (r0 + BK) < r_end;
+            if (more) load_tiles(r0 + BK);
+            const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(kk * 4 + kg) * LDA + arow + i * 16];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = Bs[(kk * 4 + kg) * LDB + brow + j * 16];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + rgrp + r;
+            if (m >= g.Mstore) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n >= g.Nstore) continue;
+                int nc = n;
+                if (g.cw_cin > 0) { const int tap = n / g.cw_cin, ci = n - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
+                atomicAdd(&g.C[(size_t)m * g.ldc + nc], acc[i][j][r]);
+            }
+        }
+}
+
+int spair_gemm_tn_impl(GemmTN g, bool conv, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
+    if (g.Mstore <= 0) g.Mstore = g.M;
+    if (g.Nstore <= 0) g.Nstore = g.N;
+    if ((g.M & 3) || (g.N & 3) || (g.lda & 3) || (!conv && (g.ldb & 3))) return SPAIR_ERR_ALIGN;
+    if (conv && (g.conv.Cin & 3)) return SPAIR_ERR_ALIGN;
+    constexpr int BM = 64, BN = 64;
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    // aim for ~4 waves of blocks over 256 CUs, at least 256 rows per split
+    int nsplit = max(1, min(ceil_div(g.R, 256), ceil_div(2048, tiles)));
+    int rps = round_up(ceil_div(g.R, nsplit), 16);
+    nsplit = ceil_div(g.R, rps);
+    g.rows_per_split = rps;
+    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), nsplit);
+    if (conv) hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// column sums: out[n] += sum_r A[r*lda + n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int R, int N, int rows_per_block,
+                                                     float* __restrict__ out) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (int r = r0 + sub; r < r1; r += 4) s += A[(size_t)r * lda + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(&out[n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s) {
+    if (R <= 0 || N <= 0) return SPAIR_ERR_SHAPE;
+    const int rpb = max(64, ceil_div(R, 512));
+    dim3 grid(ceil_div(N, 64), ceil_div(R, rpb));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, A, lda, R, N, rpb, out);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- C ABI (unit-level entry points; see include/spair_hip.h) ------------------------------
+extern "C" int spair_gemm_nt(const float* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                             const float* bias, const float* relu_mask, int ldmask, int relu, int accumulate, int dtype,
+                             void* stream) {
+    GemmNT g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.mask = relu_mask; g.ldmask = ldmask; g.relu = relu; g.accumulate = accumulate;
+    return spair_gemm_nt_impl(g, false, dtype, (hipStream_t)stream);
+}
+
+extern "C" int spair_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
+                             void* stream) {
+    GemmTN g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.R = R;
+    return spair_gemm_tn_impl(g, false, (hipStream_t)stream);
+}
+
+extern "C" int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {
+    return spair_colsum_impl(A, lda, R, N, out, (hipStream_t)stream);
+}
+
+static ConvDesc conv_from_ints(const int* p) {
+    ConvDesc c;
+    c.Hin = p[0]; c.Win = p[1]; c.Cin = p[2]; c.Hout = p[3]; c.Wout = p[4]; c.kh = p[5]; c.kw = p[6];
+    c.sy = p[7]; c.sx = p[8]; c.dky = p[9]; c.dkx = p[10]; c.oy = p[11]; c.ox = p[12];
+    return c;
+}
+
+// conv13 = {Hin,Win,Cin,Hout,Wout,kh,kw,sy,sx,dky,dkx,oy,ox}; cmap8 = {Hout,Wout,Hc,Wc,osy,osx,ooy,oox} or NULL
+extern "C" int spair_gemm_nt_conv(const float* In, const int* conv13, const void* B, int ldb, float* C, int ldc, int M,
+                                  int N, int K, const float* bias, const float* relu_mask, int ldmask, int relu,
+                                  int accumulate, const int* cmap8, int dtype, void* stream) {
+    GemmNT g{};
+    g.A = In; g.lda = 0; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.mask = relu_mask; g.ldmask = ldmask; g.relu = relu; g.accumulate = accumulate;
+    g.conv = conv_from_ints(conv13);
+    if (cmap8) {
+        g.use_cmap = 1;
+        g.cmap.Hout = cmap8[0]; g.cmap.Wout = cmap8[1]; g.cmap.Hc = cmap8[2]; g.cmap.Wc = cmap8[3];
+        g.cmap.osy = cmap8[4]; g.cmap.osx = cmap8[5]; g.cmap.ooy = cmap8[6]; g.cmap.oox = cmap8[7];
+    }
+    return spair_gemm_nt_impl(g, true, dtype, (hipStream_t)stream);
+}
+
+extern "C" int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
+                                  int N, int R, void* stream) {
+    GemmTN g{};
+    g.A = A; g.lda = lda; g.B = In; g.ldb = 0; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.R = R;
+    g.conv = conv_from_ints(conv13);
+    return spair_gemm_tn_impl(g, true, (hipStream_t)stream);
+}

@@ -1,0 +1,131 @@
+// KL terms and the loss (reference: _compute_KL models.py:169-262, _build_loss :544-563).
+//   K8  k_count_kl : the sequential count-prior Bernoulli KL -- one wave per sample walks the HW
+//                    cells in row-major order with the (HW+1)-bin count distribution in LDS.
+//   K7  k_gauss_kl : the six presence-masked Gaussian KL sums (deterministic two-stage reduce).
+//   k_loss_finalize: BCE partials + KL sums -> loss_out[0..8].
+#include "cells.h"
+
+#define KL_MAXBINS 1025   // HW+1 for G <= 32
+
+__global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
+    __shared__ float cd_sh[4][KL_MAXBINS + 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= L.B) return;
+    float* cd = cd_sh[wave];
+    const int HW = L.HW, NB = HW + 1;
+    // geometric count distribution (1-p) p^k, normalised (models.py:190-193)
+    float part = 0.f;
+    for (int e = lane; e < NB; e += 64) {
+        const float v = (1.f - prior_prob) * powf(prior_prob, (float)e);
+        cd[e] = v;
+        part += v;
+    }
+    const float norm0 = wave_reduce_sum(part);
+    for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / norm0;
+    float count = 0.f, klsum = 0.f;
+    for (int i = 0; i < HW; ++i) {
+        const int cp = P.cidx[i];   // row-major cell i = h*G + w  ->  wavefront index
+        const size_t r = (size_t)cp * L.B + b;
+        const float z = P.rec[r * L.ld_rec + L.REC - 1];
+        const float rem = (float)(HW - i);
+        float pz = 0.f;
+        for (int e = lane; e < NB; e += 64) {
+            const float q = fminf(fmaxf((float)e - count, 0.f), rem) / rem;
+            pz += cd[e] * q;
+        }
+        pz = wave_reduce_sum(pz);
+        const float s = rintf(z);   // torch.round: half to even
+        float np = 0.f;
+        for (int e = lane; e < NB; e += 64) {
+            const float q = fminf(fmaxf((float)e - count, 0.f), rem) / rem;
+            const float v = (s * q + (1.f - s) * (1.f - q)) * cd[e];
+            cd[e] = v;
+            np += v;
+        }
+        np = fmaxf(wave_reduce_sum(np), 1e-6f);
+        for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / np;
+        if (lane == 0) {
+            P.stat[r * SP_LDSTAT + ST_PZ] = pz;
+            const float e9 = 1e-9f;
+            klsum += z * (logf(z + e9) - logf(pz + e9)) + (1.f - z) * (logf(1.f - z + e9) - logf(1.f - pz + e9));
+        }
+        count += s;
+    }
+    if (lane == 0) klp[b] = klsum;
+}
+
+__device__ __forceinline__ float kl_gauss_l(float mu, float sd, float m, float s) {
+    const float vr = (sd / s) * (sd / s);
+    const float t1 = ((mu - m) / s) * ((mu - m) / s);
+    return 0.5f * (vr + t1 - 1.f - logf(vr));
+}
+
+// partial[blockIdx][6]: sum over this block's rows of z_pres * KL for (cy,cx,height,width,attr,depth)
+__global__ __launch_bounds__(256) void k_gauss_kl(CellLayout L, CellBufs P, CellHyper H, int rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(L.N, rbeg + rows_per_block);
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int per = L.A + 5;   // A attr elements + 4 box + 1 depth per row
+    for (long long idx = (long long)rbeg * per + threadIdx.x; idx < (long long)rend * per; idx += blockDim.x) {
+        const int r = (int)(idx / per), j = (int)(idx - (long long)r * per);
+        const float zp = P.rec[(size_t)r * L.ld_rec + L.REC - 1];
+        const float* st = P.stat + (size_t)r * SP_LDSTAT;
+        if (j < L.A) acc[4] += zp * kl_gauss_l(P.Oe[(size_t)r * L.ld_oe + j], P.sd_attr[(size_t)r * L.ld_rec + j], H.prior_mean[4], H.prior_std[4]);
+        else if (j < L.A + 4) {
+            const int k = j - L.A;
+            const float v = zp * kl_gauss_l(st[ST_MU_BOX + k], st[ST_SD_BOX + k], H.prior_mean[k], H.prior_std[k]);
+            if (k == 0) acc[0] += v; else if (k == 1) acc[1] += v; else if (k == 2) acc[2] += v; else acc[3] += v;
+        } else acc[5] += zp * kl_gauss_l(st[ST_MU_DEPTH], st[ST_SD_DEPTH], H.prior_mean[5], H.prior_std[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = block_reduce_sum_256(acc[k], red);
+        if (threadIdx.x == 0) partial[blockIdx.x * 6 + k] = v;
+    }
+}
+
+// loss_out[0]=total, [1]=BCE, [2..7]=Gaussian KLs * kl_scale, [8]=presence KL * kl_scale
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ bce_partial, int n_bce, const float* __restrict__ kl_partial,
+                                                       int n_kl, const float* __restrict__ klp, int B, float kl_scale, float beta,
+                                                       float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_bce; i += blockDim.x) s += bce_partial[i];
+    const float bce = block_reduce_sum_256(s, red);
+    float kls[7];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float t = 0.f;
+        for (int i = threadIdx.x; i < n_kl; i += blockDim.x) t += kl_partial[i * 6 + k];
+        kls[k] = block_reduce_sum_256(t, red) * kl_scale;
+    }
+    float t = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) t += klp[i];
+    kls[6] = block_reduce_sum_256(t, red) * kl_scale;
+    if (threadIdx.x == 0) {
+        float kl_total = 0.f;
+        for (int k = 0; k < 7; ++k) { loss_out[2 + k] = kls[k]; kl_total += kls[k]; }
+        loss_out[1] = bce;
+        loss_out[0] = bce + beta * kl_total;
+    }
+}
+
+int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s) {
+    if (L.HW + 1 > KL_MAXBINS) return SPAIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_count_kl, dim3(ceil_div(L.B, 4)), dim3(256), 0, s, L, P, prior_prob, klp);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+int loss_gauss_kl_blocks(const CellLayout& L) { return ceil_div(L.N, 64); }
+int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s) {
+    hipLaunchKernelGGL(k_gauss_kl, dim3(loss_gauss_kl_blocks(L)), dim3(256), 0, s, L, P, H, 64, partial);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale,
+                  float beta, float* loss_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, bce_partial, n_bce, kl_partial, n_kl, klp, B, kl_scale, beta, loss_out);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}

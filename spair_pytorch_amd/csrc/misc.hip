@@ -1,0 +1,240 @@
+// Small utility kernels: fused Adam (K9), counter-based noise, input padding, weight preparation,
+// per-row -> NCHW map export, and the direct first backbone layer (Cin = image channels).
+#include "cells.h"
+#include "misc.h"
+
+// ---- K9: torch.optim.Adam defaults (train.py:44) on the flat parameter buffer ------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                              float bc1, float sqrt_bc2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+extern "C" int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, int step, void* stream) {
+    if (n <= 0 || step < 1) return SPAIR_ERR_SHAPE;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float sqrt_bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, (long long)n, lr, beta1, beta2, eps, bc1, sqrt_bc2);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- noise: Philox4x32-10, Box-Muller; one counter per output element ---------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+__global__ __launch_bounds__(256) void k_noise(uint64_t seed, float* eps_box, long long n_box, float* eps_attr, long long n_attr,
+                                               float* eps_depth, long long n_depth, float* u_pres, long long n_pres) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = n_box + n_attr + n_depth + n_pres;
+    if (i >= total) return;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0x5bd1e995u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const float n = sqrtf(-2.f * logf(u01(o[0]))) * cosf(6.28318530718f * u01(o[1]));
+    if (i < n_box) eps_box[i] = n;
+    else if (i < n_box + n_attr) eps_attr[i - n_box] = n;
+    else if (i < n_box + n_attr + n_depth) eps_depth[i - n_box - n_attr] = n;
+    else u_pres[i - n_box - n_attr - n_depth] = u01(o[2]);
+}
+
+extern "C" int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth,
+                                float* u_pres, void* stream) {
+    const long long cells = (long long)d->B * d->G * d->G;
+    const long long total = cells * (4 + d->A + 2);
+    hipLaunchKernelGGL(k_noise, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, eps_box, cells * 4,
+                       eps_attr, cells * d->A, eps_depth, cells, u_pres, cells);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- input: NCHW [B,C,I,I] -> zero-padded NHWC [B,Ip,Ip,C] (modules.py:105,108) ----------------
+__global__ __launch_bounds__(256) void k_pad_input(const float* __restrict__ x, float* __restrict__ xp, int B, int C, int I, int pre,
+                                                   int Ip) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Ip * Ip * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int px = (int)(t % Ip); t /= Ip;
+    const int py = (int)(t % Ip);
+    const int b = (int)(t / Ip);
+    const int sx = px - pre, sy = py - pre;
+    xp[idx] = (sx >= 0 && sx < I && sy >= 0 && sy < I) ? x[(((size_t)b * C + c) * I + sy) * I + sx] : 0.f;
+}
+int misc_pad_input(const float* x, float* xp, int B, int C, int I, int pre, int Ip, hipStream_t s) {
+    const long long total = (long long)B * Ip * Ip * C;
+    hipLaunchKernelGGL(k_pad_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, xp, B, C, I, pre, Ip);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- weight preparation: dst[r*ld + c] = src[map(r,c)] as fp32 or bf16, zero padded --------------
+// mode 0: dst[r][c] = src[r*cols + c]                      (copy / pad / convert)
+// mode 1: dst[r][c] = src[c*rows + r]                      (transpose: dst rows = src cols)
+// mode 2: conv OIHW -> [O][ky][kx][ci]: src[((r*Cin+ci)*k+ky)*k+kx], c=(ky*k+kx)*Cin+ci
+// mode 3: conv dgrad class (py,px), stride s, T=k/s taps: dst[ci][(ty*T+tx)*O + co] = src[((co*Cin+ci)*k + py+s*ty)*k + px+s*tx]
+__global__ __launch_bounds__(256) void k_prep(PrepTable T) {
+    const PrepEntry e = T.e[blockIdx.y];
+    const long long n = (long long)e.rows * e.cols;   // pad columns are never written (workspace is zero-initialised)
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / e.cols), c = (int)(idx - (long long)r * e.cols);
+        float v;
+        if (e.mode == 0) v = e.src[(size_t)r * e.cols + c];
+        else if (e.mode == 1) v = e.src[(size_t)c * e.rows + r];
+        else if (e.mode == 2) {
+            const int tap = c / e.cin, ci = c - tap * e.cin, ky = tap / e.k, kx = tap - ky * e.k;
+            v = e.src[(((size_t)r * e.cin + ci) * e.k + ky) * e.k + kx];
+        } else {
+            const int t = c / e.cout, co = c - t * e.cout, ty = t / e.T, tx = t - ty * e.T;
+            v = e.src[(((size_t)co * e.cin + r) * e.k + (e.py + e.s * ty)) * e.k + (e.px + e.s * tx)];
+        }
+        const size_t o = (size_t)r * e.ld + c;
+        if (e.bf16) reinterpret_cast<__bf16*>(e.dst)[o] = (__bf16)v;
+        else reinterpret_cast<float*>(e.dst)[o] = v;
+    }
+}
+int misc_prep(const PrepTable& T, hipStream_t s) {
+    if (T.n <= 0) return SPAIR_OK;
+    hipLaunchKernelGGL(k_prep, dim3(64, T.n), dim3(256), 0, s, T);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- per-row quantity -> NCHW map -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export(const float* __restrict__ src, int ld, int col0, int ch, const int* __restrict__ cell_h,
+                                                const int* __restrict__ cell_w, int B, int G, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * G * G * ch;
+    if (idx >= total) return;
+    const int c = (int)(idx % ch);
+    const long long r = idx / ch;
+    const int cp = (int)(r / B), b = (int)(r - (long long)cp * B);
+    out[(((size_t)b * ch + c) * G + cell_h[cp]) * G + cell_w[cp]] = src[r * ld + col0 + c];
+}
+int misc_export(const float* src, int ld, int col0, int ch, const int* cell_h, const int* cell_w, int B, int G, float* out,
+                hipStream_t s) {
+    const long long total = (long long)B * G * G * ch;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ld, col0, ch, cell_h, cell_w, B, G, out);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- backbone layer 0 (Cin = C, tiny K = k*k*C): direct kernels -------------------------------------
+// forward: out[m][co] = relu(bias[co] + sum_k w[co][k] * patch(m)[k]); weights in LDS; thread = (pixel, 4 channels)
+__global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ xp, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int B, int Hin, int C, int k, int s, int Hout, int Cout) {
+    extern __shared__ float wsh[];   // [K0][Cout] transposed for conflict-free float4 reads
+    const int K0 = k * k * C;
+    for (int i = threadIdx.x; i < K0 * Cout; i += blockDim.x) {
+        const int co = i / K0, kk = i - co * K0;          // src OIHW: k index = (ci*k + ky)*k + kx
+        const int ci = kk / (k * k), rem = kk - ci * k * k;
+        wsh[((rem * C) + ci) * Cout + co] = w[i];            // dst k index = (ky*k+kx)*C + ci
+    }
+    __syncthreads();
+    const int q = Cout / 4;
+    const long long total = (long long)B * Hout * Hout * q;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(idx % q);
+        const long long m = idx / q;
+        const int ox = (int)(m % Hout), oy = (int)((m / Hout) % Hout), b = (int)(m / ((long long)Hout * Hout));
+        float4 acc = *reinterpret_cast<const float4*>(bias + cq * 4);
+        for (int ky = 0; ky < k; ++ky) {
+            const float* row = xp + (((size_t)b * Hin + oy * s + ky) * Hin + ox * s) * C;
+            for (int t = 0; t < k * C; ++t) {
+                const float xv = row[t];
+                const float4 wv = *reinterpret_cast<const float4*>(&wsh[((ky * k * C) + t) * Cout + cq * 4]);
+                acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+            }
+        }
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        *reinterpret_cast<float4*>(out + (size_t)m * Cout + cq * 4) = acc;
+    }
+}
+int misc_conv0_fwd(const float* xp, const float* w, const float* bias, float* out, int B, int Hin, int C, int k, int s, int Hout,
+                   int Cout, hipStream_t st) {
+    if (Cout % 4) return SPAIR_ERR_ALIGN;
+    const size_t lds = (size_t)k * k * C * Cout * sizeof(float);
+    if (lds > 64 * 1024) return SPAIR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * Hout * Hout * (Cout / 4);
+    const unsigned grid = (unsigned)min((long long)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(k_conv0_fwd, dim3(grid), dim3(256), lds, st, xp, w, bias, out, B, Hin, C, k, s, Hout, Cout);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// weight gradient: dW[co][ci][ky][kx] += sum_m dOut[m][co] * patch(m)[(ky,kx,ci)]; thread = (co, k) pairs
+__global__ __launch_bounds__(256) void k_conv0_wgrad(const float* __restrict__ xp, const float* __restrict__ dout, float* __restrict__ dw,
+                                                     int B, int Hin, int C, int k, int s, int Hout, int Cout, int rows_per_block) {
+    extern __shared__ float sh[];    // dout tile [64][Cout] then patches [64][K0]
+    const int K0 = k * k * C;
+    float* dsh = sh;
+    float* psh = sh + 64 * Cout;
+    const long long M = (long long)B * Hout * Hout;
+    const long long m_beg = (long long)blockIdx.x * rows_per_block, m_end = min(M, m_beg + rows_per_block);
+    const int npair = Cout * K0;
+    // each thread owns pairs p = threadIdx.x + i*256 (co = p % Cout, kk = p / Cout), up to 8 of them
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long m0 = m_beg; m0 < m_end; m0 += 64) {
+        const int nr = (int)min((long long)64, m_end - m0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * Cout; i += blockDim.x) dsh[i] = dout[(size_t)m0 * Cout + i];
+        for (int i = threadIdx.x; i < nr * K0; i += blockDim.x) {
+            const int rr = i / K0, kk = i - rr * K0;
+            const long long m = m0 + rr;
+            const int ox = (int)(m % Hout), oy = (int)((m / Hout) % Hout), b = (int)(m / ((long long)Hout * Hout));
+            const int tap = kk / C, ci = kk - tap * C, ky = tap / k, kx = tap - ky * k;
+            psh[i] = xp[(((size_t)b * Hin + oy * s + ky) * Hin + ox * s + kx) * C + ci];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = threadIdx.x + i * 256;
+            if (p >= npair) break;
+            const int co = p % Cout, kk = p / Cout;
+            float a = 0.f;
+            for (int rr = 0; rr < nr; ++rr) a += dsh[rr * Cout + co] * psh[rr * K0 + kk];
+            acc[i] += a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = threadIdx.x + i * 256;
+        if (p >= npair) break;
+        const int co = p % Cout, kk = p / Cout;
+        const int tap = kk / C, ci = kk - tap * C, ky = tap / k, kx = tap - ky * k;
+        atomicAdd(&dw[(((size_t)co * C + ci) * k + ky) * k + kx], acc[i]);
+    }
+}
+int misc_conv0_wgrad(const float* xp, const float* dout, float* dw, int B, int Hin, int C, int k, int s, int Hout, int Cout,
+                     hipStream_t st) {
+    const int K0 = k * k * C;
+    if (Cout * K0 > 8 * 256) return SPAIR_ERR_UNSUPPORTED;
+    const long long M = (long long)B * Hout * Hout;
+    const int rpb = 2048;
+    const size_t lds = (size_t)64 * (Cout + K0) * sizeof(float);
+    hipLaunchKernelGGL(k_conv0_wgrad, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), lds, st, xp, dout, dw, B, Hin, C, k, s, Hout,
+                       Cout, rpb);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}

@@ -1,0 +1,399 @@
+"""``SPAIR`` -- drop-in for /root/reference/spair/models.py:15-131 on an MI355X.
+
+Same constructor ``SPAIR(image_shape, writer, device)``, same ``forward(x, global_step=0) ->
+(loss, recon_x, z_where, z_pres)``, same ``state_dict`` keys and ``spair.config``
+hyper-parameters, so the reference's train.py loop (zero_grad / forward / backward / Adam
+step, train.py:64-67) runs unchanged.  All arithmetic of the step is in libspair_hip.so
+(hand-written gfx950 kernels behind the C ABI of include/spair_hip.h):
+
+* parameters live in ONE flat fp32 device buffer (each nn.Parameter is a view into it), the
+  gradients in a second one -- what the RCCL all-reduce and the fused Adam operate on;
+* ``forward`` enqueues ``spair_forward`` (backbone -> 3G-2 dependency wavefronts of the
+  per-cell encoder -> decoder -> fused inverse-STN compositor -> KL/loss); ``loss.backward()``
+  enqueues ``spair_backward`` (hand-written reverse pass) which accumulates into ``p.grad``;
+* there is no PyTorch/CPU fallback: without the HIP library or a GPU this module raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import config as cfg
+from .modules import Backbone, build_MLP, exponential_decay
+
+DIST_NAMES = ['cy_logit', 'cx_logit', 'height_logit', 'width_logit', 'attr', 'depth_logit']
+
+
+class SpairDims(ctypes.Structure):
+    """include/spair_hip.h :: SpairDims"""
+    _fields_ = [("B", ctypes.c_int), ("C", ctypes.c_int), ("I", ctypes.c_int), ("G", ctypes.c_int),
+                ("P", ctypes.c_int), ("A", ctypes.c_int), ("F", ctypes.c_int), ("NP", ctypes.c_int),
+                ("n_conv", ctypes.c_int), ("conv_k", ctypes.c_int * 8), ("conv_s", ctypes.c_int * 8),
+                ("conv_c", ctypes.c_int * 8), ("pad_pre", ctypes.c_int), ("pad_post", ctypes.c_int),
+                ("cell_px", ctypes.c_int), ("dtype", ctypes.c_int), ("align_corners", ctypes.c_int),
+                ("anchor", ctypes.c_float), ("max_yx", ctypes.c_float), ("min_yx", ctypes.c_float),
+                ("max_hw", ctypes.c_float), ("min_hw", ctypes.c_float), ("obj_logit_scale", ctypes.c_float),
+                ("alpha_logit_scale", ctypes.c_float), ("alpha_logit_bias", ctypes.c_float),
+                ("vae_beta", ctypes.c_float), ("prior_mean", ctypes.c_float * 6), ("prior_std", ctypes.c_float * 6)]
+
+
+class SpairStep(ctypes.Structure):
+    """include/spair_hip.h :: SpairStep"""
+    _fields_ = [("wheel", ctypes.c_float), ("count_prior_prob", ctypes.c_float), ("kl_scale", ctypes.c_float),
+                ("train", ctypes.c_int)]
+
+
+_DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+
+def make_dims(batch, image_shape, topology, dtype=None):
+    from .modules import backbone_geometry
+    d = SpairDims()
+    C, I, I2 = image_shape
+    assert I == I2, "square images only"
+    pre, post, G, cell, _ = backbone_geometry(I, topology)
+    d.B, d.C, d.I, d.G = int(batch), int(C), int(I), int(G)
+    d.P, d.A, d.F, d.NP = int(cfg.OBJECT_SHAPE[0]), int(cfg.N_ATTRIBUTES), int(cfg.N_BACKBONE_FEATURES), int(cfg.N_PASSTHROUGH_FEATURES)
+    d.n_conv = len(topology)
+    for i, layer in enumerate(topology):
+        d.conv_k[i], d.conv_s[i] = int(layer['kernel_size']), int(layer['stride'])
+        d.conv_c[i] = int(layer.get('filters', layer.get('out_channels')))
+    d.pad_pre, d.pad_post, d.cell_px = pre, post, cell
+    d.dtype = _DTYPES[(dtype or cfg.COMPUTE_DTYPE).lower()]
+    d.align_corners = int(bool(cfg.ALIGN_CORNERS))
+    d.anchor = float(cfg.ANCHORBOX_SHAPE[0])
+    d.max_yx, d.min_yx, d.max_hw, d.min_hw = cfg.MAX_YX, cfg.MIN_YX, cfg.MAX_HW, cfg.MIN_HW
+    d.obj_logit_scale, d.alpha_logit_scale, d.alpha_logit_bias = cfg.OBJ_LOGIT_SCALE, cfg.ALPHA_LOGIT_SCALE, cfg.ALPHA_LOGIT_BIAS
+    d.vae_beta = float(cfg.VAE_BETA)
+    for i, n in enumerate(DIST_NAMES):
+        d.prior_mean[i], d.prior_std[i] = float(cfg.PRIORS[n][0]), float(cfg.PRIORS[n][1])
+    return d
+
+
+def step_scalars(global_step, batch, world_size=1, train=True):
+    """Host evaluation of the two schedules (models.py:59,186-188) in fp32."""
+    st = SpairStep()
+    st.wheel = exponential_decay(global_step, None, **cfg.LATENT_VAR_TRAINING_WHEEL_PARAM)
+    lo = torch.tensor(exponential_decay(global_step, None, **cfg.OBJ_PRES_COUNT_LOG_PRIOR), dtype=torch.float32)
+    st.count_prior_prob = float(1 / ((-lo).exp() + 1))
+    st.kl_scale = 1.0 / (batch * world_size)
+    st.train = int(train)
+    return st
+
+
+class _NullWriter:
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+class _StepFn(torch.autograd.Function):
+    """Ties the hand-written backward into autograd.  ``anchor`` is a dummy differentiable leaf:
+    the parameter gradients are accumulated straight into the flat gradient buffer (the views
+    behind every ``p.grad``) by ``spair_backward`` instead of being returned one tensor at a time."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, step, noise):
+        loss_terms, recon, z_where, z_pres = model._run_forward(x, step, noise, train=True)
+        ctx.model, ctx.x, ctx.step, ctx.noise = model, x, step, noise
+        ctx.mark_non_differentiable(recon, z_where, z_pres)
+        model._loss_terms = loss_terms
+        return loss_terms[0].clone(), recon, z_where, z_pres
+
+    @staticmethod
+    def backward(ctx, g_loss, g_recon, g_zw, g_zp):
+        ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float())
+        return torch.zeros_like(g_loss), None, None, None, None
+
+
+class SPAIR(nn.Module):
+    def __init__(self, image_shape, writer=None, device=None, compute_dtype=None):
+        super().__init__()
+        self.image_shape = list(image_shape)
+        self.writer = writer if writer is not None else _NullWriter()
+        self.B = 1
+        self.device = torch.device(device) if device is not None else torch.device('cuda')
+        self.compute_dtype = (compute_dtype or cfg.COMPUTE_DTYPE).lower()
+        self.world_size = 1          # set by spair_pytorch_amd.ddp for the sharded loss
+        self.context_dim = (cfg.N_LOOKBACK * 2 + 1) ** 2 // 2 * (4 + cfg.N_ATTRIBUTES + 1 + 1)
+        if cfg.N_LOOKBACK != 1:
+            raise L.SpairHipError("only N_LOOKBACK=1 (4 neighbours, the reference configuration) is implemented")
+        self._build_networks()
+        self._build_edge_element()
+        self._build_indep_prior()
+        self.pixels_per_cell = tuple(int(i) for i in self.backbone.grid_cell_size)
+        self._flat = None
+        self._flat_grad = None
+        self._engines = {}
+        self._anchor = None
+        self._loss_terms = None
+        self.dist_param, self.dist = {}, {}
+        self.training_wheel = None
+        self.global_step = 0
+
+    # ---- construction: same order of RNG consumption as models.py:133-167,273-290 -------------
+    def _build_networks(self):
+        self.backbone = Backbone(self.image_shape, cfg.N_BACKBONE_FEATURES)
+        self.feature_space_dim = self.backbone.compute_output_shape()
+        n_pass = cfg.N_PASSTHROUGH_FEATURES
+        n_feat = self.feature_space_dim[0]
+        self.box_network = build_MLP(n_feat + self.context_dim, multiple_output=(8, n_pass))
+        obj_dim, chan = cfg.OBJECT_SHAPE[0], cfg.INPUT_IMAGE_SHAPE[0]
+        self.object_encoder = build_MLP(obj_dim * obj_dim * chan, 2 * cfg.N_ATTRIBUTES, hidden_layers=[256, 128])
+        z_in = 4 + cfg.N_ATTRIBUTES + n_pass + self.context_dim + cfg.N_BACKBONE_FEATURES
+        self.z_network = build_MLP(z_in, multiple_output=(2, n_pass))
+        self.obj_network = build_MLP(z_in + 1, 1)
+        self.object_decoder = build_MLP(cfg.N_ATTRIBUTES, obj_dim * obj_dim * (chan + 1), hidden_layers=[128, 256])
+        self.attn = _SelfAttnParams(55)   # dead in the reference (models.py:120,167); kept for state_dict parity
+
+    def _build_edge_element(self):
+        sizes = [4, cfg.N_ATTRIBUTES, 1, 1]
+        t = torch.randn(sum(sizes))
+        loc, attr, depth, pres = torch.split(t, sizes)
+        elem = torch.cat((torch.sigmoid(loc), attr, torch.sigmoid(depth), torch.sigmoid(pres)))
+        self.register_parameter('virtual_edge_element', nn.Parameter(elem))
+
+    def _build_indep_prior(self):
+        from torch.distributions import Normal
+        self.kl_priors = {n: Normal(m, s) for n, (m, s) in cfg.PRIORS.items()}
+
+    # ---- flat parameter / gradient buffers ---------------------------------------------------------
+    def _dims(self, batch):
+        return make_dims(batch, self.image_shape, self.backbone.topology, self.compute_dtype)
+
+    def _flatten(self):
+        """(Re)build the flat buffers on ``self.device`` and re-point every Parameter into them."""
+        lib = L.lib()
+        d = self._dims(1)
+        lib.spair_param_total.restype = ctypes.c_int64
+        total = lib.spair_param_total(ctypes.byref(d))
+        n = lib.spair_param_count(ctypes.byref(d))
+        named = dict(self.named_parameters())
+        dev = self.device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._slices = {}
+        name = ctypes.create_string_buffer(128)
+        off, ndim = ctypes.c_int64(), ctypes.c_int()
+        shape = (ctypes.c_int64 * 4)()
+        seen = set()
+        for i in range(n):
+            L.check(lib.spair_param_info(ctypes.byref(d), i, name, 128, ctypes.byref(off), shape, ctypes.byref(ndim)), "spair_param_info")
+            key = name.value.decode()
+            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            p = named[key]
+            if tuple(p.shape) != shp:
+                raise L.SpairHipError("parameter %s: module shape %s != library layout %s" % (key, tuple(p.shape), shp))
+            cnt = int(np.prod(shp))
+            view = flat[off.value:off.value + cnt].view(shp)
+            view.copy_(p.data.to(dev))
+            p.data = view
+            p.grad = None
+            self._slices[key] = (off.value, cnt, shp)
+            seen.add(key)
+        missing = set(named) - seen
+        if missing:
+            raise L.SpairHipError("parameters without a slot in the flat layout: %s" % sorted(missing))
+        self._flat, self._flat_grad = flat, flat_grad
+        self._params_by_key = named
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        self._engines = {}
+
+    def _apply(self, fn, recurse=True):
+        # .to(device)/.cuda()/.float(): let nn.Module move the tensors, then re-flatten on the new device
+        out = super()._apply(fn, recurse)
+        p0 = next(self.parameters())
+        if p0.is_cuda:
+            self.device = p0.device
+            self._flatten()
+        else:
+            self._flat = None
+        return out
+
+    def flat_parameters(self):
+        self._ensure_ready()
+        return self._flat
+
+    def flat_gradients(self):
+        self._ensure_ready()
+        return self._flat_grad
+
+    def _ensure_ready(self):
+        if self._flat is None:
+            if self.device.type != 'cuda':
+                raise L.SpairHipError("SPAIR runs on an MI355X only: move the model with .to('cuda') (there is no CPU path)")
+            self._flatten()
+        # a load_state_dict / optimizer may have swapped .data: detect and re-point (cheap pointer check)
+        p = self._params_by_key['virtual_edge_element']
+        if p.data_ptr() != self._flat.data_ptr() + 4 * self._slices['virtual_edge_element'][0]:
+            self._flatten()
+
+    def _bind_grads(self):
+        """Make every p.grad a view of the flat gradient buffer (zeroing slots that were None)."""
+        all_none = True
+        for key, p in self._params_by_key.items():
+            if p.grad is not None:
+                all_none = False
+                break
+        if all_none:
+            self._flat_grad.zero_()
+        base = self._flat_grad.data_ptr()
+        for key, p in self._params_by_key.items():
+            off, cnt, shp = self._slices[key]
+            if key.startswith('attn.'):
+                continue   # never receives a gradient in the reference (grad stays None)
+            if p.grad is None:
+                if not all_none:
+                    self._flat_grad[off:off + cnt].zero_()
+                p.grad = self._flat_grad[off:off + cnt].view(shp)
+            elif p.grad.data_ptr() != base + 4 * off:
+                v = self._flat_grad[off:off + cnt].view(shp)
+                v.copy_(p.grad)
+                p.grad = v
+
+    # ---- engine ----------------------------------------------------------------------------------------
+    def _engine(self, batch):
+        e = self._engines.get(batch)
+        if e is None:
+            lib = L.lib()
+            d = self._dims(batch)
+            lib.spair_workspace_bytes.restype = ctypes.c_int64
+            nbytes = lib.spair_workspace_bytes(ctypes.byref(d))
+            if nbytes <= 0:
+                raise L.SpairHipError("unsupported configuration for the HIP engine (B=%d, image=%s, topology=%s)" %
+                                      (batch, self.image_shape, self.backbone.topology))
+            G, A = d.G, d.A
+            dev = self.device
+            e = dict(dims=d,
+                     workspace=torch.zeros(nbytes, dtype=torch.uint8, device=dev),   # zero-initialised ONCE
+                     noise=dict(eps_box=torch.empty(batch, 4, G, G, device=dev), eps_attr=torch.empty(batch, A, G, G, device=dev),
+                                eps_depth=torch.empty(batch, 1, G, G, device=dev), u_pres=torch.empty(batch, 1, G, G, device=dev)))
+            self._engines = {batch: e}   # one live workspace (they are GBs at B=256)
+        return e
+
+    def _draw_noise(self, e):
+        """The 7 per-cell draws (models.py:333-336,84,95,402-403) as whole maps, one launch; the seed
+        comes from torch's CPU generator so torch.manual_seed controls it."""
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        n = e['noise']
+        L.check(L.lib().spair_noise_fill(ctypes.byref(e['dims']), ctypes.c_uint64(seed), L.ptr(n['eps_box']), L.ptr(n['eps_attr']),
+                                         L.ptr(n['eps_depth']), L.ptr(n['u_pres']), L.stream()), "spair_noise_fill")
+        return n
+
+    def _run_forward(self, x, step, noise, train):
+        e = self._engine(x.shape[0])
+        d = e['dims']
+        dev = x.device
+        B, G = x.shape[0], d.G
+        loss_terms = torch.empty(16, device=dev, dtype=torch.float32)
+        recon = torch.empty(B, d.C, d.I, d.I, device=dev, dtype=torch.float32)
+        z_where = torch.empty(B, 4, G, G, device=dev, dtype=torch.float32)
+        z_pres = torch.empty(B, 1, G, G, device=dev, dtype=torch.float32)
+        st = step_scalars(step, B, self.world_size, train)
+        self._last = dict(engine=e, st=st)
+        L.check(L.lib().spair_forward(ctypes.byref(d), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
+                                      L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),
+                                      L.ptr(e['workspace']), L.ptr(loss_terms), L.ptr(recon), L.ptr(z_where), L.ptr(z_pres),
+                                      L.stream()), "spair_forward")
+        return loss_terms, recon, z_where, z_pres
+
+    def _run_backward(self, x, step, noise, g_loss):
+        e = self._engine(x.shape[0])
+        st = step_scalars(step, x.shape[0], self.world_size, True)
+        self._bind_grads()
+        L.check(L.lib().spair_backward(ctypes.byref(e['dims']), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
+                                       L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),
+                                       L.ptr(e['workspace']), L.ptr(g_loss), L.ptr(self._flat_grad), L.stream()), "spair_backward")
+
+    # ---- public API ------------------------------------------------------------------------------------
+    def forward(self, x, global_step=0, noise=None):
+        """models.py:35-131.  ``noise`` (optional dict eps_box/eps_attr/eps_depth/u_pres, NCHW maps)
+        replaces the internal draws -- used by the parity tests."""
+        self._ensure_ready()
+        if not x.is_cuda:
+            raise L.SpairHipError("input must be on the MI355X (got %s); there is no CPU path" % x.device)
+        x = x.contiguous().float()
+        if list(x.shape[1:]) != list(self.image_shape):
+            raise AssertionError("expected input [B,%s], got %s" % (self.image_shape, tuple(x.shape)))
+        self.global_step = global_step
+        self.batch_size = x.shape[0]
+        e = self._engine(x.shape[0])
+        if noise is None:
+            noise = self._draw_noise(e)
+        else:
+            noise = {k: noise[k].to(x.device).contiguous().float() for k in ('eps_box', 'eps_attr', 'eps_depth', 'u_pres')}
+        self.training_wheel = exponential_decay(global_step, None, **cfg.LATENT_VAR_TRAINING_WHEEL_PARAM)
+        if torch.is_grad_enabled():
+            loss, recon, z_where, z_pres = _StepFn.apply(self._anchor, self, x, int(global_step), noise)
+        else:
+            terms, recon, z_where, z_pres = self._run_forward(x, int(global_step), noise, train=False)
+            self._loss_terms = terms
+            loss = terms[0].clone()
+        self._log_scalars()
+        self.dist_param, self.dist = _LazyDist(self), _LazyDist(self, as_normal=True)
+        return loss, recon, z_where, z_pres
+
+    def _log_scalars(self):
+        w = self.writer
+        if isinstance(w, _NullWriter):
+            return
+        t = self._loss_terms
+        w.add_scalar('training_wheel', self.training_wheel, self.global_step)
+        w.add_scalar('losses/reconst', t[1], self.global_step)
+        for i, n in enumerate(DIST_NAMES + ['pres_dist']):
+            w.add_scalar('losses/KL{}'.format(n), t[2 + i], self.global_step)
+        w.add_scalar('losses/total', t[0], self.global_step)
+
+    def loss_terms(self):
+        """Device tensor [9]: total, reconstruction BCE, KL cy,cx,height,width,attr,depth,pres (no sync)."""
+        return self._loss_terms[:9]
+
+    def export_map(self, which):
+        """Per-cell quantity of the last forward as an NCHW map (see spair_export_map)."""
+        e = self._last['engine']
+        d = e['dims']
+        ch = d.A if which in (0, 6, 12) else 1
+        out = torch.empty(d.B, ch, d.G, d.G, device=self.device, dtype=torch.float32)
+        L.check(L.lib().spair_export_map(ctypes.byref(d), L.ptr(e['workspace']), int(which), L.ptr(out), L.stream()), "spair_export_map")
+        return out
+
+
+class _LazyDist(dict):
+    """``self.dist_param[name]['mean'|'sigma']`` / ``self.dist[name]`` of the reference
+    (models.py:122-125,441-448), materialised from the engine's row buffers on first access."""
+
+    def __init__(self, model, as_normal=False):
+        super().__init__()
+        self._m, self._n = model, as_normal
+
+    def __missing__(self, name):
+        i = DIST_NAMES.index(name)
+        mean, sigma = self._m.export_map(2 + i), self._m.export_map(8 + i)
+        if self._n:
+            from torch.distributions import Normal
+            v = Normal(loc=mean, scale=sigma)
+        else:
+            v = {'mean': mean, 'sigma': sigma}
+        self[name] = v
+        return v
+
+    def keys(self):
+        return DIST_NAMES
+
+    def items(self):
+        return [(n, self[n]) for n in DIST_NAMES]
+
+
+class _SelfAttnParams(nn.Module):
+    """Parameter container for the reference's Self_Attn(55) (models.py:667-699).  Its output is
+    discarded there and its parameters never get gradients; only the state_dict entries matter."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.query_conv = nn.Conv2d(in_dim, in_dim // 8, kernel_size=1)
+        self.key_conv = nn.Conv2d(in_dim, in_dim // 8, kernel_size=1)
+        self.value_conv = nn.Conv2d(in_dim, in_dim, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))

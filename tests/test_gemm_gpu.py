@@ -1,0 +1,131 @@
+"""GPU parity of the MFMA GEMM core (csrc/gemm.hip) through the C ABI, against torch-CPU fp32."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from spair_pytorch_amd import _lib as L
+    return L
+
+
+def _i(*a):
+    return (ctypes.c_int * len(a))(*a)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (300, 100, 324), (2048, 108, 100), (9000, 256, 784), (8192, 128, 128), (70, 1, 100)])
+def test_gemm_nt(dtype, M, N, K):
+    L = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    Kp = (K + 7) // 8 * 8
+    A = torch.zeros(M, Kp)
+    A[:, :K] = torch.randn(M, K, generator=g)
+    W = torch.zeros(N, Kp)
+    W[:, :K] = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    Wb = Wd.to(torch.bfloat16).contiguous() if dtype == 1 else Wd
+    ldc = (N + 3) // 4 * 4
+    C = torch.full((M, ldc), 7.0, device="cuda")
+    rc = L.lib().spair_gemm_nt(L.ptr(Ad), Kp, L.ptr(Wb), Kp, L.ptr(C), ldc, M, N, Kp, L.ptr(bd), None, 0, 1, 0, dtype, L.stream())
+    L.check(rc, "gemm_nt")
+    if dtype == 1:
+        ref = torch.relu(A.to(torch.bfloat16).float() @ W.to(torch.bfloat16).float().t() + bias)
+        tol = 2e-3
+    else:
+        ref = torch.relu(A @ W.t() + bias)
+        tol = 2e-5
+    out = C.cpu()
+    assert (out[:, :N] - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+    assert (out[:, N:] == 7.0).all()  # pad columns untouched
+    # accumulate + relu-backward mask
+    Y = torch.randn(M, ldc, generator=g).cuda()
+    C2 = torch.ones(M, ldc, device="cuda")
+    rc = L.lib().spair_gemm_nt(L.ptr(Ad), Kp, L.ptr(Wb), Kp, L.ptr(C2), ldc, M, N, Kp, None, L.ptr(Y), ldc, 0, 1, dtype, L.stream())
+    L.check(rc, "gemm_nt")
+    if dtype == 1:
+        base = A.to(torch.bfloat16).float() @ W.to(torch.bfloat16).float().t()
+    else:
+        base = A @ W.t()
+    ref2 = (base + 1.0) * (Y.cpu()[:, :N] > 0)
+    assert (C2.cpu()[:, :N] - ref2).abs().max() <= tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,R", [(100, 324, 2048), (1568, 256, 4096), (128, 16, 5000), (4, 100, 777), (104, 480, 1000)])
+def test_gemm_tn_and_colsum(M, N, R):
+    L = _lib()
+    g = torch.Generator().manual_seed(M * 3 + N + R)
+    A = torch.randn(R, M, generator=g)
+    B = torch.randn(R, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    Cd, Ad, Bd = C0.cuda(), A.cuda(), B.cuda()  # keep device tensors alive across the launches
+    rc = L.lib().spair_gemm_tn(L.ptr(Ad), M, L.ptr(Bd), N, L.ptr(Cd), N, M, N, R, L.stream())
+    L.check(rc, "gemm_tn")
+    ref = C0.double() + A.double().t() @ B.double()
+    assert (Cd.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    out = torch.zeros(M, device="cuda")
+    L.check(L.lib().spair_colsum(L.ptr(Ad), M, R, M, L.ptr(out), L.stream()), "colsum")
+    assert (out.cpu().double() - A.double().sum(0)).abs().max() <= 1e-4 * A.double().sum(0).abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,Hin,Cin,Cout,k,s", [(3, 34, 128, 128, 4, 2), (2, 16, 128, 100, 1, 1), (5, 22, 8, 36, 4, 2)])
+def test_conv_fwd_dgrad_wgrad(dtype, B, Hin, Cin, Cout, k, s):
+    """Implicit-GEMM conv on NHWC: forward, stride-2 data-gradient by output-parity class, weight-gradient."""
+    L = _lib()
+    g = torch.Generator().manual_seed(B + Hin + Cin)
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    Hout = (Hin - k) // s + 1
+    xq, wq = (x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()) if dtype == 1 else (x, w)
+    ref = torch.relu(torch.nn.functional.conv2d(xq, wq, bias, stride=s))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    K = k * k * Cin
+    w_p = w.permute(0, 2, 3, 1).reshape(Cout, K).contiguous().cuda()      # [Cout][ky][kx][ci]
+    w_dev = w_p.to(torch.bfloat16) if dtype == 1 else w_p
+    ldc = (Cout + 3) // 4 * 4
+    out = torch.zeros(B, Hout, Hout, ldc, device="cuda")
+    M = B * Hout * Hout
+    conv = _i(Hin, Hin, Cin, Hout, Hout, k, k, s, s, 1, 1, 0, 0)
+    bias_d = bias.cuda()
+    rc = L.lib().spair_gemm_nt_conv(L.ptr(x_nhwc), conv, L.ptr(w_dev), K, L.ptr(out), ldc, M, Cout, K, L.ptr(bias_d),
+                                    None, 0, 1, 0, None, dtype, L.stream())
+    L.check(rc, "conv fwd")
+    got = out.cpu()[..., :Cout].permute(0, 3, 1, 2)
+    tol = 3e-3 if dtype == 1 else 2e-5
+    assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+
+    # ---- weight gradient (fp32 TN path): dW[co,(ky,kx,ci)] = sum_m dOut[m,co] * im2col(x)[m,k]
+    if Cout % 4 == 0:
+        go = torch.randn(B, Cout, Hout, Hout, generator=g)
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        torch.nn.functional.conv2d(xr, wr, None, stride=s).backward(go)
+        go_nhwc = go.permute(0, 2, 3, 1).contiguous().cuda()
+        dW = torch.zeros(Cout, K, device="cuda")
+        rc = L.lib().spair_gemm_tn_conv(L.ptr(go_nhwc), Cout, L.ptr(x_nhwc), conv, L.ptr(dW), K, Cout, K, M, L.stream())
+        L.check(rc, "conv wgrad")
+        ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(Cout, K)
+        assert (dW.cpu() - ref_dw).abs().max() <= 5e-5 * ref_dw.abs().max()
+        # ---- data gradient for k=4,s=2: 4 parity classes, each a 2x2 stride-1 "conv" over dOut
+        if k == 4 and s == 2 and dtype == 0:
+            dX = torch.zeros(B, Hin, Hin, Cin, device="cuda")
+            for py in range(2):
+                for px in range(2):
+                    # Wc[ci][(ty,tx,co)] = w[co, ci, py+2ty, px+2tx]
+                    wc = w[:, :, py::2, px::2].permute(1, 2, 3, 0).reshape(Cin, 4 * Cout).contiguous().cuda()
+                    Hc = (Hin - py + 1) // 2  # rows iy' with 2*iy'+py < Hin
+                    Wc = (Hin - px + 1) // 2
+                    cd = _i(Hout, Hout, Cout, Hc, Wc, 2, 2, 1, 1, -1, -1, 0, 0)
+                    cm = _i(Hc, Wc, Hin, Hin, 2, 2, py, px)
+                    rc = L.lib().spair_gemm_nt_conv(L.ptr(go_nhwc), cd, L.ptr(wc), 4 * Cout, L.ptr(dX), Cin, B * Hc * Wc, Cin,
+                                                    4 * Cout, None, None, 0, 0, 0, cm, 0, L.stream())
+                    L.check(rc, "conv dgrad")
+            ref_dx = xr.grad.permute(0, 2, 3, 1)
+            assert (dX.cpu() - ref_dx).abs().max() <= 5e-5 * ref_dx.abs().max()

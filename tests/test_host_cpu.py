@@ -1,0 +1,100 @@
+"""CPU-side checks of the host layer: init parity with the reference (RNG order), state_dict
+surface, schedules, the C-ABI library loads and exports what include/spair_hip.h declares, the
+flat parameter layout agrees with the nn.Module, and the product path fails loudly off-GPU."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fresh_cfg(I=128, strides=(3, 2, 2, 1, 1, 1)):
+    from spair_pytorch_amd import config as cfg
+    cfg.set_grid(I, strides)
+    return cfg
+
+
+def test_init_reproduces_reference_seed3(golden_dir):
+    """torch.manual_seed(3) + SPAIR(...) (train.py:39-41) gives the reference's initial weights
+    bit for bit: same construction order, including the RNG draw in compute_output_shape."""
+    _fresh_cfg()
+    from spair_pytorch_amd.models import SPAIR
+    z = np.load(os.path.join(golden_dir, "init_seed3.npz"))
+    torch.manual_seed(3)
+    m = SPAIR([1, 128, 128], None, torch.device("cpu"))
+    sd = m.state_dict()
+    keys = sorted(k[4:] for k in z.files if k.startswith("sha_"))
+    assert sorted(sd.keys()) == keys
+    assert len(keys) == 56 and sum(v.numel() for v in sd.values()) == 1462260
+    for k in keys:
+        h = np.frombuffer(hashlib.sha256(sd[k].numpy().tobytes()).digest(), np.uint8)
+        assert (h == z["sha_" + k]).all(), k
+    assert tuple(m.feature_space_dim) == tuple(z["feature_space_dim"])
+    assert tuple(m.pixels_per_cell) == tuple(z["pixels_per_cell"])
+
+
+def test_schedules_match_reference(golden_dir):
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.modules import exponential_decay
+    u = np.load(os.path.join(golden_dir, "units.npz"))
+    for s, wv, cv in zip(u["decay_steps"], u["decay_wheel"], u["decay_count_log"]):
+        assert np.float32(exponential_decay(int(s), None, **cfg.LATENT_VAR_TRAINING_WHEEL_PARAM)) == wv
+        assert np.float32(exponential_decay(int(s), None, **cfg.OBJ_PRES_COUNT_LOG_PRIOR)) == cv
+
+
+def test_geometry_known_answers():
+    from spair_pytorch_amd.modules import backbone_geometry
+    topo = [dict(kernel_size=k, stride=s) for k, s in zip((4, 4, 4, 1, 1, 1), (3, 2, 2, 1, 1, 1))]
+    assert backbone_geometry(128, topo) == (9, 14, 11, 12, 31)   # test_notebook.ipynb cell 10
+
+
+def test_library_exports_every_declared_symbol():
+    from spair_pytorch_amd import _build, _lib
+    _build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "spair_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(spair_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_flat_layout_matches_module():
+    _fresh_cfg()
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd.models import SPAIR, make_dims
+    m = SPAIR([1, 128, 128], None, torch.device("cpu"))
+    d = make_dims(4, [1, 128, 128], m.backbone.topology, "f32")
+    lib = L.lib()
+    lib.spair_param_total.restype = ctypes.c_int64
+    named = dict(m.named_parameters())
+    n = lib.spair_param_count(ctypes.byref(d))
+    assert n == len(named) == 56
+    name = ctypes.create_string_buffer(128)
+    off, ndim, shape = ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+    end = 0
+    for i in range(n):
+        assert lib.spair_param_info(ctypes.byref(d), i, name, 128, ctypes.byref(off), shape, ctypes.byref(ndim)) == 0
+        shp = tuple(shape[k] for k in range(ndim.value))
+        assert tuple(named[name.value.decode()].shape) == shp
+        assert off.value % 4 == 0 and off.value >= end     # 16-byte aligned, non-overlapping
+        end = off.value + int(np.prod(shp))
+    assert lib.spair_param_total(ctypes.byref(d)) >= end
+    lib.spair_workspace_bytes.restype = ctypes.c_int64
+    assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
+    d.C = 3   # RGB sprites are not implemented: must be refused, not silently mis-rendered
+    assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
+
+
+def test_no_cpu_fallback():
+    _fresh_cfg()
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd.models import SPAIR
+    m = SPAIR([1, 128, 128], None, torch.device("cpu"))
+    with pytest.raises(L.SpairHipError):
+        m(torch.zeros(2, 1, 128, 128), 0)

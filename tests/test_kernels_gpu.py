@@ -1,0 +1,96 @@
+"""GPU parity of the STN gather and the fused renderer, each through its C-ABI entry point, against
+the reference's own vectors (units.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spair_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _L():
+    from spair_pytorch_amd import _lib as L
+    return L
+
+
+def test_stn_glimpse_fwd_bwd_vs_reference(golden_dir):
+    L = _L()
+    u = np.load(os.path.join(golden_dir, "units.npz"))
+    img, zw = torch.from_numpy(u["stn_img"]).cuda(), torch.from_numpy(u["stn_zw"]).cuda()
+    n, C, I, P = img.shape[0], 1, img.shape[-1], 28
+    out = torch.zeros(n, C * P * P, device="cuda")
+    L.check(L.lib().spair_stn_glimpse_fwd(L.ptr(img), L.ptr(zw), n, L.ptr(out), C * P * P, n, C, I, P, 0, L.stream()), "stn fwd")
+    assert np.abs(out.cpu().numpy().reshape(n, C, P, P) - u["stn_glimpse"]).max() < 1e-5
+    gw = torch.from_numpy(u["stn_gw"]).reshape(n, -1).contiguous().cuda()
+    dzw = torch.zeros(n, 4, device="cuda")
+    L.check(L.lib().spair_stn_glimpse_bwd(L.ptr(img), L.ptr(zw), n, L.ptr(gw), C * P * P, L.ptr(dzw), n, C, I, P, 0, L.stream()), "stn bwd")
+    assert np.abs(dzw.cpu().numpy() - u["stn_dzw"]).max() <= 3e-4 * np.abs(u["stn_dzw"]).max()
+
+
+def _render_oracle(S, nbox, pres, depth, x, B, HW, I, P):
+    """Composite + BCE with the oracle's inverse STN (closed-form inverse), rows r = k*B + b."""
+    N = B * HW
+    grey, a0 = S[..., 0], S[..., 1]
+    alpha = a0 * pres.view(N, 1, 1)
+    imp = torch.clamp(alpha * depth.view(N, 1, 1), min=0.01)
+    objs = torch.stack([grey, alpha, imp], 1)                       # [N,3,P,P]
+    t = orc.stn(objs, nbox, (I, I), inverse=True, inverse_mode="closed")  # [N,3,I,I]
+    t = t.view(HW, B, 3, I, I).permute(1, 0, 2, 3, 4)               # [B,HW,3,I,I]
+    colour, al, im = t[:, :, 0:1], t[:, :, 1:2], t[:, :, 2:3] + 1e-9
+    im = im / im.sum(1, keepdim=True)
+    rec = torch.clamp((al * colour * im).sum(1), 0, 1)
+    return rec, torch.nn.functional.binary_cross_entropy(rec, x, reduction="sum")
+
+
+@pytest.mark.parametrize("B,G,I", [(2, 3, 48), (8, 4, 64)])
+def test_render_fwd_bwd_vs_oracle(B, G, I):
+    L = _L()
+    P, HW = 28, G * G
+    N = B * HW
+    g = torch.Generator().manual_seed(B + G + I)
+    logits = torch.randn(N, P, P, 2, generator=g)
+    logits[..., 1] += 1.0
+    S = torch.sigmoid(logits).requires_grad_(True)
+    nbox = torch.stack([torch.rand(N, generator=g) * 1.2 - 0.1, torch.rand(N, generator=g) * 1.2 - 0.1,
+                        torch.rand(N, generator=g) * 0.5 + 0.08, torch.rand(N, generator=g) * 0.5 + 0.08], 1).requires_grad_(True)
+    pres = torch.rand(N, generator=g).requires_grad_(True)
+    depth = (torch.rand(N, generator=g) * 4).requires_grad_(True)
+    x = (torch.rand(B, 1, I, I, generator=g) > 0.7).float() * torch.rand(B, 1, I, I, generator=g)
+    rec_o, bce_o = _render_oracle(S, nbox, pres, depth, x, B, HW, I, P)
+    bce_o.backward()
+
+    Sd = S.detach().reshape(N, -1).contiguous().cuda()
+    nb, pr, dp, xd = nbox.detach().cuda(), pres.detach().cuda(), depth.detach().cuda(), x.cuda()
+    recon = torch.zeros(B, 1, I, I, device="cuda")
+    aux = torch.zeros(B, I, I, 4, device="cuda")
+    nblk = B * ((I + 15) // 16) ** 2
+    part = torch.zeros(nblk, device="cuda")
+    ld = P * P * 2
+    L.check(L.lib().spair_render_fwd(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
+                                     B, HW, 1, I, P, 0, L.stream()), "render fwd")
+    assert (recon.cpu() - rec_o.detach()).abs().max() < 2e-5
+    assert abs(part.sum().item() - bce_o.item()) <= 2e-5 * bce_o.item()
+    gl = torch.ones((), device="cuda")
+    dlog = torch.zeros(N, ld, device="cuda")
+    dnb, dpr, ddp = torch.zeros(N, 4, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    L.check(L.lib().spair_render_bwd(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(aux), L.ptr(gl), L.ptr(dlog), L.ptr(dnb),
+                                     L.ptr(dpr), L.ptr(ddp), B, HW, 1, I, P, 0, ctypes_f(2.0), ctypes_f(0.1), L.stream()), "render bwd")
+    s = S.detach()
+    scale = torch.tensor([2.0, 0.1]).view(1, 1, 1, 2)
+    ref_dlog = (S.grad * s * (1 - s) * scale).reshape(N, -1)
+
+    def close(a, b, tol):
+        return (a.cpu() - b).abs().max().item() <= tol * b.abs().max().item() + 1e-7
+
+    assert close(dlog, ref_dlog, 2e-4)
+    assert close(dpr, pres.grad, 2e-4)
+    assert close(ddp, depth.grad, 2e-4)
+    assert close(dnb, nbox.grad, 1e-3)
+
+
+def ctypes_f(v):
+    import ctypes
+    return ctypes.c_float(v)
