@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""SPAIR train-step benchmark on MI355X (contract: see the driver's bench.py spec).
+
+Workload = BASELINE.json configs[1]: 128x128 scattered-digit scenes (<= 11 objects), 16x16 cell grid
+(backbone strides 2,2,2 -> 8-px cells), batch 256 per GPU, bf16 GEMM/conv operands, fp32 elsewhere.
+A "step" = zero_grad + forward + backward + (gradient all-reduce if N>1) + Adam, input resident in HBM,
+global_step >= 2000 (training wheel off: every gradient path live, nothing skipped).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+SLOT_NAMES = ["prep", "backbone_fwd", "cells_fwd", "decoder_fwd", "count_kl", "render_fwd", "kl_loss", "render_bwd",
+              "decoder_bwd", "cells_bwd", "cells_wgrad", "backbone_bwd", "conv1_fwd", "dec_out_fwd", "stn_fwd", "adam",
+              "dec_out_wgrad", "dec_out_dgrad"]
+
+
+def cpu_baseline(image_side, strides, batch, steps=2):
+    """The CPU oracle (oracle/spair_oracle.py, a restatement of the reference's PyTorch path) timed on this
+    box's host cores on a bounded sample of the same workload.  Reported baseline only -- never the product."""
+    from oracle import spair_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import golden_inputs as gi
+    from spair_pytorch_amd.data import scattered_digits
+    ncpu = min(16, len(os.sched_getaffinity(0)))       # the GPU box's CPU share (16 per GPU)
+    torch.set_num_threads(ncpu)
+    cfg = orc.OracleConfig(image_shape=(1, image_side, image_side), conv_strides=tuple(strides))
+    p = {k: torch.from_numpy(v).clone().requires_grad_(not k.startswith("attn.")) for k, v in gi.make_weights(3, 1.0).items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    x = torch.from_numpy(scattered_digits(99, batch, image_side, 11)[0])
+    G = gi.grid_side(image_side, strides)
+    times = []
+    for it in range(steps + 1):
+        noise = {k: torch.from_numpy(a) for k, a in gi.make_noise(it, batch, G).items()}
+        t0 = time.perf_counter()
+        for t in p.values():
+            t.grad = None
+        out = orc.forward(p, x, 2000 + it, noise, cfg, fast=True)
+        out["loss"].backward()
+        with torch.no_grad():
+            orc.adam_step({k: t for k, t in p.items()}, {k: t.grad for k, t in p.items()}, m, v2, it + 1)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return dict(value=batch / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="oracle fwd+bwd+Adam, 128x128, 16x16 grid, batch %d, %d timed steps after 1 warm-up (%.2f s/step)" % (batch, steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--image", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd import ddp
+    from spair_pytorch_amd.data import scattered_digits
+    from spair_pytorch_amd.models import SPAIR
+    from spair_pytorch_amd.optim import FusedAdam
+
+    strides = (2, 2, 2, 1, 1, 1)
+    cfg.set_grid(args.image, strides)
+    torch.manual_seed(3)                                   # train.py:39
+    model = SPAIR([1, args.image, args.image], None, dev, compute_dtype=args.dtype).to(dev)
+    ddp.attach(model, world)
+    if world > 1:
+        ddp.broadcast_parameters(model.flat_parameters())
+    opt = FusedAdam(model, lr=1e-4)
+    B = args.batch
+    x = torch.from_numpy(scattered_digits(1234 + rank, B, args.image, 11)[0]).to(dev)   # resident in HBM
+    torch.manual_seed(7 + rank)                            # noise seed, per rank
+    gstep = [2000]
+
+    def step():
+        opt.zero_grad()
+        loss, recon, z_where, z_pres = model(x, gstep[0])
+        loss.backward()
+        if world > 1:
+            ddp.allreduce_gradients(model.flat_gradients())
+        opt.step()
+        gstep[0] += 1
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    lib = L.lib()
+    L.check(lib.spair_prof_enable(1), "prof_enable")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    nslots = len(SLOT_NAMES)
+    ms = (ctypes.c_float * nslots)()
+    cnt = (ctypes.c_int * nslots)()
+    L.check(lib.spair_prof_read(ms, cnt, nslots), "prof_read")
+    lib.spair_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    terms = model.loss_terms().clone()
+    if world > 1:
+        terms = ddp.global_loss(terms)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    K = args.steps
+    per_step_ms = {SLOT_NAMES[i]: ms[i] / K for i in range(nslots) if cnt[i] > 0}
+    avg = {SLOT_NAMES[i]: ms[i] / cnt[i] for i in range(nslots) if cnt[i] > 0}       # per launch / region
+    d = model._last["engine"]["dims"]
+    N = B * d.G * d.G
+    P2 = d.P * d.P
+    sprite_b = N * P2 * 2 * 4                    # fp32 (grey, alpha) sprites
+    render_fwd_bytes = sprite_b + N * 6 * 4 + B * d.I * d.I * 4          # 429.4 MB at config 2
+    render_bwd_bytes = render_fwd_bytes + sprite_b                         # + the gradient-sprite write
+    peak_f = MFMA_PEAK_TFLOPS["bf16" if args.dtype == "bf16" else "f32"]
+    c1 = [c for c in [(d.conv_k[1], d.conv_s[1], d.conv_c[1])]][0]
+    h0 = (d.I + d.pad_pre + d.pad_post - d.conv_k[0]) // d.conv_s[0] + 1
+    h1 = (h0 - c1[0]) // c1[1] + 1
+    conv1_flop = 2.0 * B * h1 * h1 * c1[2] * (c1[0] * c1[0] * d.conv_c[0])
+    dec_out_flop = 2.0 * N * 256 * (P2 * 2)
+    kernels = {}
+
+    def add(name, bound, work, unit_scale, peak, unit):
+        if name in avg and avg[name] > 0:
+            ach = work / (avg[name] * 1e-3) / unit_scale
+            kernels[name] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_ms=avg[name], traffic=None)
+
+    add("render_fwd", "hbm", render_fwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
+    add("render_bwd", "hbm", render_bwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
+    add("conv1_fwd", "mfma", conv1_flop, 1e12, peak_f, "TFLOP/s")
+    add("dec_out_fwd", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
+    add("dec_out_dgrad", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
+    add("dec_out_wgrad", "mfma", dec_out_flop, 1e12, MFMA_PEAK_TFLOPS["f32"], "TFLOP/s")   # wgrad runs fp32 MFMA this round
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+    roof = dict(kernels[dominant], kernel=dominant) if dominant else None
+
+    out = dict(metric="SPAIR train images/sec + ELBO, 128x128 scattered-MNIST, batch 256", value=world * B * K / dt, unit="images/sec",
+               n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=dt / K * 1e3, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype=args.dtype, data="synthetic",
+               config=dict(workload="BASELINE configs[1]: 128x128 synthetic scattered digits (<=11), 16x16 grid, batch %d/GPU, "
+                                    "fwd+bwd+Adam, global_step>=2000 (wheel off)" % B,
+                           global_batch=world * B, image=args.image, grid=d.G, parallelism="dp%d" % world),
+               elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
+               roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.image, strides, batch=8)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,17 +72,25 @@ int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg
 int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream);
 int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
 
+/* Opt-in instrumentation for bench.py: HIP events on the caller's stream around regions of the step.
+ * slots: 0 prep, 1 backbone fwd, 2 per-cell chain fwd, 3 decoder fwd, 4 count-prior KL, 5 render fwd (1 kernel),
+ * 6 KL+loss, 7 render bwd (1 kernel), 8 decoder bwd, 9 per-cell chain bwd, 10 per-cell weight grads,
+ * 11 backbone bwd, 12 conv_1 fwd (1 kernel), 13 decoder.out fwd GEMM (1 kernel), 14 STN glimpse fwd (per wavefront),
+ * 15 adam, 16 decoder.out wgrad, 17 decoder.out dgrad.  spair_prof_read synchronises: call it outside timed regions. */
+int spair_prof_enable(int enable);
+int spair_prof_read(float* ms, int* counts, int nslots);
+
 /* ---- unit-level entry points (each kernel can be parity-checked alone) --------------------- */
 int spair_gemm_nt(const float* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* relu_mask, int ldmask, int relu, int accumulate, int dtype,
                   void* stream);
 int spair_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
-                  void* stream);
+                  int dtype, void* stream);
 int spair_gemm_nt_conv(const float* In, const int* conv13, const void* B, int ldb, float* C, int ldc, int M,
                        int N, int K, const float* bias, const float* relu_mask, int ldmask, int relu,
                        int accumulate, const int* cmap8, int dtype, void* stream);
 int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
-                       int N, int R, void* stream);
+                       int N, int R, int dtype, void* stream);
 int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
 /* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);
  * row r samples image x[r % B], nbox[r] = (xt,yt,xs,ys) */

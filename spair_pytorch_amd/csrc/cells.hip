@@ -307,35 +307,43 @@ __global__ __launch_bounds__(256) void k_dfeat_edge(CellLayout L, CellBufs P, in
 }
 
 // ---- tables: wavefront order, neighbours, consumers -----------------------------------------
-__global__ void k_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int c = 0;
-    const int T = 3 * G - 2;
-    for (int t = 0; t < T; ++t) {
-        diag_start[t] = c;
-        for (int h = 0; h < G; ++h) {
-            const int w = t - 2 * h;
-            if (w < 0 || w >= G) continue;
-            cell_h[c] = h; cell_w[c] = w; cidx[h * G + w] = c;
-            ++c;
+__global__ __launch_bounds__(1024) void k_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start) {
+    __shared__ int dstart[3 * 32 + 2];
+    const int T = 3 * G - 2, HW = G * G;
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int t = 0; t < T; ++t) {
+            dstart[t] = c;
+            const int hlo = max(0, (t - (G - 1) + 1) / 2), hhi = min(G - 1, t / 2);   // 0 <= t-2h < G
+            c += max(0, hhi - hlo + 1);
         }
+        dstart[T] = c;
     }
-    diag_start[T] = c;
-    const int dh[4] = {-1, -1, -1, 0}, dw[4] = {-1, 0, 1, -1};  // UL, U, UR, L (models.py:297-304)
-    for (int k = 0; k < G * G; ++k) {
-        const int h = cell_h[k], w = cell_w[k];
+    __syncthreads();
+    for (int t = threadIdx.x; t <= T; t += blockDim.x) diag_start[t] = dstart[t];
+    // wavefront index of cell (h,w): cells of diagonal t = 2h+w are ordered by ascending h
+    auto cp_of = [&](int h, int w) {
+        const int t = 2 * h + w;
+        const int hlo = max(0, (t - (G - 1) + 1) / 2);
+        return dstart[t] + (h - hlo);
+    };
+    const int dh[4] = {-1, -1, -1, 0}, dw[4] = {-1, 0, 1, -1};   // UL, U, UR, L (models.py:297-304)
+    for (int k = threadIdx.x; k < HW; k += blockDim.x) {
+        const int h = k / G, w = k - h * G;
+        const int c = cp_of(h, w);
+        cell_h[c] = h; cell_w[c] = w; cidx[k] = c;
         for (int s = 0; s < 4; ++s) {
             const int nh = h + dh[s], nw = w + dw[s];
-            nbr[k * 4 + s] = (nh >= 0 && nh < G && nw >= 0 && nw < G) ? cidx[nh * G + nw] : -1;
-            const int qh = h - dh[s], qw = w - dw[s];  // the cell that sees (h,w) in slot s
-            cons[k * 4 + s] = (qh >= 0 && qh < G && qw >= 0 && qw < G) ? cidx[qh * G + qw] : -1;
+            nbr[c * 4 + s] = (nh >= 0 && nh < G && nw >= 0 && nw < G) ? cp_of(nh, nw) : -1;
+            const int qh = h - dh[s], qw = w - dw[s];   // the cell that sees (h,w) in slot s
+            cons[c * 4 + s] = (qh >= 0 && qh < G && qw >= 0 && qw < G) ? cp_of(qh, qw) : -1;
         }
     }
 }
 
 // ---- host launchers -------------------------------------------------------------------------
 int cells_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_tables, dim3(1), dim3(1), 0, s, G, cell_h, cell_w, cidx, nbr, cons, diag_start);
+    hipLaunchKernelGGL(k_init_tables, dim3(1), dim3(1024), 0, s, G, cell_h, cell_w, cidx, nbr, cons, diag_start);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

@@ -29,6 +29,63 @@ int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, 
         if (rc__ != SPAIR_OK) return rc__; \
     } while (0)
 
+
+// ---------------------------------------------------------------------------------------------
+// opt-in instrumentation (bench.py): HIP events around regions / single kernels ON THE CALLER'S
+// STREAM.  Off by default; the step itself stays stateless.
+// ---------------------------------------------------------------------------------------------
+#define SP_PROF_SLOTS 24
+#define SP_PROF_POOL 8192
+struct ProfState {
+    int enabled;
+    int n_events;                 // created
+    int used;                     // event pairs used
+    hipEvent_t ev[2 * SP_PROF_POOL];
+    int slot[SP_PROF_POOL];
+};
+static ProfState g_prof;
+
+static inline int prof_begin(int slot, hipStream_t s) {
+    if (slot < 0 || !g_prof.enabled || g_prof.used >= SP_PROF_POOL) return -1;
+    const int i = g_prof.used++;
+    g_prof.slot[i] = slot;
+    hipEventRecord(g_prof.ev[2 * i], s);
+    return i;
+}
+static inline void prof_end(int i, hipStream_t s) {
+    if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], s);
+}
+struct ProfScope {
+    int i; hipStream_t s;
+    ProfScope(int slot, hipStream_t st) : i(prof_begin(slot, st)), s(st) {}
+    ~ProfScope() { prof_end(i, s); }
+};
+
+extern "C" int spair_prof_enable(int enable) {
+    if (enable && g_prof.n_events == 0) {
+        for (int i = 0; i < 2 * SP_PROF_POOL; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        g_prof.n_events = 2 * SP_PROF_POOL;
+    }
+    g_prof.enabled = enable ? 1 : 0;
+    g_prof.used = 0;
+    return SPAIR_OK;
+}
+// Synchronises on the recorded events (call only outside the timed region); ms[slot] += elapsed, counts[slot] += 1.
+extern "C" int spair_prof_read(float* ms, int* counts, int nslots) {
+    for (int i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        const int sl = g_prof.slot[i];
+        if (sl >= 0 && sl < nslots) { ms[sl] += t; counts[sl] += 1; }
+    }
+    g_prof.used = 0;
+    return SPAIR_OK;
+}
+enum { PS_PREP = 0, PS_BACKBONE_FWD, PS_CELLS_FWD, PS_DECODER_FWD, PS_COUNT_KL, PS_RENDER_FWD, PS_LOSS, PS_RENDER_BWD, PS_DECODER_BWD,
+       PS_CELLS_BWD, PS_CELLS_WGRAD, PS_BACKBONE_BWD, PS_CONV1_FWD, PS_DEC2_FWD, PS_STN_FWD, PS_ADAM, PS_DEC2_WGRAD, PS_DEC2_DGRAD };
+
 static int validate(const SpairDims& d) {
     if (d.B <= 0 || d.I <= 0 || d.G <= 0 || d.P <= 0 || d.A <= 0 || d.F <= 0 || d.NP <= 0) return SPAIR_ERR_SHAPE;
     if (d.C != 1) return SPAIR_ERR_UNSUPPORTED;            // renderer / sprites: greyscale only for now
@@ -285,7 +342,7 @@ static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, i
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R;
-    return spair_gemm_tn_impl(g, false, c.s);
+    return spair_gemm_tn_impl(g, false, c.d.dtype, c.s);
 }
 static const void* bptr(const void* base, size_t elem_off, int dtype) {
     return reinterpret_cast<const char*>(base) + elem_off * (dtype == SPAIR_BF16 ? 2 : 4);
@@ -376,6 +433,7 @@ static int backbone_fwd(Ctx& c) {
             memset(&g, 0, sizeof(g));
             g.A = c.w.act[i - 1]; g.B = c.w.conv_wf[i]; g.ldb = round_up(K, 8); g.C = out; g.ldc = ldc; g.M = M; g.N = cs.cout; g.K = K;
             g.bias = c.params + cs.b; g.relu = last ? 0 : 1; g.conv = fwd_desc(cs);
+            ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
             TRY(spair_gemm_nt_impl(g, true, d.dtype, c.s));
         }
     }
@@ -400,7 +458,7 @@ static int backbone_bwd(Ctx& c, float* grads) {
             const int K = cs.k * cs.k * cs.cin;
             g.A = dout; g.lda = ldd; g.B = in; g.C = grads + cs.w; g.ldc = K; g.M = round_up(cs.cout, 4); g.N = K; g.Mstore = cs.cout; g.Nstore = K;
             g.R = M; g.cw_cin = cs.cin; g.cw_taps = cs.k * cs.k; g.conv = fwd_desc(cs);
-            TRY(spair_gemm_tn_impl(g, true, c.s));
+            TRY(spair_gemm_tn_impl(g, true, c.d.dtype, c.s));
         }
         TRY(spair_colsum_impl(dout, ldd, M, cs.cout, grads + cs.b, c.s));
         // data gradient into dact[i-1] (masked by relu of act[i-1])
@@ -452,7 +510,7 @@ static int cells_fwd(Ctx& c) {
         TRY(fwd_lin(c, LIN_BOXH1, P.Hb2, SP_LDH, P.Ob, L.ld_ob, r0, R, c.w.bias_boxh, L.NP + 8, 0));
         TRY(cells_box_sample(L, P, c.H, r0, R, c.s));
         // z_what
-        TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, c.s));
+        { ProfScope ps(PS_STN_FWD, c.s); TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, c.s)); }
         TRY(fwd_lin(c, LIN_ENC0, P.glimpse, L.ld_gl, P.He1, SP_ENC_H1, r0, R, pr + PL.lin[LIN_ENC0].b, SP_ENC_H1, 1));
         TRY(fwd_lin(c, LIN_ENC1, P.He1, SP_ENC_H1, P.He2, SP_ENC_H2, r0, R, pr + PL.lin[LIN_ENC1].b, SP_ENC_H2, 1));
         TRY(fwd_lin(c, LIN_ENC2, P.He2, SP_ENC_H2, P.Oe, L.ld_oe, r0, R, pr + PL.lin[LIN_ENC2].b, 2 * L.A, 0));
@@ -480,22 +538,32 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     const CellLayout& L = c.L;
     CellBufs& P = c.w.cb;
     P.z_where = z_where; P.z_pres = z_pres;
-    TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
-    TRY(prep_weights(c, st->train != 0));
-    TRY(backbone_fwd(c));
-    TRY(cells_fwd(c));
+    {
+        ProfScope ps(PS_PREP, c.s);
+        TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
+        TRY(prep_weights(c, st->train != 0));
+    }
+    { ProfScope ps(PS_BACKBONE_FWD, c.s); TRY(backbone_fwd(c)); }
+    { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
     // decoder (models.py:474-492)
     const ParamLayout& PL = c.PL;
     const int N = L.N;
-    TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
-    TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
     const int per = d->P * d->P * (d->C + 1);
-    TRY(fwd_lin(c, LIN_DEC2, c.w.Hd2, SP_DEC_H2, c.w.S, c.w.ld_s, 0, N, params + PL.lin[LIN_DEC2].b, per, 0));
-    TRY(render_sprite_act(c.w.S, c.w.ld_s, N, per, d->C + 1, d->obj_logit_scale, d->alpha_logit_scale, d->alpha_logit_bias, c.s));
+    {
+        ProfScope ps(PS_DECODER_FWD, c.s);
+        TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
+        TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
+        { ProfScope p2(PS_DEC2_FWD, c.s); TRY(fwd_lin(c, LIN_DEC2, c.w.Hd2, SP_DEC_H2, c.w.S, c.w.ld_s, 0, N, params + PL.lin[LIN_DEC2].b, per, 0)); }
+        TRY(render_sprite_act(c.w.S, c.w.ld_s, N, per, d->C + 1, d->obj_logit_scale, d->alpha_logit_scale, d->alpha_logit_bias, c.s));
+    }
     // KL + render + loss
-    TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, c.s));
-    TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
-                   c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s));
+    { ProfScope ps(PS_COUNT_KL, c.s); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, c.s)); }
+    {
+        ProfScope ps(PS_RENDER_FWD, c.s);
+        TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
+                       c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s));
+    }
+    ProfScope psl(PS_LOSS, c.s);
     TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, c.s));
     TRY(loss_finalize(c.w.bce_partial, render_num_blocks(d->B, d->I), c.w.kl_partial, loss_gauss_kl_blocks(L), c.w.klp, d->B,
                       st->kl_scale, d->vae_beta, loss_out, c.s));
@@ -528,17 +596,23 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     const int N = L.N;
     const int per = d->P * d->P * (d->C + 1);
     // renderer -> d logits, d z_where, d z_pres, d z_depth
-    TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
-                   P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
-                   d->alpha_logit_scale, c.s));
-    // decoder
-    TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N));
-    TRY(bwd_lin(c, LIN_DEC2, per, c.w.dLog, c.w.ld_s, c.w.dHd2, SP_DEC_H2, 0, N, c.w.Hd2, SP_DEC_H2));
-    TRY(wgrad_lin(c, LIN_DEC1, c.w.dHd2, SP_DEC_H2, c.w.Hd1, SP_DEC_H1, grads, N));
-    TRY(bwd_lin(c, LIN_DEC1, SP_DEC_H2, c.w.dHd2, SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 0, N, c.w.Hd1, SP_DEC_H1));
-    TRY(wgrad_lin(c, LIN_DEC0, c.w.dHd1, SP_DEC_H1, c.w.Za, L.ld_rec, grads, N));
-    TRY(bwd_lin(c, LIN_DEC0, SP_DEC_H1, c.w.dHd1, SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, nullptr, 0));
+    {
+        ProfScope ps(PS_RENDER_BWD, c.s);
+        TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
+                       P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
+                       d->alpha_logit_scale, c.s));
+    }
+    {   // decoder
+        ProfScope ps(PS_DECODER_BWD, c.s);
+        { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }
+        { ProfScope p2(PS_DEC2_DGRAD, c.s); TRY(bwd_lin(c, LIN_DEC2, per, c.w.dLog, c.w.ld_s, c.w.dHd2, SP_DEC_H2, 0, N, c.w.Hd2, SP_DEC_H2)); }
+        TRY(wgrad_lin(c, LIN_DEC1, c.w.dHd2, SP_DEC_H2, c.w.Hd1, SP_DEC_H1, grads, N));
+        TRY(bwd_lin(c, LIN_DEC1, SP_DEC_H2, c.w.dHd2, SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 0, N, c.w.Hd1, SP_DEC_H1));
+        TRY(wgrad_lin(c, LIN_DEC0, c.w.dHd1, SP_DEC_H1, c.w.Za, L.ld_rec, grads, N));
+        TRY(bwd_lin(c, LIN_DEC0, SP_DEC_H1, c.w.dHd1, SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, nullptr, 0));
+    }
     // per-cell chain, reverse wavefront order
+    const int ps_cells = prof_begin(PS_CELLS_BWD, c.s);
     for (int t = c.T - 1; t >= 0; --t) {
         const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
         TRY(cells_bwd_pres(L, P, c.H, r0, R, c.s));
@@ -560,6 +634,8 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         TRY(bwd_lin(c, LIN_BOX0, SP_H, P.dHb1, SP_LDH, P.dXb, L.ld_xb, r0, R, nullptr, 0));
     }
     TRY(cells_dfeat_edge(L, P, grads + PL.edge, c.s));
+    prof_end(ps_cells, c.s);
+    const int ps_wg = prof_begin(PS_CELLS_WGRAD, c.s);
     // weight gradients of the per-cell nets: one long-K GEMM per layer over all N rows
     TRY(wgrad_lin(c, LIN_BOX0, P.dHb1, SP_LDH, P.Xb, L.ld_xb, grads, N));
     TRY(wgrad_lin(c, LIN_BOX1, P.dHb2, SP_LDH, P.Hb1, SP_LDH, grads, N));
@@ -575,7 +651,8 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(wgrad_lin(c, LIN_OBJ0, P.dHo1, SP_LDH, P.Xo, L.ld_x, grads, N));
     TRY(wgrad_lin(c, LIN_OBJ1, P.dHo2, SP_LDH, P.Ho1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
-    TRY(backbone_bwd(c, grads));
+    prof_end(ps_wg, c.s);
+    { ProfScope ps(PS_BACKBONE_BWD, c.s); TRY(backbone_bwd(c, grads)); }
     return SPAIR_OK;
 }
 

@@ -23,5 +23,5 @@ struct GemmTN {
     ConvDesc conv;
 };
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);
-int spair_gemm_tn_impl(GemmTN g, bool conv, hipStream_t s);
+int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s);
 int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s);

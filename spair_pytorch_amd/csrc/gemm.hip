@@ -343,12 +343,152 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
         }
 }
 
-int spair_gemm_tn_impl(GemmTN g, bool conv, hipStream_t s) {
+
+// ---- bf16 TN: operands are staged row-major ([r][col], exactly as they sit in HBM) and the k-contiguous
+// MFMA fragments come out of LDS through gfx950's transposing read ds_read_b64_tr_b16: per 16-lane group,
+// lane 4q+p supplies the address of row q / columns 4p..4p+3 of a 4x16 block and receives column (lane&15)
+// of the 4 rows (cdna_hip_programming.md T10).  Two such reads give the 8 k-values a 16x16x32 operand needs.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const __bf16* tile, int ld, int k0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const __bf16* a0 = tile + (k0 + 8 * g + q) * ld + c0 + 4 * p;
+    const __bf16* a1 = a0 + 4 * ld;
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a0));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a1));
+    union { struct { v4s_t lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+template <int BM, int BN, bool BCONV>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
+    constexpr int BK = 32, LDA = BM + 8, LDB = BN + 8;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int NA = BK * BM / 4 / 256, NB = BK * BN / 4 / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int r_begin = blockIdx.z * g.rows_per_split;
+    const int r_end = min(g.R, r_begin + g.rows_per_split);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[NA], rb[NB];
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256, kr = f / (BM / 4), mq = f - kr * (BM / 4);
+            const int r = r0 + kr, m = m0 + mq * 4;
+            ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)r * g.lda + m)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            const int r = r0 + kr, n = n0 + nq * 4;
+            if (r < r_end && n < g.N) {
+                if (BCONV) {
+                    int b, yb, xb;
+                    conv_row_decode(g.conv, r, b, yb, xb);
+                    rb[i] = conv_load4(g.B, g.conv, b, yb, xb, n);
+                } else {
+                    rb[i] = *reinterpret_cast<const float4*>(g.B + (size_t)r * g.ldb + n);
+                }
+            } else {
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256, kr = f / (BM / 4), mq = f - kr * (BM / 4);
+            bf16x4 v;
+            v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+            *reinterpret_cast<bf16x4*>(&As[kr * LDA + mq * 4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            bf16x4 v;
+            v[0] = (__bf16)rb[i].x; v[1] = (__bf16)rb[i].y; v[2] = (__bf16)rb[i].z; v[3] = (__bf16)rb[i].w;
+            *reinterpret_cast<bf16x4*>(&Bs[kr * LDB + nq * 4]) = v;
+        }
+    };
+
+    if (r_begin < r_end) {
+        load_tiles(r_begin);
+        store_tiles();
+        __syncthreads();
+        for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+            const bool more = (r0 + BK) < r_end;
+            if (more) load_tiles(r0 + BK);
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_tr_frag(As, LDA, 0, wm * WM + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = lds_tr_frag(Bs, LDB, 0, wn * WN + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + rgrp + r;
+            if (m >= g.Mstore) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n >= g.Nstore) continue;
+                int nc = n;
+                if (g.cw_cin > 0) { const int tap = n / g.cw_cin, ci = n - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
+                atomicAdd(&g.C[(size_t)m * g.ldc + nc], acc[i][j][r]);
+            }
+        }
+}
+
+template <int BM, int BN>
+static int launch_tn_bf16(GemmTN g, bool conv, hipStream_t s) {
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    int nsplit = max(1, min(ceil_div(g.R, 512), ceil_div(1024, tiles)));
+    int rps = round_up(ceil_div(g.R, nsplit), 32);
+    nsplit = ceil_div(g.R, rps);
+    g.rows_per_split = rps;
+    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), nsplit);
+    if (conv) hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
     if (g.Mstore <= 0) g.Mstore = g.M;
     if (g.Nstore <= 0) g.Nstore = g.N;
     if ((g.M & 3) || (g.N & 3) || (g.lda & 3) || (!conv && (g.ldb & 3))) return SPAIR_ERR_ALIGN;
     if (conv && (g.conv.Cin & 3)) return SPAIR_ERR_ALIGN;
+    if (dtype == SPAIR_BF16) {
+        if (g.M > 64 && g.N > 64) return launch_tn_bf16<128, 128>(g, conv, s);
+        return launch_tn_bf16<64, 64>(g, conv, s);
+    }
+    if (dtype != SPAIR_F32) return SPAIR_ERR_DTYPE;
     constexpr int BM = 64, BN = 64;
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     // aim for ~4 waves of blocks over 256 CUs, at least 256 rows per split
@@ -398,10 +538,10 @@ extern "C" int spair_gemm_nt(const float* A, int lda, const void* B, int ldb, fl
 }
 
 extern "C" int spair_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
-                             void* stream) {
+                             int dtype, void* stream) {
     GemmTN g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.R = R;
-    return spair_gemm_tn_impl(g, false, (hipStream_t)stream);
+    return spair_gemm_tn_impl(g, false, dtype, (hipStream_t)stream);
 }
 
 extern "C" int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {
@@ -432,9 +572,9 @@ extern "C" int spair_gemm_nt_conv(const float* In, const int* conv13, const void
 }
 
 extern "C" int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
-                                  int N, int R, void* stream) {
+                                  int N, int R, int dtype, void* stream) {
     GemmTN g{};
     g.A = A; g.lda = lda; g.B = In; g.ldb = 0; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.R = R;
     g.conv = conv_from_ints(conv13);
-    return spair_gemm_tn_impl(g, true, (hipStream_t)stream);
+    return spair_gemm_tn_impl(g, true, dtype, (hipStream_t)stream);
 }

@@ -56,17 +56,21 @@ def test_gemm_nt(dtype, M, N, K):
     assert (C2.cpu()[:, :N] - ref2).abs().max() <= tol * max(1.0, ref2.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("M,N,R", [(100, 324, 2048), (1568, 256, 4096), (128, 16, 5000), (4, 100, 777), (104, 480, 1000)])
-def test_gemm_tn_and_colsum(M, N, R):
+def test_gemm_tn_and_colsum(M, N, R, dtype):
     L = _lib()
     g = torch.Generator().manual_seed(M * 3 + N + R)
     A = torch.randn(R, M, generator=g)
     B = torch.randn(R, N, generator=g)
     C0 = torch.randn(M, N, generator=g)
     Cd, Ad, Bd = C0.cuda(), A.cuda(), B.cuda()  # keep device tensors alive across the launches
-    rc = L.lib().spair_gemm_tn(L.ptr(Ad), M, L.ptr(Bd), N, L.ptr(Cd), N, M, N, R, L.stream())
+    rc = L.lib().spair_gemm_tn(L.ptr(Ad), M, L.ptr(Bd), N, L.ptr(Cd), N, M, N, R, dtype, L.stream())
     L.check(rc, "gemm_tn")
-    ref = C0.double() + A.double().t() @ B.double()
+    if dtype == 1:
+        ref = C0.double() + A.to(torch.bfloat16).double().t() @ B.to(torch.bfloat16).double()
+    else:
+        ref = C0.double() + A.double().t() @ B.double()
     assert (Cd.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
     out = torch.zeros(M, device="cuda")
     L.check(L.lib().spair_colsum(L.ptr(Ad), M, R, M, L.ptr(out), L.stream()), "colsum")
@@ -109,10 +113,10 @@ def test_conv_fwd_dgrad_wgrad(dtype, B, Hin, Cin, Cout, k, s):
         torch.nn.functional.conv2d(xr, wr, None, stride=s).backward(go)
         go_nhwc = go.permute(0, 2, 3, 1).contiguous().cuda()
         dW = torch.zeros(Cout, K, device="cuda")
-        rc = L.lib().spair_gemm_tn_conv(L.ptr(go_nhwc), Cout, L.ptr(x_nhwc), conv, L.ptr(dW), K, Cout, K, M, L.stream())
+        rc = L.lib().spair_gemm_tn_conv(L.ptr(go_nhwc), Cout, L.ptr(x_nhwc), conv, L.ptr(dW), K, Cout, K, M, dtype, L.stream())
         L.check(rc, "conv wgrad")
         ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(Cout, K)
-        assert (dW.cpu() - ref_dw).abs().max() <= 5e-5 * ref_dw.abs().max()
+        assert (dW.cpu() - ref_dw).abs().max() <= (1e-2 if dtype == 1 else 5e-5) * ref_dw.abs().max()
         # ---- data gradient for k=4,s=2: 4 parity classes, each a 2x2 stride-1 "conv" over dOut
         if k == 4 and s == 2 and dtype == 0:
             dX = torch.zeros(B, Hin, Hin, Cin, device="cuda")
