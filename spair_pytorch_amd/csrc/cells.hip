@@ -2,11 +2,7 @@
 // helpers :292-450), batched over one dependency wavefront (rows r0 .. r0+R-1) per launch.
 // The matmuls between these stages are gemm.hip calls issued by engine.hip.
 #include "cells.h"
-
-__device__ __forceinline__ float clamp10(float x) { return fminf(fmaxf(x, -10.f), 10.f); }
-__device__ __forceinline__ float in10(float x) { return (x >= -10.f && x <= 10.f) ? 1.f : 0.f; }
-// value-preserving freeze (models.py:425): f*x + (1-f)*x
-__device__ __forceinline__ float freeze_val(float f, float x) { return f * x + (1.f - f) * x; }
+#include "cell_math.h"
 
 // ---------------------------------------------------------------------------------------------
 // F1: assemble [feat | context] for the three per-cell nets (models.py:71-76,292-320)
@@ -41,35 +37,20 @@ __global__ __launch_bounds__(128) void k_box_sample(CellLayout L, CellBufs P, Ce
     for (int i = threadIdx.x; i < L.NP; i += blockDim.x) P.Xz[(size_t)r * L.ld_x + L.x_pass + i] = ob[i];
     if (threadIdx.x != 0) return;
     const int h = P.cell_h[cp], w = P.cell_w[cp];
-    float z[4];
+    float eps[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) eps[k] = P.eps_box[(((size_t)b * 4 + k) * L.G + h) * L.G + w];
+    const BoxFwd o = box_forward(ob + L.ob_lat, eps, H, h, w);
     float* st = P.stat + (size_t)r * SP_LDSTAT;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {  // chunk order cy, cx, height, width (models.py:330-331)
-        const float mean = freeze_val(H.wheel, ob[L.ob_lat + k]);
-        const float std_ = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(ob[L.ob_lat + 4 + k])));
-        const float eps = P.eps_box[(((size_t)b * 4 + k) * L.G + h) * L.G + w];
-        z[k] = mean + std_ * eps;
-        st[ST_MU_BOX + k] = mean;
-        st[ST_SD_BOX + k] = std_;
-    }
-    const float ryx = H.max_yx - H.min_yx, rhw = H.max_hw - H.min_hw;
-    const float cell_y = ryx * sigmoidf_(clamp10(z[0])) + H.min_yx;
-    const float cell_x = ryx * sigmoidf_(clamp10(z[1])) + H.min_yx;
-    const float height = rhw * sigmoidf_(clamp10(z[2])) + H.min_hw;
-    const float width = rhw * sigmoidf_(clamp10(z[3])) + H.min_hw;
-    const float ys = height * H.anchor / H.img;
-    const float xs = width * H.anchor / H.img;
-    const float yt = H.cell_over_img * (cell_y + (float)h);
-    const float xt = H.cell_over_img * (cell_x + (float)w);
-    const float box[4] = {cell_x, cell_y, width, height};
-    const float nb[4] = {xt, yt, xs, ys};
-#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        P.rec[(size_t)r * L.ld_rec + k] = box[k];
-        P.Xz[(size_t)r * L.ld_x + L.x_box + k] = box[k];
-        P.Xo[(size_t)r * L.ld_x + L.x_box + k] = box[k];
-        P.nbox[(size_t)r * 4 + k] = nb[k];
-        P.z_where[(((size_t)b * 4 + k) * L.G + h) * L.G + w] = nb[k];
+        st[ST_MU_BOX + k] = o.mu[k];
+        st[ST_SD_BOX + k] = o.sd[k];
+        P.rec[(size_t)r * L.ld_rec + k] = o.box[k];
+        P.Xz[(size_t)r * L.ld_x + L.x_box + k] = o.box[k];
+        P.Xo[(size_t)r * L.ld_x + L.x_box + k] = o.box[k];
+        P.nbox[(size_t)r * 4 + k] = o.nbox[k];
+        P.z_where[(((size_t)b * 4 + k) * L.G + h) * L.G + w] = o.nbox[k];
     }
 }
 
@@ -83,9 +64,9 @@ __global__ __launch_bounds__(64) void k_attr_sample(CellLayout L, CellBufs P, in
     const float* oe = P.Oe + (size_t)r * L.ld_oe;
     for (int j = threadIdx.x; j < L.A; j += blockDim.x) {
         const float mean = oe[j];
-        const float std_ = 2.f * sigmoidf_(clamp10(oe[L.A + j]));
         const float eps = P.eps_attr[(((size_t)b * L.A + j) * L.G + h) * L.G + w];
-        const float attr = mean + std_ * eps;
+        float std_, attr;
+        attr_forward(mean, oe[L.A + j], eps, std_, attr);
         P.sd_attr[(size_t)r * L.ld_rec + j] = std_;
         P.rec[(size_t)r * L.ld_rec + 4 + j] = attr;
         P.Za[(size_t)r * L.ld_rec + j] = attr;
@@ -104,11 +85,9 @@ __global__ __launch_bounds__(128) void k_depth_sample(CellLayout L, CellBufs P, 
     for (int i = threadIdx.x; i < L.NP; i += blockDim.x) P.Xo[(size_t)r * L.ld_x + L.x_pass + i] = oz[i];
     if (threadIdx.x != 0) return;
     const int h = P.cell_h[cp], w = P.cell_w[cp];
-    const float mean = freeze_val(H.wheel, oz[L.oz_lat]);
-    const float std_ = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(oz[L.oz_lat + 1])));
     const float eps = P.eps_depth[((size_t)b * L.G + h) * L.G + w];
-    const float dl = mean + std_ * eps;
-    const float depth = 4.f * sigmoidf_(clamp10(dl));
+    float mean, std_, depth;
+    depth_forward(oz[L.oz_lat], oz[L.oz_lat + 1], eps, H, mean, std_, depth);
     float* st = P.stat + (size_t)r * SP_LDSTAT;
     st[ST_MU_DEPTH] = mean;
     st[ST_SD_DEPTH] = std_;
@@ -125,11 +104,8 @@ __global__ __launch_bounds__(256) void k_pres_sample(CellLayout L, CellBufs P, C
     const int r = r0 + i;
     const int cp = r / L.B, b = r - cp * L.B;
     const int h = P.cell_h[cp], w = P.cell_w[cp];
-    const float logit = freeze_val(H.wheel, P.Oo[(size_t)r * L.ld_oo]);
-    const float lo = clamp10(logit);
     const float u = P.u_pres[((size_t)b * L.G + h) * L.G + w];
-    const float noise = logf(u + 1e-9f) - logf(1.0f - u + 1e-9f);
-    const float pres = sigmoidf_(lo + noise);
+    const float pres = pres_forward(P.Oo[(size_t)r * L.ld_oo], u, H);
     P.rec[(size_t)r * L.ld_rec + L.REC - 1] = pres;
     P.z_pres[((size_t)b * L.G + h) * L.G + w] = pres;
 }
@@ -137,12 +113,6 @@ __global__ __launch_bounds__(256) void k_pres_sample(CellLayout L, CellBufs P, C
 // =============================================================================================
 // Backward stages (reverse wavefront order)
 // =============================================================================================
-__device__ __forceinline__ float kl_gauss(float mu, float sd, float m, float s) {
-    const float vr = (sd / s) * (sd / s);
-    const float t1 = ((mu - m) / s) * ((mu - m) / s);
-    return 0.5f * (vr + t1 - 1.f - logf(vr));
-}
-
 // B1: gather the gradient of this cell's record from its (up to 4) consumers, then presence.
 // One wave per row.
 __global__ __launch_bounds__(256) void k_bwd_pres(CellLayout L, CellBufs P, CellHyper H, int r0, int R) {
@@ -179,15 +149,7 @@ __global__ __launch_bounds__(256) void k_bwd_pres(CellLayout L, CellBufs P, Cell
     gsum_pres = wave_reduce_sum(gsum_pres);
     if (lane == 0) {
         const float z = P.rec[(size_t)r * L.ld_rec + L.REC - 1];
-        const float pz = st[ST_PZ];
-        // d/dz of z*(log(z+e)-log(pz+e)) + (1-z)*(log(1-z+e)-log(1-pz+e))   (models.py:223-226)
-        const float e = 1e-9f;
-        const float dkl = logf(z + e) - logf(pz + e) + z / (z + e) - logf(1.f - z + e) + logf(1.f - pz + e) -
-                          (1.f - z) / (1.f - z + e);
-        const float g = gsum_pres + P.g_pres_r[r] + ks * (kl + dkl);
-        const float logit = P.Oo[(size_t)r * L.ld_oo];  // freeze_val(logit) == logit for wheel in {0,1}
-        const float lf = freeze_val(H.wheel, logit);
-        P.dOo[(size_t)r * L.ld_oo] = g * z * (1.f - z) * in10(lf) * (1.f - H.wheel);
+        P.dOo[(size_t)r * L.ld_oo] = pres_backward(gsum_pres + P.g_pres_r[r], z, st[ST_PZ], kl, P.Oo[(size_t)r * L.ld_oo], ks, H);
     }
 }
 
@@ -201,20 +163,11 @@ __global__ __launch_bounds__(128) void k_bwd_depth(CellLayout L, CellBufs P, Cel
     const int h = P.cell_h[cp], w = P.cell_w[cp];
     const float ks = H.kl_scale * (*P.gloss);
     const float* st = P.stat + (size_t)r * SP_LDSTAT;
-    const float mu = st[ST_MU_DEPTH], sd = st[ST_SD_DEPTH];
     const float eps = P.eps_depth[((size_t)b * L.G + h) * L.G + w];
-    const float dl = mu + sd * eps;
-    const float s = sigmoidf_(clamp10(dl));
     const float zp = P.rec[(size_t)r * L.ld_rec + L.REC - 1];
     const float g_depth = P.grec[(size_t)r * L.ld_rec + 4 + L.A] + P.dXo[(size_t)r * L.ld_x + L.x_depth] + P.g_depth_r[r];
-    const float g_dl = g_depth * 4.f * s * (1.f - s) * in10(dl);
-    const float m = H.prior_mean[5], ps = H.prior_std[5];
-    const float g_mu = (g_dl + ks * zp * (mu - m) / (ps * ps)) * (1.f - H.wheel);
-    const float g_sd = (g_dl * eps + ks * zp * (sd / (ps * ps) - 1.f / sd)) * (1.f - H.wheel);
-    const float ls = P.Oz[(size_t)r * L.ld_oz + L.oz_lat + 1];
-    const float sl = sigmoidf_(clamp10(ls));
-    doz[L.oz_lat] = g_mu;
-    doz[L.oz_lat + 1] = g_sd * 2.f * sl * (1.f - sl) * in10(ls);
+    depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], P.Oz[(size_t)r * L.ld_oz + L.oz_lat + 1], eps, zp, ks, H, doz[L.oz_lat],
+                   doz[L.oz_lat + 1]);
 }
 
 // B9: attributes -> gradient of the encoder output
@@ -224,19 +177,12 @@ __global__ __launch_bounds__(64) void k_bwd_attr(CellLayout L, CellBufs P, CellH
     const int h = P.cell_h[cp], w = P.cell_w[cp];
     const float ks = H.kl_scale * (*P.gloss);
     const float zp = P.rec[(size_t)r * L.ld_rec + L.REC - 1];
-    const float m = H.prior_mean[4], ps = H.prior_std[4];
     for (int j = threadIdx.x; j < L.A; j += blockDim.x) {
         const float g = P.grec[(size_t)r * L.ld_rec + 4 + j] + P.dXz[(size_t)r * L.ld_x + L.x_attr + j] +
                         P.dXo[(size_t)r * L.ld_x + L.x_attr + j] + P.g_attr_r[(size_t)r * L.ld_rec + j];
-        const float mu = P.Oe[(size_t)r * L.ld_oe + j];
-        const float sd = P.sd_attr[(size_t)r * L.ld_rec + j];
         const float eps = P.eps_attr[(((size_t)b * L.A + j) * L.G + h) * L.G + w];
-        const float g_mu = g + ks * zp * (mu - m) / (ps * ps);
-        const float g_sd = g * eps + ks * zp * (sd / (ps * ps) - 1.f / sd);
-        const float ls = P.Oe[(size_t)r * L.ld_oe + L.A + j];
-        const float sl = sigmoidf_(clamp10(ls));
-        P.dOe[(size_t)r * L.ld_oe + j] = g_mu;
-        P.dOe[(size_t)r * L.ld_oe + L.A + j] = g_sd * 2.f * sl * (1.f - sl) * in10(ls);
+        attr_backward(g, P.Oe[(size_t)r * L.ld_oe + j], P.sd_attr[(size_t)r * L.ld_rec + j], P.Oe[(size_t)r * L.ld_oe + L.A + j], eps, zp, ks,
+                      H, P.dOe[(size_t)r * L.ld_oe + j], P.dOe[(size_t)r * L.ld_oe + L.A + j]);
     }
 }
 
@@ -259,29 +205,10 @@ __global__ __launch_bounds__(128) void k_bwd_box(CellLayout L, CellBufs P, CellH
         gb[k] = P.grec[(size_t)r * L.ld_rec + k] + P.dXz[(size_t)r * L.ld_x + L.x_box + k] +
                 P.dXo[(size_t)r * L.ld_x + L.x_box + k];  // (cell_x, cell_y, width, height)
     }
-    const float ryx = H.max_yx - H.min_yx, rhw = H.max_hw - H.min_hw;
-    // gradient wrt the 4 squashed quantities in latent order (cy, cx, height, width)
-    const float gq[4] = {
-        (gb[1] + gn[1] * H.cell_over_img) * ryx,   // cell_y
-        (gb[0] + gn[0] * H.cell_over_img) * ryx,   // cell_x
-        (gb[3] + gn[3] * H.anchor / H.img) * rhw,  // height
-        (gb[2] + gn[2] * H.anchor / H.img) * rhw,  // width
-    };
+    float eps[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float mu = st[ST_MU_BOX + k], sd = st[ST_SD_BOX + k];
-        const float eps = P.eps_box[(((size_t)b * 4 + k) * L.G + h) * L.G + w];
-        const float z = mu + sd * eps;
-        const float s = sigmoidf_(clamp10(z));
-        const float g_z = gq[k] * s * (1.f - s) * in10(z);
-        const float m = H.prior_mean[k], ps = H.prior_std[k];
-        const float g_mu = (g_z + ks * zp * (mu - m) / (ps * ps)) * (1.f - H.wheel);
-        const float g_sd = (g_z * eps + ks * zp * (sd / (ps * ps) - 1.f / sd)) * (1.f - H.wheel);
-        const float ls = P.Ob[(size_t)r * L.ld_ob + L.ob_lat + 4 + k];
-        const float sl = sigmoidf_(clamp10(ls));
-        dob[L.ob_lat + k] = g_mu;
-        dob[L.ob_lat + 4 + k] = g_sd * 2.f * sl * (1.f - sl) * in10(ls);
-    }
+    for (int k = 0; k < 4; ++k) eps[k] = P.eps_box[(((size_t)b * 4 + k) * L.G + h) * L.G + w];
+    box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, P.Ob + (size_t)r * L.ld_ob + L.ob_lat + 4, zp, ks, H, dob + L.ob_lat);
 }
 
 // After the loop: d feat = sum of the three nets' feature-column gradients (row order (b,h,w)),

@@ -1,0 +1,17 @@
+#pragma once
+#include "cells.h"
+
+enum ChainW { CW_BOX0, CW_BOX1, CW_BOXH, CW_ENC0, CW_ENC1, CW_ENC2, CW_Z0, CW_Z1, CW_ZH, CW_OBJ0, CW_OBJ1, CW_OBJ2, CW_COUNT };
+
+struct ChainArgs {
+    CellLayout L;
+    CellBufs P;
+    CellHyper H;
+    const uint4* w[CW_COUNT];     // fragment-packed bf16 weights (k_prep mode 4 / 5)
+    const float* bias[CW_COUNT];
+    const float* x;
+    int I, Pp, ac;
+};
+
+int chain_fwd_supported(const SpairDims& d);
+int chain_fwd(const ChainArgs& a, hipStream_t s);

@@ -10,6 +10,7 @@
 #include "cells.h"
 #include "gemm.h"
 #include "misc.h"
+#include "chain.h"
 
 // kernels in other translation units
 int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, hipStream_t s);
@@ -114,6 +115,7 @@ struct Ws {
     void* lin_wf[LIN_COUNT];     // heads: BOXH1 / ZH1 slots hold the concatenated [pass | lat] matrix
     void* lin_wt[LIN_COUNT];
     float *bias_boxh, *bias_zh;
+    void* chain_w[CW_COUNT];      // fragment-packed weights for the fused chain (bf16)
     float* xpad;
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
     float *feat, *dfeat;
@@ -170,6 +172,11 @@ static Ws carve(const SpairDims& d, void* base) {
     }
     w.bias_boxh = c.take<float>(L.NP + 8);
     w.bias_zh = c.take<float>(L.NP + 8);
+    if (chain_fwd_supported(d)) {
+        const int nt[CW_COUNT] = {7, 7, 7, 16, 8, 7, 7, 7, 7, 7, 7, 1};
+        const int kt[CW_COUNT] = {11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4, 4};
+        for (int i = 0; i < CW_COUNT; ++i) w.chain_w[i] = c.take_bytes((size_t)nt[i] * kt[i] * 1024);
+    }
     // backbone
     const int Ip = d.I + d.pad_pre + d.pad_post;
     w.xpad = c.take<float>((size_t)d.B * Ip * Ip * d.C);
@@ -289,6 +296,7 @@ struct Ctx {
     const float* x;
     hipStream_t s;
     int T;                 // number of wavefront diagonals
+    int use_chain;         // fused persistent per-cell kernels (bf16, reference network sizes)
     std::vector<int> dstart;
 };
 
@@ -325,6 +333,7 @@ static int make_ctx(Ctx& c, const SpairDims* d, const SpairStep* st, const float
     c.w.cb.edge = params + c.PL.edge;
     c.w.cb.eps_box = eps_box; c.w.cb.eps_attr = eps_attr; c.w.cb.eps_depth = eps_depth; c.w.cb.u_pres = u_pres;
     fill_diag(c);
+    c.use_chain = chain_fwd_supported(*d) && !(st->flags & 1);
     return SPAIR_OK;
 }
 
@@ -355,6 +364,7 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
     auto push = [&](const float* src, void* dst, int rows, int cols, int ld, int mode, int bf16, int cin = 0, int cout = 0, int k = 0,
                     int py = 0, int px = 0, int T = 0, int s = 0) {
         PrepEntry e;
+        memset(&e, 0, sizeof(e));
         e.src = src; e.dst = dst; e.rows = rows; e.cols = cols; e.ld = ld; e.mode = mode; e.bf16 = bf16;
         e.cin = cin; e.cout = cout; e.k = k; e.py = py; e.px = px; e.T = T; e.s = s;
         es.push_back(e);
@@ -392,6 +402,29 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
             push(c.params + h.w, const_cast<void*>(bptr(c.w.lin_wf[id], (size_t)l.out * ldf, c.d.dtype)), h.out, h.in, ldf, 0, bf);
             if (need_dgrad) push(c.params + h.w, const_cast<void*>(bptr(c.w.lin_wt[id], (size_t)l.out, c.d.dtype)), h.in, h.out, ldt, 1, bf);
         }
+    }
+    if (c.use_chain) {
+        auto pack = [&](int cw, int lin_id, int KT, int ksplit, int kpad0, int n_off) {
+            const LinSpec& l = c.PL.lin[lin_id];
+            PrepEntry e;
+            memset(&e, 0, sizeof(e));
+            e.src = c.params + l.w; e.dst = c.w.chain_w[cw]; e.rows = l.out; e.cols = l.in; e.mode = 4; e.bf16 = 1;
+            e.KT = KT; e.ksplit = ksplit; e.kpad0 = kpad0; e.n_off = n_off;
+            es.push_back(e);
+        };
+        const int fc = c.L.F + c.L.CTX;   // 324
+        pack(CW_BOX0, LIN_BOX0, 11, fc, 352, 0);
+        pack(CW_BOX1, LIN_BOX1, 4, SP_H, 128, 0);
+        pack(CW_BOXH, LIN_BOXH1, 4, SP_H, 128, 0); pack(CW_BOXH, LIN_BOXH0, 4, SP_H, 128, c.L.NP);
+        pack(CW_ENC0, LIN_ENC0, 25, 784, 800, 0);
+        pack(CW_ENC1, LIN_ENC1, 8, 256, 256, 0);
+        pack(CW_ENC2, LIN_ENC2, 4, 128, 128, 0);
+        pack(CW_Z0, LIN_Z0, 16, fc, 352, 0);
+        pack(CW_Z1, LIN_Z1, 4, SP_H, 128, 0);
+        pack(CW_ZH, LIN_ZH1, 4, SP_H, 128, 0); pack(CW_ZH, LIN_ZH0, 4, SP_H, 128, c.L.NP);
+        pack(CW_OBJ0, LIN_OBJ0, 16, fc, 352, 0);
+        pack(CW_OBJ1, LIN_OBJ1, 4, SP_H, 128, 0);
+        pack(CW_OBJ2, LIN_OBJ2, 4, SP_H, 128, 0);
     }
     push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
     push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
@@ -501,6 +534,17 @@ static int cells_fwd(Ctx& c) {
     CellBufs& P = c.w.cb;
     const ParamLayout& PL = c.PL;
     const float* pr = c.params;
+    if (c.use_chain) {
+        ChainArgs a;
+        a.L = L; a.P = P; a.H = c.H;
+        for (int i = 0; i < CW_COUNT; ++i) a.w[i] = reinterpret_cast<const uint4*>(c.w.chain_w[i]);
+        a.bias[CW_BOX0] = pr + PL.lin[LIN_BOX0].b; a.bias[CW_BOX1] = pr + PL.lin[LIN_BOX1].b; a.bias[CW_BOXH] = c.w.bias_boxh;
+        a.bias[CW_ENC0] = pr + PL.lin[LIN_ENC0].b; a.bias[CW_ENC1] = pr + PL.lin[LIN_ENC1].b; a.bias[CW_ENC2] = pr + PL.lin[LIN_ENC2].b;
+        a.bias[CW_Z0] = pr + PL.lin[LIN_Z0].b; a.bias[CW_Z1] = pr + PL.lin[LIN_Z1].b; a.bias[CW_ZH] = c.w.bias_zh;
+        a.bias[CW_OBJ0] = pr + PL.lin[LIN_OBJ0].b; a.bias[CW_OBJ1] = pr + PL.lin[LIN_OBJ1].b; a.bias[CW_OBJ2] = pr + PL.lin[LIN_OBJ2].b;
+        a.x = c.x; a.I = c.d.I; a.Pp = c.d.P; a.ac = c.d.align_corners;
+        return chain_fwd(a, c.s);
+    }
     for (int t = 0; t < c.T; ++t) {
         const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
         TRY(cells_ctx_gather(L, P, r0, R, c.s));

@@ -7,6 +7,7 @@ struct PrepEntry {
     int rows, cols, ld;   // destination geometry
     int mode, bf16;
     int cin, cout, k, py, px, T, s;
+    int KT, ksplit, kpad0, n_off;   // mode 4/5: MFMA-fragment packing (chain.hip)
 };
 #define SP_MAX_PREP 32
 struct PrepTable {

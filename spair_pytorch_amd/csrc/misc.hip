@@ -93,9 +93,25 @@ int misc_pad_input(const float* x, float* xp, int B, int C, int I, int pre, int 
 // mode 0: dst[r][c] = src[r*cols + c]                      (copy / pad / convert)
 // mode 1: dst[r][c] = src[c*rows + r]                      (transpose: dst rows = src cols)
 // mode 2: conv OIHW -> [O][ky][kx][ci]: src[((r*Cin+ci)*k+ky)*k+kx], c=(ky*k+kx)*Cin+ci
+// mode 4: MFMA-fragment packing of a Linear weight src[rows][cols] for the fused chain (forward, B[k][n] = W[n][k]):
+//         fragment (nt,kt) = 64 lanes x 8 bf16, lane l holds W[nt*16 + (l&15)][kk], kk = kt*32 + 8*(l>>4) + j; packed k -> source
+//         column: kk < kpad0 ? (kk < ksplit ? kk : none) : ksplit + (kk - kpad0); rows are offset by n_off (concatenated heads)
 // mode 3: conv dgrad class (py,px), stride s, T=k/s taps: dst[ci][(ty*T+tx)*O + co] = src[((co*Cin+ci)*k + py+s*ty)*k + px+s*tx]
 __global__ __launch_bounds__(256) void k_prep(PrepTable T) {
     const PrepEntry e = T.e[blockIdx.y];
+    if (e.mode == 4) {
+        const int KP = e.KT * 32;
+        const long long n4 = (long long)e.rows * KP;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long long)gridDim.x * blockDim.x) {
+            const int r = (int)(idx / KP), kk = (int)(idx - (long long)r * KP);
+            int col = (kk < e.kpad0) ? (kk < e.ksplit ? kk : -1) : e.ksplit + (kk - e.kpad0);
+            if (col >= e.cols) col = -1;
+            const float v = col >= 0 ? e.src[(size_t)r * e.cols + col] : 0.f;
+            const int nn = e.n_off + r, nt = nn >> 4, li = nn & 15, kt = kk >> 5, g = (kk & 31) >> 3, j = kk & 7;
+            reinterpret_cast<__bf16*>(e.dst)[(((size_t)nt * e.KT + kt) * 64 + g * 16 + li) * 8 + j] = (__bf16)v;
+        }
+        return;
+    }
     const long long n = (long long)e.rows * e.cols;   // pad columns are never written (workspace is zero-initialised)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / e.cols), c = (int)(idx - (long long)r * e.cols);

@@ -43,8 +43,10 @@ class SpairDims(ctypes.Structure):
 class SpairStep(ctypes.Structure):
     """include/spair_hip.h :: SpairStep"""
     _fields_ = [("wheel", ctypes.c_float), ("count_prior_prob", ctypes.c_float), ("kl_scale", ctypes.c_float),
-                ("train", ctypes.c_int)]
+                ("train", ctypes.c_int), ("flags", ctypes.c_int)]
 
+
+STEP_FLAGS = 0   # bit 0: disable the fused persistent per-cell kernels (tests compare both paths)
 
 _DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
@@ -81,6 +83,7 @@ def step_scalars(global_step, batch, world_size=1, train=True):
     st.count_prior_prob = float(1 / ((-lo).exp() + 1))
     st.kl_scale = 1.0 / (batch * world_size)
     st.train = int(train)
+    st.flags = int(STEP_FLAGS)
     return st
 
 
