@@ -9,9 +9,13 @@ struct ChainArgs {
     CellHyper H;
     const uint4* w[CW_COUNT];     // fragment-packed bf16 weights (k_prep mode 4 / 5)
     const float* bias[CW_COUNT];
+    const uint4* wt[CW_COUNT];    // data-gradient packs (k_prep mode 5): B[k=out][n=in]
+    const float* w_obj2;          // obj_network.out.weight [1,100] fp32 (rank-1 data-gradient)
+    float* gedge;                 // gradient of virtual_edge_element
     const float* x;
     int I, Pp, ac;
 };
 
 int chain_fwd_supported(const SpairDims& d);
 int chain_fwd(const ChainArgs& a, hipStream_t s);
+int chain_bwd(const ChainArgs& a, hipStream_t s);

@@ -381,6 +381,348 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     }
 }
 
+
+// =============================================================================================
+// Backward: the same ownership (one workgroup per sample), wavefronts in reverse order.  Data-gradient
+// chain only -- every layer's pre-activation gradient is written to its HBM row buffer and the weight
+// gradients are long-K GEMMs over all rows afterwards.  The input gradients of the three per-cell nets
+// never go to HBM: their [feat | context] part is summed in a 4-deep LDS ring (a cell's record gradient
+// is gathered from its <= 4 consumers' context columns, which live in wavefronts t+1..t+3), the feature
+// part is emitted as d feat, out-of-grid context slots accumulate the edge element's gradient in LDS.
+// The glimpse gradient is consumed in the epilogue of the encoder's first-layer data-gradient GEMM
+// (bilinear taps of x -> d z_where) and is never stored.
+// =============================================================================================
+namespace {
+
+constexpr int LD_R = 328;      // ring row: [feat 100 | ctx 224] fp32
+
+// out[16, NT*16] = in[16, 32*KT] . Wt ; wide-N / short-K form: A fragments held in registers, column tiles streamed with a 2-tile
+// weight-fragment double buffer; `epi(nt, acc)` consumes each tile as soon as it is complete.
+template <int KT, int NT, class Epi>
+__device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uint4* __restrict__ Wt, int wave, int lane, Epi epi) {
+    bf16x8 af[KT];
+    const int arow = lane & 15, kg = (lane >> 4) * 8;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) af[kt] = *reinterpret_cast<const bf16x8*>(in + arow * ld + kt * 32 + kg);
+    uint4 bq[2][KT];
+    if (wave < NT) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) bq[0][kt] = Wt[(size_t)(wave * KT + kt) * 64 + lane];
+    }
+    // two tiles per trip so that the double-buffer indices are static (no scratch) while the code is emitted only twice
+#pragma unroll 1
+    for (int nt0 = wave; nt0 < NT; nt0 += 2 * NW) {
+        const int nt1 = nt0 + NW, nt2 = nt0 + 2 * NW;
+        if (nt1 < NT) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) bq[1][kt] = Wt[(size_t)(nt1 * KT + kt) * 64 + lane];
+        }
+        {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[0][kt]), acc, 0, 0, 0);
+            epi(nt0, acc);
+        }
+        if (nt2 < NT) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) bq[0][kt] = Wt[(size_t)(nt2 * KT + kt) * 64 + lane];
+        }
+        if (nt1 < NT) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[1][kt]), acc, 0, 0, 0);
+            epi(nt1, acc);
+        }
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float ring[4][MT][LD_R];
+    __shared__ __attribute__((aligned(16))) float tailO[MT][KX];
+    __shared__ __attribute__((aligned(16))) float tailZ[MT][KX];
+    __shared__ __attribute__((aligned(16))) __bf16 Aa[MT * LD_H];
+    __shared__ __attribute__((aligned(16))) __bf16 Ab[MT * LD_H];
+    __shared__ float grec[MT][REC];
+    __shared__ float gnb[MT][4], nb_sh[MT][4];
+    __shared__ float dOo_sh[MT], zp_sh[MT];
+    __shared__ float edge_acc[REC];
+    __shared__ int row_r[MT], row_h[MT], row_w[MT];
+    __shared__ int cons_sh[MT][4], nbr_row[MT][4];
+    __shared__ int dstart_sh[3 * 32 + 2];
+
+    const CellLayout& L = a.L;
+    const CellBufs& P = a.P;
+    const CellHyper& H = a.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int G = L.G, T = 3 * G - 2;
+    const float ks = H.kl_scale * (*P.gloss);
+
+    for (int i = tid; i < MT * LD_H; i += NTH) { Aa[i] = (__bf16)0.f; Ab[i] = (__bf16)0.f; }
+    for (int i = tid; i < 4 * MT * LD_R; i += NTH) (&ring[0][0][0])[i] = 0.f;
+    for (int i = tid; i < MT * KX; i += NTH) { (&tailO[0][0])[i] = 0.f; (&tailZ[0][0])[i] = 0.f; }
+    for (int i = tid; i <= T; i += NTH) dstart_sh[i] = P.diag_start[i];
+    if (tid < REC) edge_acc[tid] = 0.f;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int c0 = dstart_sh[t];
+        const int nc = dstart_sh[t + 1] - c0;
+        float (*slot)[LD_R] = ring[t & 3];
+        if (tid < MT) {
+            const int cp = c0 + min(tid, nc - 1);
+            const int r = cp * L.B + b;
+            row_r[tid] = r;
+            row_h[tid] = P.cell_h[cp];
+            row_w[tid] = P.cell_w[cp];
+            zp_sh[tid] = P.rec[(size_t)r * L.ld_rec + REC - 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cons_sh[tid][k] = P.cons[cp * 4 + k];
+                nbr_row[tid][k] = P.nbr[cp * 4 + k];
+                nb_sh[tid][k] = P.nbox[(size_t)r * 4 + k];
+                gnb[tid][k] = 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
+        for (int idx = tid; idx < nc * REC; idx += NTH) {
+            const int row = idx / REC, j = idx - row * REC;
+            float g = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int q = cons_sh[row][s];
+                if (q < 0) continue;
+                const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);
+                g += ring[(t + dt) & 3][q - dstart_sh[t + dt]][F + s * REC + j];
+            }
+            grec[row][j] = g;
+        }
+        __syncthreads();
+        // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit)
+        {
+            const int row = tid >> 5, l = tid & 31;
+            float kl = 0.f;
+            if (row < nc) {
+                const size_t r = row_r[row];
+                const float* st = P.stat + r * SP_LDSTAT;
+                for (int j = l; j < A_; j += 32)
+                    kl += kl_gauss(P.Oe[r * L.ld_oe + j], P.sd_attr[r * L.ld_rec + j], H.prior_mean[4], H.prior_std[4]);
+                if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], H.prior_mean[l], H.prior_std[l]);
+                if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], H.prior_mean[5], H.prior_std[5]);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
+            if (row < nc && l == 0) {
+                const size_t r = row_r[row];
+                const float d = pres_backward(grec[row][REC - 1] + P.g_pres_r[r], zp_sh[row], P.stat[r * SP_LDSTAT + ST_PZ], kl,
+                                              P.Oo[r * L.ld_oo], ks, H);
+                dOo_sh[row] = d;
+                P.dOo[r * L.ld_oo] = d;
+            }
+        }
+        __syncthreads();
+        // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu
+        for (int idx = tid; idx < MT * SP_H; idx += NTH) {
+            const int row = idx / SP_H, n = idx - row * SP_H;
+            float v = 0.f;
+            if (row < nc) {
+                const size_t r = row_r[row];
+                v = (P.Ho2[r * SP_LDH + n] > 0.f) ? dOo_sh[row] * a.w_obj2[n] : 0.f;
+                P.dHo2[r * SP_LDH + n] = v;
+            }
+            Aa[row * LD_H + n] = (__bf16)v;
+        }
+        __syncthreads();
+        auto hidden_epi = [&](const float* __restrict__ Hm, int ldh, float* __restrict__ dOut, int nout, __bf16* dst) {
+            return [=](int nt, const f32x4& acc) {
+                const int n = nt * 16 + (lane & 15);
+                if (n >= nout) return;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = (lane >> 4) * 4 + rr;
+                    float v = 0.f;
+                    if (row < nc) {
+                        const size_t r = row_r[row];
+                        v = (Hm[r * ldh + n] > 0.f) ? acc[rr] : 0.f;
+                        dOut[r * ldh + n] = v;
+                    }
+                    dst[row * LD_H + n] = (__bf16)v;
+                }
+            };
+        };
+        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_OBJ1], wave, lane, hidden_epi(P.Ho1, SP_LDH, P.dHo1, SP_H, Ab));
+        __syncthreads();
+        wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int nt, const f32x4& acc) {
+            const int n = nt * 16 + (lane & 15);
+            if (n >= F + CTX + KX) return;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = (lane >> 4) * 4 + rr;
+                if (n < F + CTX) slot[row][n] = acc[rr];
+                else tailO[row][n - (F + CTX)] = acc[rr];
+            }
+        });
+        __syncthreads();
+        // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
+        for (int idx = tid; idx < MT * NP; idx += NTH) {
+            const int row = idx / NP, i = idx - row * NP;
+            const float v = row < nc ? tailO[row][i] : 0.f;
+            Aa[row * LD_H + i] = (__bf16)v;
+            if (row < nc) P.dOz[(size_t)row_r[row] * L.ld_oz + i] = v;
+        }
+        if (tid < MT) {
+            float d_mu = 0.f, d_ls = 0.f;
+            if (tid < nc) {
+                const size_t r = row_r[tid];
+                const float* st = P.stat + r * SP_LDSTAT;
+                const float eps = P.eps_depth[((size_t)b * G + row_h[tid]) * G + row_w[tid]];
+                const float g_depth = grec[tid][4 + A_] + tailO[tid][NP + 4 + A_] + P.g_depth_r[r];
+                depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], P.Oz[r * L.ld_oz + NP + 1], eps, zp_sh[tid], ks, H, d_mu, d_ls);
+                P.dOz[r * L.ld_oz + NP] = d_mu;
+                P.dOz[r * L.ld_oz + NP + 1] = d_ls;
+            }
+            Aa[tid * LD_H + NP] = (__bf16)d_mu;
+            Aa[tid * LD_H + NP + 1] = (__bf16)d_ls;
+        }
+        __syncthreads();
+        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_ZH], wave, lane, hidden_epi(P.Hz2, SP_LDH, P.dHz2, SP_H, Ab));
+        __syncthreads();
+        wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_Z1], wave, lane, hidden_epi(P.Hz1, SP_LDH, P.dHz1, SP_H, Aa));
+        __syncthreads();
+        wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int nt, const f32x4& acc) {
+            const int n = nt * 16 + (lane & 15);
+            if (n >= F + CTX + KX) return;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = (lane >> 4) * 4 + rr;
+                if (n < F + CTX) slot[row][n] += acc[rr];
+                else tailZ[row][n - (F + CTX)] = acc[rr];
+            }
+        });
+        __syncthreads();
+        // ---- attributes -> gradient of the encoder output
+        for (int idx = tid; idx < MT * A_; idx += NTH) {
+            const int row = idx / A_, j = idx - row * A_;
+            float d_mean = 0.f, d_ls = 0.f;
+            if (row < nc) {
+                const size_t r = row_r[row];
+                const float g = grec[row][4 + j] + tailZ[row][NP + 4 + j] + tailO[row][NP + 4 + j] + P.g_attr_r[r * L.ld_rec + j];
+                const float eps = P.eps_attr[(((size_t)b * A_ + j) * G + row_h[row]) * G + row_w[row]];
+                attr_backward(g, P.Oe[r * L.ld_oe + j], P.sd_attr[r * L.ld_rec + j], P.Oe[r * L.ld_oe + A_ + j], eps, zp_sh[row], ks, H, d_mean, d_ls);
+                P.dOe[r * L.ld_oe + j] = d_mean;
+                P.dOe[r * L.ld_oe + A_ + j] = d_ls;
+            }
+            Ab[row * LD_H + j] = (__bf16)d_mean;
+            Ab[row * LD_H + A_ + j] = (__bf16)d_ls;
+        }
+        __syncthreads();
+        wg_gemm_wide<4, 8>(Ab, LD_H, a.wt[CW_ENC2], wave, lane, hidden_epi(P.He2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa));
+        __syncthreads();
+        wg_gemm_wide<4, 16>(Aa, LD_H, a.wt[CW_ENC1], wave, lane, hidden_epi(P.He1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab));
+        __syncthreads();
+        // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273); the glimpse gradient is never stored
+        wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int nt, const f32x4& acc) {
+            const int e = nt * 16 + (lane & 15);
+            const bool ok = e < GLN;
+            const int i = ok ? e / a.Pp : 0, j = ok ? e - i * a.Pp : 0;
+            const float* img = a.x + (size_t)b * a.I * a.I;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = (lane >> 4) * 4 + rr;
+                float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f;
+                if (ok && row < nc) {
+                    float ix, iy, mx, my;
+                    const float X = stn_src_coord(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, j, a.Pp, a.I, a.ac, true, ix, mx);
+                    const float Y = stn_src_coord(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, i, a.Pp, a.I, a.ac, true, iy, my);
+                    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+                    const float wx1 = ix - (float)x0, wy1 = iy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                    const bool xin = (x0 + 1) < a.I, yin = (y0 + 1) < a.I;
+                    const float v00 = img[y0 * a.I + x0];
+                    const float v01 = xin ? img[y0 * a.I + x0 + 1] : 0.f;
+                    const float v10 = yin ? img[(y0 + 1) * a.I + x0] : 0.f;
+                    const float v11 = (xin && yin) ? img[(y0 + 1) * a.I + x0 + 1] : 0.f;
+                    const float g = acc[rr];
+                    const float gix = g * ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
+                    const float giy = g * ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
+                    g_tx = gix; g_xs = gix * X; g_ty = giy; g_ys = giy * Y;
+                }
+                // reduce over the 16 lanes that share this row (same lane>>4), then one LDS atomic per value
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    g_tx += __shfl_xor(g_tx, o, 64); g_ty += __shfl_xor(g_ty, o, 64);
+                    g_xs += __shfl_xor(g_xs, o, 64); g_ys += __shfl_xor(g_ys, o, 64);
+                }
+                if ((lane & 15) == 0 && row < nc) {
+                    atomicAdd(&gnb[row][0], 2.f * g_tx); atomicAdd(&gnb[row][1], 2.f * g_ty);
+                    atomicAdd(&gnb[row][2], g_xs); atomicAdd(&gnb[row][3], g_ys);
+                }
+            }
+        });
+        __syncthreads();
+        // ---- box (models.py:322-381 backward); passthrough gradient -> box-net head
+        for (int idx = tid; idx < MT * NP; idx += NTH) {
+            const int row = idx / NP, i = idx - row * NP;
+            const float v = row < nc ? tailZ[row][i] : 0.f;
+            Aa[row * LD_H + i] = (__bf16)v;
+            if (row < nc) P.dOb[(size_t)row_r[row] * L.ld_ob + i] = v;
+        }
+        if (tid < MT) {
+            float dlat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (tid < nc) {
+                const size_t r = row_r[tid];
+                const float* st = P.stat + r * SP_LDSTAT;
+                float gn[4], gb[4], eps[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gn[k] = gnb[tid][k] + P.g_nbox_r[r * 4 + k];
+                    gb[k] = grec[tid][k] + tailZ[tid][NP + k] + tailO[tid][NP + k];
+                    eps[k] = P.eps_box[(((size_t)b * 4 + k) * G + row_h[tid]) * G + row_w[tid]];
+                }
+                box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, P.Ob + r * L.ld_ob + NP + 4, zp_sh[tid], ks, H, dlat);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) P.dOb[r * L.ld_ob + NP + k] = dlat[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Aa[tid * LD_H + NP + k] = (__bf16)dlat[k];
+        }
+        __syncthreads();
+        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_BOXH], wave, lane, hidden_epi(P.Hb2, SP_LDH, P.dHb2, SP_H, Ab));
+        __syncthreads();
+        wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_BOX1], wave, lane, hidden_epi(P.Hb1, SP_LDH, P.dHb1, SP_H, Aa));
+        __syncthreads();
+        wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int nt, const f32x4& acc) {
+            const int n = nt * 16 + (lane & 15);
+            if (n >= F + CTX) return;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) slot[(lane >> 4) * 4 + rr][n] += acc[rr];
+        });
+        __syncthreads();
+        // ---- d feat out; out-of-grid context slots feed the learned edge element
+        for (int idx = tid; idx < nc * (F + CTX); idx += NTH) {
+            const int row = idx / (F + CTX), n = idx - row * (F + CTX);
+            const float v = slot[row][n];
+            if (n < F) {
+                P.dfeat[((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n] = v;
+            } else {
+                const int s = (n - F) / REC;
+                if (nbr_row[row][s] < 0) atomicAdd(&edge_acc[(n - F) - s * REC], v);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < REC) atomicAdd(&a.gedge[tid], edge_acc[tid]);
+}
+
+int chain_bwd(const ChainArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_bwd, dim3(a.L.B), dim3(NTH), 0, s, a);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
 int chain_fwd_supported(const SpairDims& d) {
     return d.dtype == SPAIR_BF16 && d.F == F && d.A == A_ && d.NP == NP && d.P == 28 && d.C == 1 && d.G <= 32 &&
            (d.G + 1) / 2 <= MT && d.G >= 2;

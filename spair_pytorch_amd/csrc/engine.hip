@@ -116,6 +116,7 @@ struct Ws {
     void* lin_wt[LIN_COUNT];
     float *bias_boxh, *bias_zh;
     void* chain_w[CW_COUNT];      // fragment-packed weights for the fused chain (bf16)
+    void* chain_wt[CW_COUNT];     // ... and their data-gradient packs
     float* xpad;
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
     float *feat, *dfeat;
@@ -176,6 +177,9 @@ static Ws carve(const SpairDims& d, void* base) {
         const int nt[CW_COUNT] = {7, 7, 7, 16, 8, 7, 7, 7, 7, 7, 7, 1};
         const int kt[CW_COUNT] = {11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4, 4};
         for (int i = 0; i < CW_COUNT; ++i) w.chain_w[i] = c.take_bytes((size_t)nt[i] * kt[i] * 1024);
+        const int ntb[CW_COUNT] = {21, 7, 7, 49, 16, 8, 30, 7, 7, 30, 7, 0};
+        const int ktb[CW_COUNT] = {4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0};
+        for (int i = 0; i < CW_COUNT; ++i) w.chain_wt[i] = ntb[i] ? c.take_bytes((size_t)ntb[i] * ktb[i] * 1024) : nullptr;
     }
     // backbone
     const int Ip = d.I + d.pad_pre + d.pad_post;
@@ -425,6 +429,22 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
         pack(CW_OBJ0, LIN_OBJ0, 16, fc, 352, 0);
         pack(CW_OBJ1, LIN_OBJ1, 4, SP_H, 128, 0);
         pack(CW_OBJ2, LIN_OBJ2, 4, SP_H, 128, 0);
+        if (need_dgrad) {
+            auto packt = [&](int cw, int lin_id, int KT, int k_off) {
+                const LinSpec& l = c.PL.lin[lin_id];
+                PrepEntry e;
+                memset(&e, 0, sizeof(e));
+                e.src = c.params + l.w; e.dst = c.w.chain_wt[cw]; e.rows = l.out; e.cols = l.in; e.mode = 5; e.bf16 = 1;
+                e.KT = KT; e.n_off = k_off;
+                es.push_back(e);
+            };
+            packt(CW_BOX0, LIN_BOX0, 4, 0); packt(CW_BOX1, LIN_BOX1, 4, 0);
+            packt(CW_BOXH, LIN_BOXH1, 4, 0); packt(CW_BOXH, LIN_BOXH0, 4, c.L.NP);
+            packt(CW_ENC0, LIN_ENC0, 8, 0); packt(CW_ENC1, LIN_ENC1, 4, 0); packt(CW_ENC2, LIN_ENC2, 4, 0);
+            packt(CW_Z0, LIN_Z0, 4, 0); packt(CW_Z1, LIN_Z1, 4, 0);
+            packt(CW_ZH, LIN_ZH1, 4, 0); packt(CW_ZH, LIN_ZH0, 4, c.L.NP);
+            packt(CW_OBJ0, LIN_OBJ0, 4, 0); packt(CW_OBJ1, LIN_OBJ1, 4, 0);
+        }
     }
     push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
     push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
@@ -543,6 +563,8 @@ static int cells_fwd(Ctx& c) {
         a.bias[CW_Z0] = pr + PL.lin[LIN_Z0].b; a.bias[CW_Z1] = pr + PL.lin[LIN_Z1].b; a.bias[CW_ZH] = c.w.bias_zh;
         a.bias[CW_OBJ0] = pr + PL.lin[LIN_OBJ0].b; a.bias[CW_OBJ1] = pr + PL.lin[LIN_OBJ1].b; a.bias[CW_OBJ2] = pr + PL.lin[LIN_OBJ2].b;
         a.x = c.x; a.I = c.d.I; a.Pp = c.d.P; a.ac = c.d.align_corners;
+        a.w_obj2 = nullptr; a.gedge = nullptr;
+        for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = nullptr;
         return chain_fwd(a, c.s);
     }
     for (int t = 0; t < c.T; ++t) {
@@ -657,6 +679,16 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     }
     // per-cell chain, reverse wavefront order
     const int ps_cells = prof_begin(PS_CELLS_BWD, c.s);
+    if (c.use_chain) {
+        ChainArgs a;
+        memset(&a, 0, sizeof(a));
+        a.L = L; a.P = P; a.H = c.H;
+        for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = reinterpret_cast<const uint4*>(c.w.chain_wt[i]);
+        a.w_obj2 = params + PL.lin[LIN_OBJ2].w;
+        a.gedge = grads + PL.edge;
+        a.x = x; a.I = d->I; a.Pp = d->P; a.ac = d->align_corners;
+        TRY(chain_bwd(a, c.s));
+    } else {
     for (int t = c.T - 1; t >= 0; --t) {
         const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
         TRY(cells_bwd_pres(L, P, c.H, r0, R, c.s));
@@ -678,6 +710,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         TRY(bwd_lin(c, LIN_BOX0, SP_H, P.dHb1, SP_LDH, P.dXb, L.ld_xb, r0, R, nullptr, 0));
     }
     TRY(cells_dfeat_edge(L, P, grads + PL.edge, c.s));
+    }
     prof_end(ps_cells, c.s);
     const int ps_wg = prof_begin(PS_CELLS_WGRAD, c.s);
     // weight gradients of the per-cell nets: one long-K GEMM per layer over all N rows

@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256) void k_prep(PrepTable T) {
         }
         return;
     }
+    if (e.mode == 5) {   // data-gradient pack: B[k = n_off + o][n = i] = W[o][i]; padding relies on the zero-initialised workspace
+        const long long n5 = (long long)e.rows * e.cols;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n5; idx += (long long)gridDim.x * blockDim.x) {
+            const int o = (int)(idx / e.cols), i = (int)(idx - (long long)o * e.cols);
+            const int kk = e.n_off + o, nt = i >> 4, li = i & 15, kt = kk >> 5, g = (kk & 31) >> 3, j = kk & 7;
+            reinterpret_cast<__bf16*>(e.dst)[(((size_t)nt * e.KT + kt) * 64 + g * 16 + li) * 8 + j] = (__bf16)e.src[idx];
+        }
+        return;
+    }
     const long long n = (long long)e.rows * e.cols;   // pad columns are never written (workspace is zero-initialised)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / e.cols), c = (int)(idx - (long long)r * e.cols);
