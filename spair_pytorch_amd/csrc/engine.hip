@@ -350,11 +350,11 @@ static int nt(Ctx& c, const float* A, int lda, const void* B, int ldb, float* C,
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.relu = relu;
     return spair_gemm_nt_impl(g, false, c.d.dtype, c.s);
 }
-static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, int R) {
+static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, int N, float* C, int ldc, int R, float* colsum = nullptr) {
     GemmTN g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R;
+    g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
     return spair_gemm_tn_impl(g, false, c.d.dtype, c.s);
 }
 static const void* bptr(const void* base, size_t elem_off, int dtype) {
@@ -504,16 +504,15 @@ static int backbone_bwd(Ctx& c, float* grads) {
         const float* in = c.w.act[i - 1];
         // weight + bias gradients
         if (cs.k == 1) {
-            TRY(tn(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, grads + cs.w, cs.cin, M));
+            TRY(tn(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, grads + cs.w, cs.cin, M, grads + cs.b));
         } else {
             GemmTN g;
             memset(&g, 0, sizeof(g));
             const int K = cs.k * cs.k * cs.cin;
             g.A = dout; g.lda = ldd; g.B = in; g.C = grads + cs.w; g.ldc = K; g.M = round_up(cs.cout, 4); g.N = K; g.Mstore = cs.cout; g.Nstore = K;
-            g.R = M; g.cw_cin = cs.cin; g.cw_taps = cs.k * cs.k; g.conv = fwd_desc(cs);
+            g.R = M; g.cw_cin = cs.cin; g.cw_taps = cs.k * cs.k; g.conv = fwd_desc(cs); g.colsum_out = grads + cs.b;
             TRY(spair_gemm_tn_impl(g, true, c.d.dtype, c.s));
         }
-        TRY(spair_colsum_impl(dout, ldd, M, cs.cout, grads + cs.b, c.s));
         // data gradient into dact[i-1] (masked by relu of act[i-1])
         if (cs.k == 1) {
             const int Kd = round_up(cs.cout, 8);
@@ -537,9 +536,16 @@ static int backbone_bwd(Ctx& c, float* grads) {
                 }
         }
     }
-    const ConvSpec& c0 = c.PL.conv[0];
-    TRY(misc_conv0_wgrad(c.w.xpad, c.w.dact[0], grads + c0.w, d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, c.s));
-    TRY(spair_colsum_impl(c.w.dact[0], c0.cout, d.B * c0.hout * c0.hout, c0.cout, grads + c0.b, c.s));
+    {   // first layer (Cin = image channels): the same TN GEMM, B gathered element-wise from the padded input
+        const ConvSpec& c0 = c.PL.conv[0];
+        GemmTN g;
+        memset(&g, 0, sizeof(g));
+        const int K = c0.k * c0.k * c0.cin;
+        g.A = c.w.dact[0]; g.lda = c0.cout; g.B = c.w.xpad; g.C = grads + c0.w; g.ldc = K; g.M = round_up(c0.cout, 4); g.N = round_up(K, 4);
+        g.Mstore = c0.cout; g.Nstore = K; g.R = d.B * c0.hout * c0.hout; g.cw_cin = c0.cin; g.cw_taps = c0.k * c0.k; g.conv = fwd_desc(c0);
+        g.colsum_out = grads + c0.b;
+        TRY(spair_gemm_tn_impl(g, true, c.d.dtype, c.s));
+    }
     return SPAIR_OK;
 }
 
@@ -645,8 +651,7 @@ static int bwd_lin(Ctx& c, int id, int out_total, const float* dOut, int ldo, fl
 }
 static int wgrad_lin(Ctx& c, int id, const float* dOut, int ldo, const float* In, int ldi, float* grads, int R) {
     const LinSpec& l = c.PL.lin[id];
-    TRY(tn(c, dOut, ldo, l.out, In, ldi, l.in, grads + l.w, l.in, R));
-    return spair_colsum_impl(dOut, ldo, R, l.out, grads + l.b, c.s);
+    return tn(c, dOut, ldo, l.out, In, ldi, l.in, grads + l.w, l.in, R, grads + l.b);
 }
 
 extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,

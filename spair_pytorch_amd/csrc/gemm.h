@@ -20,6 +20,7 @@ struct GemmTN {
     int Mstore, Nstore;     // store extents (<= M, N)
     int cw_cin, cw_taps;    // if cw_cin > 0: n = tap*cin + ci is stored at column ci*taps + tap (OIHW conv weights)
     int rows_per_split;
+    float* colsum_out;      // optional: += column sums of A (bias gradient), fused into the same pass
     ConvDesc conv;
 };
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);

@@ -26,28 +26,49 @@ template <> struct MmaTraits<SPAIR_BF16> {
 };
 
 
-__device__ __forceinline__ void conv_row_decode(const ConvDesc& c, int m, int& b, int& ybase, int& xbase) {
-    const int hw = c.Hout * c.Wout;
-    b = m / hw;
-    const int rem = m - b * hw;
-    const int y = rem / c.Wout;
-    const int x = rem - y * c.Wout;
-    ybase = y * c.sy + c.oy;
-    xbase = x * c.sx + c.ox;
-}
+// Implicit-GEMM addressing without divisions in the K loop: a GEMM row is a position (b,y,x) of the logical output grid and a
+// GEMM column a tap (ky,kx,ci); both are decoded once and then ADVANCED incrementally as the tiles march on.
+struct ConvRow { int b, y, x; };
+struct ConvTap { int ky, kx, ci; };
 
-// Load 4 consecutive k-elements (same tap: Cin % 4 == 0) of implicit-GEMM row (b,ybase,xbase).
-__device__ __forceinline__ float4 conv_load4(const float* __restrict__ In, const ConvDesc& c, int b, int ybase,
-                                             int xbase, int k) {
+__device__ __forceinline__ void conv_row_init(const ConvDesc& c, int m, ConvRow& r) {
+    const int hw = c.Hout * c.Wout;
+    r.b = m / hw;
+    const int rem = m - r.b * hw;
+    r.y = rem / c.Wout;
+    r.x = rem - r.y * c.Wout;
+}
+__device__ __forceinline__ void conv_row_advance(const ConvDesc& c, ConvRow& r, int step) {
+    r.x += step;
+    while (r.x >= c.Wout) { r.x -= c.Wout; ++r.y; }
+    while (r.y >= c.Hout) { r.y -= c.Hout; ++r.b; }
+}
+__device__ __forceinline__ void conv_tap_init(const ConvDesc& c, int k, ConvTap& t) {
     const int tap = k / c.Cin;
-    const int ci = k - tap * c.Cin;
-    const int ky = tap / c.kw;
-    const int kx = tap - ky * c.kw;
-    const int sy = ybase + ky * c.dky;
-    const int sx = xbase + kx * c.dkx;
+    t.ci = k - tap * c.Cin;
+    t.ky = tap / c.kw;
+    t.kx = tap - t.ky * c.kw;
+}
+__device__ __forceinline__ void conv_tap_advance(const ConvDesc& c, ConvTap& t, int step) {
+    t.ci += step;
+    while (t.ci >= c.Cin) {
+        t.ci -= c.Cin;
+        if (++t.kx == c.kw) { t.kx = 0; ++t.ky; }
+    }
+}
+// 4 consecutive k-elements of one tap (Cin % 4 == 0), bounds-checked (zero outside the tensor)
+__device__ __forceinline__ float4 conv_load4(const float* __restrict__ In, const ConvDesc& c, const ConvRow& r, const ConvTap& t) {
+    const int sy = r.y * c.sy + c.oy + t.ky * c.dky;
+    const int sx = r.x * c.sx + c.ox + t.kx * c.dkx;
     if (sy < 0 || sy >= c.Hin || sx < 0 || sx >= c.Win) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t off = (((size_t)b * c.Hin + sy) * c.Win + sx) * c.Cin + ci;
+    const size_t off = (((size_t)r.b * c.Hin + sy) * c.Win + sx) * c.Cin + t.ci;
     return *reinterpret_cast<const float4*>(In + off);
+}
+// forward-geometry gather for the weight-gradient B operand (always inside the tensor); handles Cin % 4 != 0 by 4 scalar loads
+__device__ __forceinline__ float4 conv_gather4(const float* __restrict__ In, const ConvDesc& c, const ConvRow& r, const int (&tapoff)[4], bool vec) {
+    const size_t base = (((size_t)r.b * c.Hin + r.y * c.sy + c.oy) * c.Win + r.x * c.sx + c.ox) * c.Cin;
+    if (vec) return *reinterpret_cast<const float4*>(In + base + tapoff[0]);
+    return make_float4(In[base + tapoff[0]], In[base + tapoff[1]], In[base + tapoff[2]], In[base + tapoff[3]]);
 }
 
 template <int MMA, int BM, int BN, bool ACONV>
@@ -71,7 +92,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // per-thread staging coordinates
-    int a_row[NA], a_kq[NA], a_b[NA], a_y[NA], a_x[NA];
+    int a_row[NA], a_kq[NA];
+    ConvRow a_cr[NA];
+    ConvTap a_ct[NA];
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -80,8 +103,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         a_kq[i] = f - a_row[i] * KQ;
         const int gm = m0 + a_row[i];
         a_ok[i] = gm < g.M;
-        a_b[i] = a_y[i] = a_x[i] = 0;
-        if (ACONV && a_ok[i]) conv_row_decode(g.conv, gm, a_b[i], a_y[i], a_x[i]);
+        a_cr[i].b = a_cr[i].y = a_cr[i].x = 0;
+        a_ct[i].ky = a_ct[i].kx = a_ct[i].ci = 0;
+        if (ACONV && a_ok[i]) {
+            conv_row_init(g.conv, gm, a_cr[i]);
+            conv_tap_init(g.conv, a_kq[i] * 4, a_ct[i]);
+        }
     }
     int b_row[NB], b_q[NB];
     bool b_ok[NB];
@@ -100,11 +127,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         for (int i = 0; i < NA; ++i) {
             const int k = k0 + a_kq[i] * 4;
             if (a_ok[i] && k < g.K) {
-                if (ACONV) ra[i] = conv_load4(g.A, g.conv, a_b[i], a_y[i], a_x[i], k);
+                if (ACONV) ra[i] = conv_load4(g.A, g.conv, a_cr[i], a_ct[i]);
                 else ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + a_row[i]) * g.lda + k);
             } else {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (ACONV) conv_tap_advance(g.conv, a_ct[i], BK);   // load_tiles is called once per consecutive K tile
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -259,6 +287,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[NA], rb[NB];
+    // weight-gradient B operand as a conv gather: the column (tap) of each of this thread's chunks is fixed for the whole kernel,
+    // its row (b,y,x) advances by BK per tile -- no division in the loop
+    ConvRow b_cr[NB];
+    int b_tapoff[NB][4];
+    bool b_vec = true;
+    if (BCONV) {
+        b_vec = (g.conv.Cin & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            conv_row_init(g.conv, min(r_begin + kr, g.R - 1), b_cr[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ConvTap t;
+                conv_tap_init(g.conv, min(n0 + nq * 4 + e, g.N - 1), t);
+                b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
+            }
+        }
+    }
+    float csum[NA][4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) csum[i][0] = csum[i][1] = csum[i][2] = csum[i][3] = 0.f;
+    const bool do_colsum = g.colsum_out != nullptr && blockIdx.y == 0;
     auto load_tiles = [&](int r0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -266,6 +317,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
             const int r = r0 + kr, m = m0 + mq * 4;
             ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)r * g.lda + m)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_colsum) { csum[i][0] += ra[i].x; csum[i][1] += ra[i].y; csum[i][2] += ra[i].z; csum[i][3] += ra[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -273,15 +325,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
             const int r = r0 + kr, n = n0 + nq * 4;
             if (r < r_end && n < g.N) {
                 if (BCONV) {
-                    int b, yb, xb;
-                    conv_row_decode(g.conv, r, b, yb, xb);
-                    rb[i] = conv_load4(g.B, g.conv, b, yb, xb, n);
+                    rb[i] = conv_gather4(g.B, g.conv, b_cr[i], b_tapoff[i], b_vec);
                 } else {
                     rb[i] = *reinterpret_cast<const float4*>(g.B + (size_t)r * g.ldb + n);
                 }
             } else {
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (BCONV) conv_row_advance(g.conv, b_cr[i], BK);
         }
     };
     auto store_tiles = [&]() {
@@ -323,6 +374,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
                 store_tiles();
                 __syncthreads();
             }
+        }
+    }
+    if (do_colsum) {   // bias gradient: column sums of the A operand, reduced over this block's rows in LDS, one atomic per column
+        constexpr int GR = 256 / (BM / 4);
+        __syncthreads();
+        float* scr = reinterpret_cast<float*>(As);
+        const int mq = tid % (BM / 4), grp = tid / (BM / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) t += csum[i][e];
+            scr[grp * BM + mq * 4 + e] = t;
+        }
+        __syncthreads();
+        for (int m = tid; m < BM; m += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GR; ++q) t += scr[q * BM + m];
+            if (m0 + m < g.Mstore) atomicAdd(&g.colsum_out[m0 + m], t);
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
@@ -380,6 +451,29 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[NA], rb[NB];
+    // weight-gradient B operand as a conv gather: the column (tap) of each of this thread's chunks is fixed for the whole kernel,
+    // its row (b,y,x) advances by BK per tile -- no division in the loop
+    ConvRow b_cr[NB];
+    int b_tapoff[NB][4];
+    bool b_vec = true;
+    if (BCONV) {
+        b_vec = (g.conv.Cin & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256, kr = f / (BN / 4), nq = f - kr * (BN / 4);
+            conv_row_init(g.conv, min(r_begin + kr, g.R - 1), b_cr[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ConvTap t;
+                conv_tap_init(g.conv, min(n0 + nq * 4 + e, g.N - 1), t);
+                b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
+            }
+        }
+    }
+    float csum[NA][4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) csum[i][0] = csum[i][1] = csum[i][2] = csum[i][3] = 0.f;
+    const bool do_colsum = g.colsum_out != nullptr && blockIdx.y == 0;
     auto load_tiles = [&](int r0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -387,6 +481,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
             const int r = r0 + kr, m = m0 + mq * 4;
             ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)r * g.lda + m)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_colsum) { csum[i][0] += ra[i].x; csum[i][1] += ra[i].y; csum[i][2] += ra[i].z; csum[i][3] += ra[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -394,15 +489,14 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
             const int r = r0 + kr, n = n0 + nq * 4;
             if (r < r_end && n < g.N) {
                 if (BCONV) {
-                    int b, yb, xb;
-                    conv_row_decode(g.conv, r, b, yb, xb);
-                    rb[i] = conv_load4(g.B, g.conv, b, yb, xb, n);
+                    rb[i] = conv_gather4(g.B, g.conv, b_cr[i], b_tapoff[i], b_vec);
                 } else {
                     rb[i] = *reinterpret_cast<const float4*>(g.B + (size_t)r * g.ldb + n);
                 }
             } else {
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (BCONV) conv_row_advance(g.conv, b_cr[i], BK);
         }
     };
     auto store_tiles = [&]() {
@@ -446,6 +540,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
             }
         }
     }
+    if (do_colsum) {   // bias gradient: column sums of the A operand, reduced over this block's rows in LDS, one atomic per column
+        constexpr int GR = 256 / (BM / 4);
+        __syncthreads();
+        float* scr = reinterpret_cast<float*>(As);
+        const int mq = tid % (BM / 4), grp = tid / (BM / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) t += csum[i][e];
+            scr[grp * BM + mq * 4 + e] = t;
+        }
+        __syncthreads();
+        for (int m = tid; m < BM; m += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GR; ++q) t += scr[q * BM + m];
+            if (m0 + m < g.Mstore) atomicAdd(&g.colsum_out[m0 + m], t);
+        }
+    }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -483,7 +597,6 @@ int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s) {
     if (g.Mstore <= 0) g.Mstore = g.M;
     if (g.Nstore <= 0) g.Nstore = g.N;
     if ((g.M & 3) || (g.N & 3) || (g.lda & 3) || (!conv && (g.ldb & 3))) return SPAIR_ERR_ALIGN;
-    if (conv && (g.conv.Cin & 3)) return SPAIR_ERR_ALIGN;
     if (dtype == SPAIR_BF16) {
         if (g.M > 64 && g.N > 64) return launch_tn_bf16<128, 128>(g, conv, s);
         return launch_tn_bf16<64, 64>(g, conv, s);
