@@ -625,8 +625,16 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         ProfScope ps(PS_DECODER_FWD, c.s);
         TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
         TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
-        { ProfScope p2(PS_DEC2_FWD, c.s); TRY(fwd_lin(c, LIN_DEC2, c.w.Hd2, SP_DEC_H2, c.w.S, c.w.ld_s, 0, N, params + PL.lin[LIN_DEC2].b, per, 0)); }
-        TRY(render_sprite_act(c.w.S, c.w.ld_s, N, per, d->C + 1, d->obj_logit_scale, d->alpha_logit_scale, d->alpha_logit_bias, c.s));
+        {   // decoder.out with the sprite sigmoid epilogue fused (models.py:485-492)
+            ProfScope p2(PS_DEC2_FWD, c.s);
+            GemmNT g;
+            memset(&g, 0, sizeof(g));
+            const int K = round_up(PL.lin[LIN_DEC2].in, 8);
+            g.A = c.w.Hd2; g.lda = SP_DEC_H2; g.B = c.w.lin_wf[LIN_DEC2]; g.ldb = K; g.C = c.w.S; g.ldc = c.w.ld_s; g.M = N; g.N = per; g.K = K;
+            g.bias = params + PL.lin[LIN_DEC2].b; g.sprite_ch = d->C + 1;
+            g.obj_scale = d->obj_logit_scale; g.alpha_scale = d->alpha_logit_scale; g.alpha_bias = d->alpha_logit_bias;
+            TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
+        }
     }
     // KL + render + loss
     { ProfScope ps(PS_COUNT_KL, c.s); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, c.s)); }

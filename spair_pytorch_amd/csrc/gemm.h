@@ -9,6 +9,8 @@ struct GemmNT {
     const float* bias;
     const float* mask; int ldmask;
     int relu, accumulate;
+    int sprite_ch;                        // >0: decoder epilogue (models.py:485-492): analytic sigmoid of scaled logits, alpha = last of sprite_ch
+    float obj_scale, alpha_scale, alpha_bias;
     ConvDesc conv;
     RowMap cmap; int use_cmap;
 };

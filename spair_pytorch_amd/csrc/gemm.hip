@@ -236,6 +236,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
                 if (g.accumulate) v += cptr[n];
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (g.mask) v = (g.mask[crow * g.ldmask + n] > 0.f) ? v : 0.f;
+                if (g.sprite_ch > 0) {
+                    const float t = ((n % g.sprite_ch) == g.sprite_ch - 1) ? v * g.alpha_scale + g.alpha_bias : v * g.obj_scale;
+                    v = 1.f / (expf(-t) + 1.f);
+                }
                 cptr[n] = v;
             }
         }

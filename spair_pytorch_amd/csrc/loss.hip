@@ -9,11 +9,17 @@
 
 __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
     __shared__ float cd_sh[4][KL_MAXBINS + 7];
+    __shared__ float z_sh[4][KL_MAXBINS - 1];
+    __shared__ float pz_sh[4][KL_MAXBINS - 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= L.B) return;
     float* cd = cd_sh[wave];
+    float* zs = z_sh[wave];
+    float* pzs = pz_sh[wave];
     const int HW = L.HW, NB = HW + 1;
+    // all of this sample's z_pres in row-major cell order: no global access inside the sequential loop
+    for (int i = lane; i < HW; i += 64) zs[i] = P.rec[((size_t)P.cidx[i] * L.B + b) * L.ld_rec + L.REC - 1];
     // geometric count distribution (1-p) p^k, normalised (models.py:190-193)
     float part = 0.f;
     for (int e = lane; e < NB; e += 64) {
@@ -23,35 +29,34 @@ __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, floa
     }
     const float norm0 = wave_reduce_sum(part);
     for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / norm0;
-    float count = 0.f, klsum = 0.f;
+    float count = 0.f;
     for (int i = 0; i < HW; ++i) {
-        const int cp = P.cidx[i];   // row-major cell i = h*G + w  ->  wavefront index
-        const size_t r = (size_t)cp * L.B + b;
-        const float z = P.rec[r * L.ld_rec + L.REC - 1];
+        const float z = zs[i];
         const float rem = (float)(HW - i);
-        float pz = 0.f;
-        for (int e = lane; e < NB; e += 64) {
-            const float q = fminf(fmaxf((float)e - count, 0.f), rem) / rem;
-            pz += cd[e] * q;
-        }
-        pz = wave_reduce_sum(pz);
         const float s = rintf(z);   // torch.round: half to even
-        float np = 0.f;
+        float pz = 0.f, np = 0.f;
         for (int e = lane; e < NB; e += 64) {
             const float q = fminf(fmaxf((float)e - count, 0.f), rem) / rem;
-            const float v = (s * q + (1.f - s) * (1.f - q)) * cd[e];
+            const float c = cd[e];
+            pz += c * q;
+            const float v = (s * q + (1.f - s) * (1.f - q)) * c;
             cd[e] = v;
             np += v;
         }
+        pz = wave_reduce_sum(pz);
         np = fmaxf(wave_reduce_sum(np), 1e-6f);
         for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / np;
-        if (lane == 0) {
-            P.stat[r * SP_LDSTAT + ST_PZ] = pz;
-            const float e9 = 1e-9f;
-            klsum += z * (logf(z + e9) - logf(pz + e9)) + (1.f - z) * (logf(1.f - z + e9) - logf(1.f - pz + e9));
-        }
+        if (lane == 0) pzs[i] = pz;
         count += s;
     }
+    // Bernoulli KL per cell (models.py:223-226) and the p_z map the backward pass needs
+    float klsum = 0.f;
+    for (int i = lane; i < HW; i += 64) {
+        const float z = zs[i], pz = pzs[i], e9 = 1e-9f;
+        P.stat[((size_t)P.cidx[i] * L.B + b) * SP_LDSTAT + ST_PZ] = pz;
+        klsum += z * (logf(z + e9) - logf(pz + e9)) + (1.f - z) * (logf(1.f - z + e9) - logf(1.f - pz + e9));
+    }
+    klsum = wave_reduce_sum(klsum);
     if (lane == 0) klp[b] = klsum;
 }
 
