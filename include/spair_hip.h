@@ -43,7 +43,7 @@ typedef struct SpairStep {
     float count_prior_prob;    /* 1/(1+exp(-log(v+1e-6))), models.py:186-188 */
     float kl_scale;            /* 1/(B*world_size): batch-mean of the KL terms (models.py:553) */
     int train;                 /* 1: keep what backward needs */
-    int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing) */
+    int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps */
 } SpairStep;
 
 /* ---- parameter / workspace layout -------------------------------------------------------- */
@@ -71,6 +71,8 @@ int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg
 /* Copy a per-row quantity of the last forward into an NCHW map [B,ch,G,G].
  * which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 their sigma, 14 count-prior p_z */
 int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream);
+/* diagnostic: stage time stamps of the fused forward chain kernel (SpairStep.flags bit 1), n <= 4096 uint64 */
+int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long long* out, int n, void* stream);
 int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
 
 /* Opt-in instrumentation for bench.py: HIP events on the caller's stream around regions of the step.

@@ -25,87 +25,95 @@ constexpr int KG = 800, LD_GL = KG + 8;   // glimpse padded to 25 k-steps
 constexpr int LD_H = 256 + 8;
 constexpr int LD_O = 112;
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains every outstanding global access (s_waitcnt vmcnt(0)):
+// here that would stall each of the ~20 stages per wavefront on the acks of its activation stores and would force the weight
+// fragments prefetched for the next layer to land before the barrier.  Nothing written to HBM by these kernels is read back by
+// them, so LDS ordering is all the stages need (cdna_hip_programming.md §5 "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
     union { uint4 u; bf16x8 b; } c;
     c.u = v;
     return c.b;
 }
 
-// Weight-fragment pipeline: PD k-steps (x up to 4 column tiles) of 16-byte-per-lane loads in flight per wave.  The ring lives in
-// registers across layer boundaries and barriers: pipe_fill() for layer l+1 is issued right after the MFMAs of layer l, so the L2
-// latency of a layer's first fragments hides under the previous layer's epilogue and the workgroup barrier.
+// Weight-fragment pipeline.  Every wave owns ONE 16-column tile per (half-)layer; its share of the layer is the linear sequence
+// of that tile's KT 1-KiB fragments, RD of which are kept in flight in a register ring.  The code between a fragment's load and
+// its MFMA is STRAIGHT-LINE: waves without a tile (NT not a multiple of 8) run on a clamped tile index and only skip the store --
+// a wave-uniform `if (nt < NT)` around the loads/MFMAs splits basic blocks and makes hipcc wait vmcnt(0) before every MFMA,
+// which serialises the whole stream (measured: ~4.5k cycles per stage regardless of its size).  The ring lives across layer
+// boundaries and barriers: pipe_fill() for layer l+1 is issued right after the MFMAs of layer l.
 constexpr int NW = 8;                     // waves per workgroup
 constexpr int NTH = NW * 64;
-constexpr int PD = 4;
-struct WPipe { uint4 q[PD][2]; };
+constexpr int RD = 12;
+struct WPipe { uint4 q[RD]; };
 
-template <int KT, int NT>
-__device__ __forceinline__ void pipe_fill(const uint4* __restrict__ Wp, WPipe& p, int wave, int lane) {
-    constexpr int MY = (NT + NW - 1) / NW;
-#pragma unroll
-    for (int d = 0; d < PD; ++d) {
-        if (d >= KT) break;
-#pragma unroll
-        for (int j = 0; j < MY; ++j) {
-            const int nt = wave + NW * j;
-            if (nt < NT) p.q[d][j] = Wp[(size_t)(nt * KT + d) * 64 + lane];
-        }
-    }
+template <int KT, int NT, int NT0>
+__device__ __forceinline__ const uint4* tile_base(const uint4* __restrict__ Wp, int wave, int lane) {
+    const int nt = min(NT0 + wave, NT - 1);
+    return Wp + (size_t)nt * KT * 64 + lane;
 }
 
-// acc[j] (j-th column tile of this wave: nt = wave + 4j) = in[16, K] . Wp^T ; K = 32*(KT0+KT1), the first KT0 k-steps read inA,
-// the rest inB.  Wp is fragment-packed: fragment (nt, kt) = 64 lanes x 16 B at Wp[(nt*KT + kt)*64 + lane].  Expects pipe_fill<KT,NT>.
-template <int KT0, int KT1, int NT>
+template <int KT, int NT, int NT0 = 0>
+__device__ __forceinline__ void pipe_fill(const uint4* __restrict__ Wp, WPipe& p, int wave, int lane) {
+    const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
+#pragma unroll
+    for (int f = 0; f < RD; ++f)
+        if (f < KT) p.q[f] = base[f * 64];
+}
+
+// acc = in[16, K] . W_tile^T for this wave's tile NT0 + wave; K = 32*(KT0+KT1): the first KT0 k-steps read inA, the rest inB.
+template <int KT0, int KT1, int NT, int NT0 = 0>
 __device__ __forceinline__ void wg_gemm(const __bf16* inA, int ldA, const __bf16* inB, int ldB, const uint4* __restrict__ Wp, WPipe& p,
-                                        f32x4 (&acc)[(NT + NW - 1) / NW], int wave, int lane) {
-    constexpr int KT = KT0 + KT1, MY = (NT + NW - 1) / NW;
-#pragma unroll
-    for (int j = 0; j < MY; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int arow = lane & 15, kg = (lane >> 4) * 8;
+                                        f32x4& acc, int wave, int lane) {
+    constexpr int KT = KT0 + KT1;
+    constexpr int NMAIN = (KT >= 2 * RD) ? (KT / RD - 1) : 0;    // groups whose RD refills all exist
+    const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
+    const __bf16* pa = inA + (lane & 15) * ldA + (lane >> 4) * 8;
+    const __bf16* pb = (KT1 > 0) ? inB + (lane & 15) * ldB + (lane >> 4) * 8 : pa;
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto afrag = [&](int kt) -> bf16x8 {
+        if constexpr (KT1 == 0) return *reinterpret_cast<const bf16x8*>(pa + kt * 32);
+        else return *reinterpret_cast<const bf16x8*>((kt < KT0) ? pa + kt * 32 : pb + (kt - KT0) * 32);
+    };
 #pragma unroll 1
-    for (int kt0 = 0; kt0 < KT; kt0 += PD) {
+    for (int g = 0; g < NMAIN; ++g) {
 #pragma unroll
-        for (int d = 0; d < PD; ++d) {
-            const int kt = kt0 + d;
-            if (kt < KT) {
-                const __bf16* src = (kt < KT0) ? inA + arow * ldA + kt * 32 + kg : inB + arow * ldB + (kt - KT0) * 32 + kg;
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(src);
-#pragma unroll
-                for (int j = 0; j < MY; ++j) {
-                    const int nt = wave + NW * j;
-                    if (nt < NT) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, as_frag(p.q[d][j]), acc[j], 0, 0, 0);
-                        if (kt + PD < KT) p.q[d][j] = Wp[(size_t)(nt * KT + kt + PD) * 64 + lane];
-                    }
-                }
-            }
+        for (int d = 0; d < RD; ++d) {
+            const int f = g * RD + d;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f), as_frag(p.q[d]), acc, 0, 0, 0);
+            p.q[d] = base[(size_t)(f + RD) * 64];
         }
+    }
+#pragma unroll
+    for (int f = NMAIN * RD; f < KT; ++f) {          // compile-time tail: every condition folds
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f), as_frag(p.q[f % RD]), acc, 0, 0, 0);
+        if (f + RD < KT) p.q[f % RD] = base[(size_t)(f + RD) * 64];
     }
 }
 
 // epilogue: v = acc + bias (+relu); optional bf16 copy to LDS (next layer's input), fp32 copy to LDS (head outputs) and to the
 // HBM row buffer (what backward / weight-gradient GEMMs read).  Lane holds col = nt*16 + (lane&15), rows (lane>>4)*4 + r.
-template <int NT, bool RELU>
-__device__ __forceinline__ void wg_store(const f32x4 (&acc)[(NT + NW - 1) / NW], const float* __restrict__ bias, int nout, __bf16* lds_bf, int ld_bf,
+template <int NT, bool RELU, int NT0 = 0>
+__device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restrict__ bias, int nout, __bf16* lds_bf, int ld_bf,
                                          float* lds_f, int ld_f, float* __restrict__ hbm, int ld_hbm, const int* row_r, int nc, int wave,
                                          int lane) {
-    constexpr int MY = (NT + NW - 1) / NW;
+    const int nt = NT0 + wave;
+    const int n = nt * 16 + (lane & 15);
+    if (nt >= NT || n >= nout) return;
+    const float bv = bias[n];
 #pragma unroll
-    for (int j = 0; j < MY; ++j) {
-        const int nt = wave + NW * j;
-        if (nt >= NT) continue;
-        const int n = nt * 16 + (lane & 15);
-        if (n >= nout) continue;
-        const float bv = bias[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = (lane >> 4) * 4 + r;
-            float v = acc[j][r] + bv;
-            if (RELU) v = fmaxf(v, 0.f);
-            if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
-            if (lds_f) lds_f[row * ld_f + n] = v;
-            if (row < nc) hbm[(size_t)row_r[row] * ld_hbm + n] = v;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r;
+        float v = acc[r] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
+        if (lds_f) lds_f[row * ld_f + n] = v;
+        if (row < nc) hbm[(size_t)row_r[row] * ld_hbm + n] = v;
     }
 }
 
@@ -128,8 +136,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
     const CellHyper& H = a.H;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    int tid = tid0, lane = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
 
@@ -144,7 +153,15 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
 
     WPipe pipe;
     pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
+    int stamp_i = 0;
+#define CH_STAMP() do { if (a.stamps && b == 0 && tid == 0) a.stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int t = 0; t < T; ++t) {
+        // opaque per-iteration copies: keeps LICM from hoisting every layer's lane-dependent address arithmetic out of the
+        // wavefront loop (that cost >100 VGPRs held across the whole loop and forced the weight ring to be shallow)
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        CH_STAMP();
         const int c0 = dstart_sh[t];
         const int nc = dstart_sh[t + 1] - c0;
         float (*rec_cur)[REC] = recs[t & 3];
@@ -155,7 +172,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             row_h[tid] = P.cell_h[cp];
             row_w[tid] = P.cell_w[cp];
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread
         for (int idx = tid; idx < MT * (KC / 4); idx += NTH) {
             const int row = idx / (KC / 4), c4 = (idx - row * (KC / 4)) * 4;
@@ -182,29 +200,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
             *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = o;
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- z_where: box MLP (models.py:76-77)
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, acc, wave, lane);
             pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
             wg_store<7, false>(acc, a.bias[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- box latents (models.py:322-381); passthrough -> z-net input
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
@@ -235,7 +257,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 P.z_where[(((size_t)b * 4 + k) * G + h) * G + w] = o.nbox[k];
             }
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- z_what: glimpse (modules.py:216-273, border padding) + encoder MLP (models.py:383-391)
         for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
@@ -264,28 +287,35 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
             *reinterpret_cast<float4*>(P.glimpse + (size_t)row_r[row] * L.ld_gl + e) = make_float4(out[0], out[1], out[2], out[3]);
         }
-        __syncthreads();
-        {
-            f32x4 acc[2];
-            wg_gemm<25, 0, 16>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc, wave, lane);
+        lds_barrier();
+        CH_STAMP();
+        {   // 256 outputs = 16 tiles: two half-layers of 8 tiles, one tile per wave each
+            f32x4 acc0, acc1;
+            wg_gemm<25, 0, 16, 0>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc0, wave, lane);
+            pipe_fill<25, 16, 8>(a.w[CW_ENC0], pipe, wave, lane);
+            wg_gemm<25, 0, 16, 8>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store<16, true>(acc, a.bias[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
+            wg_store<16, true, 0>(acc0, a.bias[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
+            wg_store<16, true, 8>(acc1, a.bias[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
             wg_store<8, true>(acc, a.bias[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
             wg_store<7, false>(acc, a.bias[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- attributes (models.py:83-85)
         for (int idx = tid; idx < nc * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
@@ -302,29 +332,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.Xz[r * L.ld_x + L.x_attr + j] = attr;
             P.Xo[r * L.ld_x + L.x_attr + j] = attr;
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- z_depth (models.py:88-97)
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
             wg_store<7, false>(acc, a.bias[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = Ost[row * LD_O + i];
@@ -345,29 +379,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.rec[r * L.ld_rec + 4 + A_] = depth;
             P.Xo[r * L.ld_x + L.x_depth] = depth;
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         // ---- z_pres (models.py:100-102,393-411)
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, acc, wave, lane);
             pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
             wg_store<7, true>(acc, a.bias[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         {
-            f32x4 acc[1];
+            f32x4 acc;
             wg_gemm<4, 0, 1>(Hb, LD_H, nullptr, 0, a.w[CW_OBJ2], pipe, acc, wave, lane);
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
             wg_store<1, false>(acc, a.bias[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
             const size_t r = row_r[tid];
@@ -377,7 +415,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.rec[r * L.ld_rec + REC - 1] = pres;
             P.z_pres[((size_t)b * G + h) * G + w] = pres;
         }
-        __syncthreads();
+        lds_barrier();
+        CH_STAMP();
     }
 }
 
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 gnb[tid][k] = 0.f;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
         for (int idx = tid; idx < nc * REC; idx += NTH) {
             const int row = idx / REC, j = idx - row * REC;
@@ -501,7 +540,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
             grec[row][j] = g;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit)
         {
             const int row = tid >> 5, l = tid & 31;
@@ -524,7 +563,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 P.dOo[r * L.ld_oo] = d;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu
         for (int idx = tid; idx < MT * SP_H; idx += NTH) {
             const int row = idx / SP_H, n = idx - row * SP_H;
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
             Aa[row * LD_H + n] = (__bf16)v;
         }
-        __syncthreads();
+        lds_barrier();
         auto hidden_epi = [&](const float* __restrict__ Hm, int ldh, float* __restrict__ dOut, int nout, __bf16* dst) {
             return [=](int nt, const f32x4& acc) {
                 const int n = nt * 16 + (lane & 15);
@@ -555,7 +594,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             };
         };
         wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_OBJ1], wave, lane, hidden_epi(P.Ho1, SP_LDH, P.dHo1, SP_H, Ab));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX + KX) return;
@@ -566,7 +605,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 else tailO[row][n - (F + CTX)] = acc[rr];
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
@@ -588,11 +627,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             Aa[tid * LD_H + NP] = (__bf16)d_mu;
             Aa[tid * LD_H + NP + 1] = (__bf16)d_ls;
         }
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_ZH], wave, lane, hidden_epi(P.Hz2, SP_LDH, P.dHz2, SP_H, Ab));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_Z1], wave, lane, hidden_epi(P.Hz1, SP_LDH, P.dHz1, SP_H, Aa));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX + KX) return;
@@ -603,7 +642,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 else tailZ[row][n - (F + CTX)] = acc[rr];
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- attributes -> gradient of the encoder output
         for (int idx = tid; idx < MT * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
@@ -619,11 +658,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             Ab[row * LD_H + j] = (__bf16)d_mean;
             Ab[row * LD_H + A_ + j] = (__bf16)d_ls;
         }
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 8>(Ab, LD_H, a.wt[CW_ENC2], wave, lane, hidden_epi(P.He2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 16>(Aa, LD_H, a.wt[CW_ENC1], wave, lane, hidden_epi(P.He1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab));
-        __syncthreads();
+        lds_barrier();
         // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273); the glimpse gradient is never stored
         wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int nt, const f32x4& acc) {
             const int e = nt * 16 + (lane & 15);
@@ -662,7 +701,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 }
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- box (models.py:322-381 backward); passthrough gradient -> box-net head
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
@@ -689,18 +728,18 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) Aa[tid * LD_H + NP + k] = (__bf16)dlat[k];
         }
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_BOXH], wave, lane, hidden_epi(P.Hb2, SP_LDH, P.dHb2, SP_H, Ab));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_BOX1], wave, lane, hidden_epi(P.Hb1, SP_LDH, P.dHb1, SP_H, Aa));
-        __syncthreads();
+        lds_barrier();
         wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX) return;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) slot[(lane >> 4) * 4 + rr][n] += acc[rr];
         });
-        __syncthreads();
+        lds_barrier();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
         for (int idx = tid; idx < nc * (F + CTX); idx += NTH) {
             const int row = idx / (F + CTX), n = idx - row * (F + CTX);
@@ -712,7 +751,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 if (nbr_row[row][s] < 0) atomicAdd(&edge_acc[(n - F) - s * REC], v);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (tid < REC) atomicAdd(&a.gedge[tid], edge_acc[tid]);
 }

@@ -123,6 +123,7 @@ struct Ws {
     CellBufs cb;
     float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;
     float *aux, *bce_partial, *kl_partial, *klp;
+    unsigned long long* stamps;
     int ld_feat, ld_s;
     size_t total;
 };
@@ -218,6 +219,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
+    w.stamps = c.take<unsigned long long>(4096);
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -569,7 +571,7 @@ static int cells_fwd(Ctx& c) {
         a.bias[CW_Z0] = pr + PL.lin[LIN_Z0].b; a.bias[CW_Z1] = pr + PL.lin[LIN_Z1].b; a.bias[CW_ZH] = c.w.bias_zh;
         a.bias[CW_OBJ0] = pr + PL.lin[LIN_OBJ0].b; a.bias[CW_OBJ1] = pr + PL.lin[LIN_OBJ1].b; a.bias[CW_OBJ2] = pr + PL.lin[LIN_OBJ2].b;
         a.x = c.x; a.I = c.d.I; a.Pp = c.d.P; a.ac = c.d.align_corners;
-        a.w_obj2 = nullptr; a.gedge = nullptr;
+        a.w_obj2 = nullptr; a.gedge = nullptr; a.stamps = (c.st.flags & 2) ? c.w.stamps : nullptr;
         for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = nullptr;
         return chain_fwd(a, c.s);
     }
@@ -743,6 +745,15 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
     prof_end(ps_wg, c.s);
     { ProfScope ps(PS_BACKBONE_BWD, c.s); TRY(backbone_bwd(c, grads)); }
+    return SPAIR_OK;
+}
+
+// diagnostic: copy the forward chain kernel's stage stamps (SpairStep.flags bit 1) into a caller buffer of n uint64
+extern "C" int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long long* out, int n, void* stream) {
+    if (!d || !workspace || !out || n > 4096) return SPAIR_ERR_SHAPE;
+    TRY(validate(*d));
+    const Ws w = carve(*d, const_cast<void*>(workspace));
+    if (hipMemcpyAsync(out, w.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return SPAIR_ERR_LAUNCH;
     return SPAIR_OK;
 }
 

@@ -21,7 +21,7 @@ struct GemmTN {
     int M, N, R;            // M, N: load extents (multiples of 4, may run into zero pad columns)
     int Mstore, Nstore;     // store extents (<= M, N)
     int cw_cin, cw_taps;    // if cw_cin > 0: n = tap*cin + ci is stored at column ci*taps + tap (OIHW conv weights)
-    int rows_per_split;
+    int rows_per_split, nsplit, tiles_m, tiles_n;   // filled by the launcher
     float* colsum_out;      // optional: += column sums of A (bias gradient), fused into the same pass
     ConvDesc conv;
 };

@@ -280,8 +280,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int r_begin = blockIdx.z * g.rows_per_split;
+    // XCD-aware tile order (1-D grid): all (m,n) tiles of one row split run back to back on ONE XCD (blocks id, id+8, ... share an
+    // XCD under round-robin dispatch), so the split's rows of A and B -- for a conv weight-gradient the same input pixels seen
+    // through all kh*kw taps -- are fetched from HBM once and then hit that XCD's L2.  Speed only; any mapping is correct.
+    int mt_, nt_, sp_;
+    {
+        const int id = blockIdx.x, ntm = g.tiles_m, ntn = g.tiles_n;
+        if ((g.nsplit & 7) == 0) {
+            const int xcd = id & 7, j = id >> 3;
+            mt_ = j % ntm; nt_ = (j / ntm) % ntn; sp_ = (j / (ntm * ntn)) * 8 + xcd;
+        } else {
+            mt_ = id % ntm; nt_ = (id / ntm) % ntn; sp_ = id / (ntm * ntn);
+        }
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int r_begin = sp_ * g.rows_per_split;
     const int r_end = min(g.R, r_begin + g.rows_per_split);
 
     f32x4 acc[TM][TN];
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     float csum[NA][4];
 #pragma unroll
     for (int i = 0; i < NA; ++i) csum[i][0] = csum[i][1] = csum[i][2] = csum[i][3] = 0.f;
-    const bool do_colsum = g.colsum_out != nullptr && blockIdx.y == 0;
+    const bool do_colsum = g.colsum_out != nullptr && nt_ == 0;
     auto load_tiles = [&](int r0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -444,8 +457,21 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
     __shared__ __attribute__((aligned(16))) __bf16 Bs[BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int r_begin = blockIdx.z * g.rows_per_split;
+    // XCD-aware tile order (1-D grid): all (m,n) tiles of one row split run back to back on ONE XCD (blocks id, id+8, ... share an
+    // XCD under round-robin dispatch), so the split's rows of A and B -- for a conv weight-gradient the same input pixels seen
+    // through all kh*kw taps -- are fetched from HBM once and then hit that XCD's L2.  Speed only; any mapping is correct.
+    int mt_, nt_, sp_;
+    {
+        const int id = blockIdx.x, ntm = g.tiles_m, ntn = g.tiles_n;
+        if ((g.nsplit & 7) == 0) {
+            const int xcd = id & 7, j = id >> 3;
+            mt_ = j % ntm; nt_ = (j / ntm) % ntn; sp_ = (j / (ntm * ntn)) * 8 + xcd;
+        } else {
+            mt_ = id % ntm; nt_ = (id / ntm) % ntn; sp_ = id / (ntm * ntn);
+        }
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int r_begin = sp_ * g.rows_per_split;
     const int r_end = min(g.R, r_begin + g.rows_per_split);
 
     f32x4 acc[TM][TN];
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
     float csum[NA][4];
 #pragma unroll
     for (int i = 0; i < NA; ++i) csum[i][0] = csum[i][1] = csum[i][2] = csum[i][3] = 0.f;
-    const bool do_colsum = g.colsum_out != nullptr && blockIdx.y == 0;
+    const bool do_colsum = g.colsum_out != nullptr && nt_ == 0;
     auto load_tiles = [&](int r0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -586,10 +612,11 @@ template <int BM, int BN>
 static int launch_tn_bf16(GemmTN g, bool conv, hipStream_t s) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     int nsplit = max(1, min(ceil_div(g.R, 512), ceil_div(1024, tiles)));
+    if (nsplit >= 8) nsplit = nsplit / 8 * 8;
     int rps = round_up(ceil_div(g.R, nsplit), 32);
-    nsplit = ceil_div(g.R, rps);
-    g.rows_per_split = rps;
-    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), nsplit);
+    if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
+    g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
+    dim3 grid(g.tiles_m * g.tiles_n * nsplit);
     if (conv) hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
     SPAIR_CHECK_LAUNCH();
@@ -610,10 +637,11 @@ int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     // aim for ~4 waves of blocks over 256 CUs, at least 256 rows per split
     int nsplit = max(1, min(ceil_div(g.R, 256), ceil_div(2048, tiles)));
+    if (nsplit >= 8) nsplit = nsplit / 8 * 8;
     int rps = round_up(ceil_div(g.R, nsplit), 16);
-    nsplit = ceil_div(g.R, rps);
-    g.rows_per_split = rps;
-    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), nsplit);
+    if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
+    g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
+    dim3 grid(g.tiles_m * g.tiles_n * nsplit);
     if (conv) hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
     SPAIR_CHECK_LAUNCH();

@@ -143,41 +143,62 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: one workgroup per object
+// backward: one WAVE per object (4 objects of the same sample per workgroup).  Each wave keeps its sprite and the
+// sprite gradient in LDS, walks the object's pixel footprint, scatters tap gradients with ds_add_f32, reduces
+// d(z_where, pres, depth) with wave shuffles (no block barriers in the hot path) and writes dlogits once.
+// Workgroup -> sample mapping is XCD-aware: every object of sample b runs on XCD b%8, so the per-pixel aux map of a
+// sample (I*I*16 B) is only ever cached in one L2.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
-                                                    const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
-                                                    const float4* __restrict__ aux, const float* __restrict__ gloss,
-                                                    float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
-                                                    float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
-                                                    float obj_scale, float alpha_scale) {
+#define RB_WAVES 4
+__global__ __launch_bounds__(64 * RB_WAVES) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+                                                              const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
+                                                              const float4* __restrict__ aux, const float* __restrict__ gloss,
+                                                              float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
+                                                              float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
+                                                              float obj_scale, float alpha_scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int PP2 = P * P * 2;
-    float* Ssh = sm;            // sprite (grey, alpha)
-    float* dSh = sm + PP2;      // its gradient
-    __shared__ float red[4];
-    const int r = blockIdx.x, b = r % B;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Ssh = sm + (size_t)wave * 2 * PP2;     // sprite (grey, alpha)
+    float* dSh = Ssh + PP2;                        // its gradient
+    // (sample, object) of this wave
+    const int kgroups = (HW + RB_WAVES - 1) / RB_WAVES;
+    int b, kg;
+    if ((B & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = (j % (B >> 3)) * 8 + xcd;
+        kg = j / (B >> 3);
+    } else {
+        b = blockIdx.x % B;
+        kg = blockIdx.x / B;
+    }
+    const int k = kg * RB_WAVES + wave;
+    const bool live = k < HW && kg < kgroups;
+    const int r = live ? k * B + b : 0;
     const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
     const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
     const float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
-    for (int e = threadIdx.x; e < PP2; e += blockDim.x) {
-        Ssh[e] = S[(size_t)r * ld_s + e];
-        dSh[e] = 0.f;
+    if (live) {
+        for (int e = lane * 4; e < PP2; e += 256) {
+            *reinterpret_cast<float4*>(&Ssh[e]) = *reinterpret_cast<const float4*>(S + (size_t)r * ld_s + e);
+            *reinterpret_cast<float4*>(&dSh[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
-    // pixel footprint: source coord is affine in the pixel index; widen by 2 and test exactly below
-    const float sx0 = src_of(ax, bx, 0, I, P, ac), sxa = src_of(ax, bx, 1, I, P, ac) - sx0;
-    const float sy0 = src_of(ay, by, 0, I, P, ac), sya = src_of(ay, by, 1, I, P, ac) - sy0;
-    int X0 = (int)floorf((-1.f - sx0) / sxa) - 2, X1 = (int)ceilf(((float)P - sx0) / sxa) + 2;
-    int Y0 = (int)floorf((-1.f - sy0) / sya) - 2, Y1 = (int)ceilf(((float)P - sy0) / sya) + 2;
-    X0 = max(X0, 0); Y0 = max(Y0, 0); X1 = min(X1, I - 1); Y1 = min(Y1, I - 1);
-    const int fw = X1 - X0 + 1, fh = Y1 - Y0 + 1;
     float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f, g_pr = 0.f, g_dp = 0.f;
-    const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
-    if (fw > 0 && fh > 0) {
-        for (int idx = threadIdx.x; idx < fw * fh; idx += blockDim.x) {
+    if (live) {
+        // pixel footprint: source coord is affine in the pixel index; widen by 2 and test exactly below
+        const float sx0 = src_of(ax, bx, 0, I, P, ac), sxa = src_of(ax, bx, 1, I, P, ac) - sx0;
+        const float sy0 = src_of(ay, by, 0, I, P, ac), sya = src_of(ay, by, 1, I, P, ac) - sy0;
+        int X0 = (int)floorf((-1.f - sx0) / sxa) - 2, X1 = (int)ceilf(((float)P - sx0) / sxa) + 2;
+        int Y0 = (int)floorf((-1.f - sy0) / sya) - 2, Y1 = (int)ceilf(((float)P - sy0) / sya) + 2;
+        X0 = max(X0, 0); Y0 = max(Y0, 0); X1 = min(X1, I - 1); Y1 = min(Y1, I - 1);
+        const int fw = X1 - X0 + 1, fh = Y1 - Y0 + 1;
+        const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
+        const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
+        for (int idx = lane; idx < npx; idx += 64) {
             const int py = Y0 + idx / fw, px = X0 + idx % fw;
             const float sx = src_of(ax, bx, px, I, P, ac), sy = src_of(ay, by, py, I, P, ac);
             if (!(sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P)) continue;
@@ -191,8 +212,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(const float* __restrict__ S,
                 const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
                 ok[t] = !(yy < 0 || yy >= P || xx < 0 || xx >= P);
                 W[t] = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
-                G[t] = ok[t] ? Ssh[(yy * P + xx) * 2] : 0.f;
-                A0[t] = ok[t] ? Ssh[(yy * P + xx) * 2 + 1] : 0.f;
+                const float2 v = ok[t] ? *reinterpret_cast<const float2*>(&Ssh[(yy * P + xx) * 2]) : make_float2(0.f, 0.f);
+                G[t] = v.x;
+                A0[t] = v.y;
                 Mt[t] = ok[t] ? fmaxf(A0[t] * pd, 0.01f) : 0.f;
                 g += W[t] * G[t];
                 a += W[t] * (A0[t] * pr);
@@ -226,25 +248,27 @@ __global__ __launch_bounds__(256) void k_render_bwd(const float* __restrict__ S,
             g_ty += -g_gy * ay; g_ys += -g_gy * gyn * ay;
         }
     }
-    g_tx = block_reduce_sum_256(g_tx, red);
-    g_ty = block_reduce_sum_256(g_ty, red);
-    g_xs = block_reduce_sum_256(g_xs, red);
-    g_ys = block_reduce_sum_256(g_ys, red);
-    g_pr = block_reduce_sum_256(g_pr, red);
-    g_dp = block_reduce_sum_256(g_dp, red);
-    if (threadIdx.x == 0) {
-        dnbox[(size_t)r * 4 + 0] = 2.f * g_tx;
-        dnbox[(size_t)r * 4 + 1] = 2.f * g_ty;
-        dnbox[(size_t)r * 4 + 2] = g_xs;
-        dnbox[(size_t)r * 4 + 3] = g_ys;
+    g_tx = wave_reduce_sum(g_tx); g_ty = wave_reduce_sum(g_ty);
+    g_xs = wave_reduce_sum(g_xs); g_ys = wave_reduce_sum(g_ys);
+    g_pr = wave_reduce_sum(g_pr); g_dp = wave_reduce_sum(g_dp);
+    if (live && lane == 0) {
+        *reinterpret_cast<float4*>(dnbox + (size_t)r * 4) = make_float4(2.f * g_tx, 2.f * g_ty, g_xs, g_ys);
         dpres[r] = g_pr;
         ddepth[r] = g_dp;
     }
     __syncthreads();
     // through the analytical sigmoid and the logit scales (models.py:485-492)
-    for (int e = threadIdx.x; e < PP2; e += blockDim.x) {
-        const float s = Ssh[e];
-        dlogits[(size_t)r * ld_g + e] = dSh[e] * s * (1.f - s) * ((e & 1) ? alpha_scale : obj_scale);
+    if (live) {
+        for (int e = lane * 4; e < PP2; e += 256) {
+            const float4 sv = *reinterpret_cast<const float4*>(&Ssh[e]);
+            const float4 dv = *reinterpret_cast<const float4*>(&dSh[e]);
+            float4 o;
+            o.x = dv.x * sv.x * (1.f - sv.x) * obj_scale;
+            o.y = dv.y * sv.y * (1.f - sv.y) * alpha_scale;
+            o.z = dv.z * sv.z * (1.f - sv.z) * obj_scale;
+            o.w = dv.w * sv.w * (1.f - sv.w) * alpha_scale;
+            *reinterpret_cast<float4*>(dlogits + (size_t)r * ld_g + e) = o;
+        }
     }
 }
 
@@ -275,8 +299,10 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I,
                int P, int ac, float obj_scale, float alpha_scale, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)P * P * 2 * 2 * sizeof(float);
-    hipLaunchKernelGGL(k_render_bwd, dim3(B * HW), dim3(256), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
+    if ((P * P * 2) % 4 || (ld_s & 3) || (ld_g & 3)) return SPAIR_ERR_ALIGN;
+    const size_t lds = (size_t)RB_WAVES * P * P * 2 * 2 * sizeof(float);
+    const int kgroups = (HW + RB_WAVES - 1) / RB_WAVES;
+    hipLaunchKernelGGL(k_render_bwd, dim3(B * kgroups), dim3(64 * RB_WAVES), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
                        reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
                        alpha_scale);
     SPAIR_CHECK_LAUNCH();
