@@ -37,6 +37,7 @@ struct CellBufs {
     float *Xo, *Ho1, *Ho2, *Oo;
     float *rec, *sd_attr, *nbox, *stat;
     float* Za;                                              // attr rows for the decoder [N, ld_rec], zero padded
+    unsigned int* gxy;                                      // fused chain only: per glimpse element (d val/d gx, d val/d gy) as bf16x2 [N, ld_gl]
     float *z_where, *z_pres;                                // NCHW outputs
     // backward
     float *dXb, *dHb1, *dHb2, *dOb;

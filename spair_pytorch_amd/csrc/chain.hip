@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             const float* r0p = img + y0 * a.I;
             const float* r1p = img + (yin ? y0 + 1 : y0) * a.I;
             float out[4];
+            unsigned int gxy[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float ix, mx;
@@ -280,12 +281,20 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const float wx1 = ix - (float)x0, wx0 = 1.f - wx1;
                 const int x1 = ((x0 + 1) < a.I) ? x0 + 1 : x0;
                 const float m1 = ((x0 + 1) < a.I) ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
-                out[q] = r0p[x0] * (wy0 * wx0) + m1 * r0p[x1] * (wy0 * wx1) + n1 * r1p[x0] * (wy1 * wx0) + m1 * n1 * r1p[x1] * (wy1 * wx1);
+                const float v00 = r0p[x0], v01 = m1 * r0p[x1], v10 = n1 * r1p[x0], v11 = m1 * n1 * r1p[x1];
+                out[q] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
+                // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
+                const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
+                const float gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
+                union { __bf16 h[2]; unsigned int u; } pk;
+                pk.h[0] = (__bf16)gx; pk.h[1] = (__bf16)gy;
+                gxy[q] = pk.u;
             }
             bf16x4 o;
             o[0] = (__bf16)out[0]; o[1] = (__bf16)out[1]; o[2] = (__bf16)out[2]; o[3] = (__bf16)out[3];
             *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
             *reinterpret_cast<float4*>(P.glimpse + (size_t)row_r[row] * L.ld_gl + e) = make_float4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<uint4*>(P.gxy + (size_t)row_r[row] * L.ld_gl + e) = make_uint4(gxy[0], gxy[1], gxy[2], gxy[3]);
         }
         lds_barrier();
         CH_STAMP();
@@ -436,43 +445,76 @@ namespace {
 constexpr int LD_R = 328;      // ring row: [feat 100 | ctx 224] fp32
 
 // out[16, NT*16] = in[16, 32*KT] . Wt ; wide-N / short-K form: A fragments held in registers, column tiles streamed with a 2-tile
-// weight-fragment double buffer; `epi(nt, acc)` consumes each tile as soon as it is complete.
+// weight-fragment double buffer; `epi(nt, acc)` consumes each tile as soon as it is complete (it must ignore nt >= NT).
+// Straight-line between a tile's loads and its MFMAs (see wg_gemm): the trip count is the same for every wave and tiles past
+// the end are clamped, never branched around.
 template <int KT, int NT, class Epi>
 __device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uint4* __restrict__ Wt, int wave, int lane, Epi epi) {
+    // epi(j, nt, acc): j = ordinal of the tile within this wave (compile-time constant: the pair loop is fully unrolled so that
+    // per-tile data prefetched into registers can be indexed statically)
+    constexpr int MY = (NT + NW - 1) / NW, PAIRS = (MY + 1) / 2;
     bf16x8 af[KT];
     const int arow = lane & 15, kg = (lane >> 4) * 8;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) af[kt] = *reinterpret_cast<const bf16x8*>(in + arow * ld + kt * 32 + kg);
+    auto tile_ptr = [&](int nt) { return Wt + (size_t)min(nt, NT - 1) * KT * 64 + lane; };
     uint4 bq[2][KT];
-    if (wave < NT) {
+    {
+        const uint4* b0 = tile_ptr(wave);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) bq[0][kt] = Wt[(size_t)(wave * KT + kt) * 64 + lane];
+        for (int kt = 0; kt < KT; ++kt) bq[0][kt] = b0[kt * 64];
     }
-    // two tiles per trip so that the double-buffer indices are static (no scratch) while the code is emitted only twice
-#pragma unroll 1
-    for (int nt0 = wave; nt0 < NT; nt0 += 2 * NW) {
-        const int nt1 = nt0 + NW, nt2 = nt0 + 2 * NW;
-        if (nt1 < NT) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) bq[1][kt] = Wt[(size_t)(nt1 * KT + kt) * 64 + lane];
+    for (int pr = 0; pr < PAIRS; ++pr) {
+        const int nt0 = wave + 2 * pr * NW, nt1 = nt0 + NW, nt2 = nt0 + 2 * NW;
+        {
+            const uint4* b1 = tile_ptr(nt1);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) bq[1][kt] = b1[kt * 64];
         }
         {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[0][kt]), acc, 0, 0, 0);
-            epi(nt0, acc);
+            epi(2 * pr, nt0, acc);
         }
-        if (nt2 < NT) {
+        {
+            const uint4* b2 = tile_ptr(nt2);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) bq[0][kt] = Wt[(size_t)(nt2 * KT + kt) * 64 + lane];
+            for (int kt = 0; kt < KT; ++kt) bq[0][kt] = b2[kt * 64];
         }
-        if (nt1 < NT) {
+        {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[1][kt]), acc, 0, 0, 0);
-            epi(nt1, acc);
+            epi(2 * pr + 1, nt1, acc);
         }
     }
+}
+
+// One hidden layer of the data-gradient chain: dPre[16, nout] = (dOut . W) * relu'(H).  The relu masks come from the forward
+// activations in HBM: at the start of every wavefront step all 7 masks of the step are fetched with coalesced 16-byte loads
+// (7 per thread -- per-lane 4-byte loads in the MFMA output layout would need 32 and, together with the other prefetches,
+// overflow the 6-bit vmcnt counter, which serialises the wave) and parked in LDS as one byte per element.
+constexpr int MK_H = 112, MK_ROW = 5 * MK_H + 128 + 256;        // per-row mask bytes: Ho1 Hz2 Hz1 Hb2 Hb1 | He2 | He1
+constexpr int MK_HO1 = 0, MK_HZ2 = MK_H, MK_HZ1 = 2 * MK_H, MK_HB2 = 3 * MK_H, MK_HB1 = 4 * MK_H, MK_HE2 = 5 * MK_H, MK_HE1 = 5 * MK_H + 128;
+constexpr int MK_F4_ROW = 5 * 25 + 32 + 64;                     // float4 loads per row
+constexpr int MK_PER_THREAD = (MT * MK_F4_ROW + NTH - 1) / NTH;
+
+template <int KT, int NT>
+__device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned char* mk, int ldh,
+                                           float* __restrict__ dOut, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane) {
+    wg_gemm_wide<KT, NT>(in, LD_H, Wt, wave, lane, [&](int j, int nt, const f32x4& acc) {
+        const int n = nt * 16 + (lane & 15);
+        if (n >= nout) return;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = (lane >> 4) * 4 + rr;
+            const float v = mk[row * MK_ROW + n] ? acc[rr] : 0.f;
+            if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = v;
+            dst[row * LD_H + n] = (__bf16)v;
+        }
+    });
 }
 
 }  // namespace
@@ -487,6 +529,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ float gnb[MT][4], nb_sh[MT][4];
     __shared__ float dOo_sh[MT], zp_sh[MT];
     __shared__ float edge_acc[REC];
+    __shared__ __attribute__((aligned(16))) unsigned char mk_sh[MT * MK_ROW];
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ int cons_sh[MT][4], nbr_row[MT][4];
     __shared__ int dstart_sh[3 * 32 + 2];
@@ -494,8 +537,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
     const CellHyper& H = a.H;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    int tid = tid0, lane = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
     const float ks = H.kl_scale * (*P.gloss);
@@ -507,7 +551,13 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     if (tid < REC) edge_acc[tid] = 0.f;
     __syncthreads();
 
+    int stamp_j = 2048;
+#define CB_STAMP() do { if (a.stamps && b == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int t = T - 1; t >= 0; --t) {
+        CB_STAMP();
+        tid = tid0;   // opaque per-iteration copy: no LICM of lane-dependent address arithmetic (see k_chain_fwd)
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
         const int c0 = dstart_sh[t];
         const int nc = dstart_sh[t + 1] - c0;
         float (*slot)[LD_R] = ring[t & 3];
@@ -527,6 +577,35 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         lds_barrier();
+        CB_STAMP();
+        // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
+        // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
+        float4 mkq[MK_PER_THREAD];
+        {
+            const float* mbase[7] = {P.Ho1, P.Hz2, P.Hz1, P.Hb2, P.Hb1, P.He2, P.He1};
+            const int mld[7] = {SP_LDH, SP_LDH, SP_LDH, SP_LDH, SP_LDH, SP_ENC_H2, SP_ENC_H1};
+#pragma unroll
+            for (int q = 0; q < MK_PER_THREAD; ++q) {
+                const int idx = tid + q * NTH;
+                mkq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < MT * MK_F4_ROW) {
+                    const int row = idx / MK_F4_ROW, c = idx - row * MK_F4_ROW;
+                    const int layer = c < 125 ? c / 25 : (c < 157 ? 5 : 6);
+                    const int q4 = c < 125 ? c - layer * 25 : (c < 157 ? c - 125 : c - 157);
+                    if (row < nc) mkq[q] = *reinterpret_cast<const float4*>(mbase[layer] + (size_t)row_r[row] * mld[layer] + q4 * 4);
+                }
+            }
+        }
+        unsigned int gxy_pf[7][4];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int e = (wave + NW * j) * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = (lane >> 4) * 4 + rr;
+                gxy_pf[j][rr] = (row < nc && e < GLN) ? P.gxy[(size_t)row_r[row] * L.ld_gl + e] : 0u;
+            }
+        }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
         for (int idx = tid; idx < nc * REC; idx += NTH) {
             const int row = idx / REC, j = idx - row * REC;
@@ -541,6 +620,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             grec[row][j] = g;
         }
         lds_barrier();
+        CB_STAMP();
         // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit)
         {
             const int row = tid >> 5, l = tid & 31;
@@ -564,6 +644,21 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         lds_barrier();
+        CB_STAMP();
+        // park the prefetched relu masks in LDS (one byte per element); first consumer is two stages away
+#pragma unroll
+        for (int q = 0; q < MK_PER_THREAD; ++q) {
+            const int idx = tid + q * NTH;
+            if (idx < MT * MK_F4_ROW) {
+                const int row = idx / MK_F4_ROW, c = idx - row * MK_F4_ROW;
+                const int layer = c < 125 ? c / 25 : (c < 157 ? 5 : 6);
+                const int q4 = c < 125 ? c - layer * 25 : (c < 157 ? c - 125 : c - 157);
+                const int off = (layer < 5 ? layer * MK_H : (layer == 5 ? MK_HE2 : MK_HE1)) + q4 * 4;
+                const unsigned int pk = (mkq[q].x > 0.f ? 1u : 0u) | (mkq[q].y > 0.f ? 0x100u : 0u) | (mkq[q].z > 0.f ? 0x10000u : 0u) |
+                                        (mkq[q].w > 0.f ? 0x1000000u : 0u);
+                *reinterpret_cast<unsigned int*>(&mk_sh[row * MK_ROW + off]) = pk;
+            }
+        }
         // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu
         for (int idx = tid; idx < MT * SP_H; idx += NTH) {
             const int row = idx / SP_H, n = idx - row * SP_H;
@@ -576,26 +671,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             Aa[row * LD_H + n] = (__bf16)v;
         }
         lds_barrier();
-        auto hidden_epi = [&](const float* __restrict__ Hm, int ldh, float* __restrict__ dOut, int nout, __bf16* dst) {
-            return [=](int nt, const f32x4& acc) {
-                const int n = nt * 16 + (lane & 15);
-                if (n >= nout) return;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = (lane >> 4) * 4 + rr;
-                    float v = 0.f;
-                    if (row < nc) {
-                        const size_t r = row_r[row];
-                        v = (Hm[r * ldh + n] > 0.f) ? acc[rr] : 0.f;
-                        dOut[r * ldh + n] = v;
-                    }
-                    dst[row * LD_H + n] = (__bf16)v;
-                }
-            };
-        };
-        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_OBJ1], wave, lane, hidden_epi(P.Ho1, SP_LDH, P.dHo1, SP_H, Ab));
+        CB_STAMP();
+        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mk_sh + MK_HO1, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int nt, const f32x4& acc) {
+        CB_STAMP();
+        wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int j, int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX + KX) return;
 #pragma unroll
@@ -606,6 +686,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         });
         lds_barrier();
+        CB_STAMP();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
@@ -628,11 +709,14 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             Aa[tid * LD_H + NP + 1] = (__bf16)d_ls;
         }
         lds_barrier();
-        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_ZH], wave, lane, hidden_epi(P.Hz2, SP_LDH, P.dHz2, SP_H, Ab));
+        CB_STAMP();
+        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mk_sh + MK_HZ2, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_Z1], wave, lane, hidden_epi(P.Hz1, SP_LDH, P.dHz1, SP_H, Aa));
+        CB_STAMP();
+        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mk_sh + MK_HZ1, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int nt, const f32x4& acc) {
+        CB_STAMP();
+        wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int j, int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX + KX) return;
 #pragma unroll
@@ -643,6 +727,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         });
         lds_barrier();
+        CB_STAMP();
         // ---- attributes -> gradient of the encoder output
         for (int idx = tid; idx < MT * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
@@ -659,49 +744,53 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             Ab[row * LD_H + A_ + j] = (__bf16)d_ls;
         }
         lds_barrier();
-        wg_gemm_wide<4, 8>(Ab, LD_H, a.wt[CW_ENC2], wave, lane, hidden_epi(P.He2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa));
+        CB_STAMP();
+        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mk_sh + MK_HE2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 16>(Aa, LD_H, a.wt[CW_ENC1], wave, lane, hidden_epi(P.He1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab));
+        CB_STAMP();
+        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mk_sh + MK_HE1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane);
         lds_barrier();
-        // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273); the glimpse gradient is never stored
-        wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int nt, const f32x4& acc) {
-            const int e = nt * 16 + (lane & 15);
-            const bool ok = e < GLN;
-            const int i = ok ? e / a.Pp : 0, j = ok ? e - i * a.Pp : 0;
-            const float* img = a.x + (size_t)b * a.I * a.I;
+        CB_STAMP();
+        // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273): the glimpse gradient is never stored;
+        // each element meets the (d val/d gx, d val/d gy) pair the forward kernel saved, lane sums are reduced once per layer
+        {
+            float gsum[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) gsum[rr][0] = gsum[rr][1] = gsum[rr][2] = gsum[rr][3] = 0.f;
+            wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int j, int nt, const f32x4& acc) {
+                const int e = nt * 16 + (lane & 15);
+                if (e >= GLN) return;
+                const int gi = e / a.Pp, gj = e - gi * a.Pp;
+                const float X = stn_base(gj, a.Pp, a.ac), Y = stn_base(gi, a.Pp, a.ac);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = (lane >> 4) * 4 + rr;
+                    if (row < nc && j < 7) {
+                        union { unsigned int u; __bf16 h[2]; } pk;
+                        pk.u = gxy_pf[j < 7 ? j : 0][rr];
+                        const float gix = acc[rr] * (float)pk.h[0], giy = acc[rr] * (float)pk.h[1];
+                        gsum[rr][0] += gix; gsum[rr][1] += giy; gsum[rr][2] += gix * X; gsum[rr][3] += giy * Y;
+                    }
+                }
+            });
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int row = (lane >> 4) * 4 + rr;
-                float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f;
-                if (ok && row < nc) {
-                    float ix, iy, mx, my;
-                    const float X = stn_src_coord(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, j, a.Pp, a.I, a.ac, true, ix, mx);
-                    const float Y = stn_src_coord(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, i, a.Pp, a.I, a.ac, true, iy, my);
-                    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
-                    const float wx1 = ix - (float)x0, wy1 = iy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                    const bool xin = (x0 + 1) < a.I, yin = (y0 + 1) < a.I;
-                    const float v00 = img[y0 * a.I + x0];
-                    const float v01 = xin ? img[y0 * a.I + x0 + 1] : 0.f;
-                    const float v10 = yin ? img[(y0 + 1) * a.I + x0] : 0.f;
-                    const float v11 = (xin && yin) ? img[(y0 + 1) * a.I + x0 + 1] : 0.f;
-                    const float g = acc[rr];
-                    const float gix = g * ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
-                    const float giy = g * ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
-                    g_tx = gix; g_xs = gix * X; g_ty = giy; g_ys = giy * Y;
-                }
-                // reduce over the 16 lanes that share this row (same lane>>4), then one LDS atomic per value
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    g_tx += __shfl_xor(g_tx, o, 64); g_ty += __shfl_xor(g_ty, o, 64);
-                    g_xs += __shfl_xor(g_xs, o, 64); g_ys += __shfl_xor(g_ys, o, 64);
+                for (int k = 0; k < 4; ++k) {
+                    float v = gsum[rr][k];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    gsum[rr][k] = v;
                 }
+                const int row = (lane >> 4) * 4 + rr;
                 if ((lane & 15) == 0 && row < nc) {
-                    atomicAdd(&gnb[row][0], 2.f * g_tx); atomicAdd(&gnb[row][1], 2.f * g_ty);
-                    atomicAdd(&gnb[row][2], g_xs); atomicAdd(&gnb[row][3], g_ys);
+                    atomicAdd(&gnb[row][0], 2.f * gsum[rr][0]); atomicAdd(&gnb[row][1], 2.f * gsum[rr][1]);   // tx = 2*xt - 1
+                    atomicAdd(&gnb[row][2], gsum[rr][2]); atomicAdd(&gnb[row][3], gsum[rr][3]);
                 }
             }
-        });
+        }
         lds_barrier();
+        CB_STAMP();
         // ---- box (models.py:322-381 backward); passthrough gradient -> box-net head
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
@@ -729,17 +818,21 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             for (int k = 0; k < 8; ++k) Aa[tid * LD_H + NP + k] = (__bf16)dlat[k];
         }
         lds_barrier();
-        wg_gemm_wide<4, 7>(Aa, LD_H, a.wt[CW_BOXH], wave, lane, hidden_epi(P.Hb2, SP_LDH, P.dHb2, SP_H, Ab));
+        CB_STAMP();
+        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mk_sh + MK_HB2, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 7>(Ab, LD_H, a.wt[CW_BOX1], wave, lane, hidden_epi(P.Hb1, SP_LDH, P.dHb1, SP_H, Aa));
+        CB_STAMP();
+        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mk_sh + MK_HB1, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane);
         lds_barrier();
-        wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int nt, const f32x4& acc) {
+        CB_STAMP();
+        wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int j, int nt, const f32x4& acc) {
             const int n = nt * 16 + (lane & 15);
             if (n >= F + CTX) return;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) slot[(lane >> 4) * 4 + rr][n] += acc[rr];
         });
         lds_barrier();
+        CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
         for (int idx = tid; idx < nc * (F + CTX); idx += NTH) {
             const int row = idx / (F + CTX), n = idx - row * (F + CTX);
@@ -752,6 +845,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         lds_barrier();
+        CB_STAMP();
     }
     if (tid < REC) atomicAdd(&a.gedge[tid], edge_acc[tid]);
 }

@@ -213,6 +213,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.ld_s = round_up(d.P * d.P * (d.C + 1), 8);
     w.Za = c.take<float>(N * L.ld_rec);
     b.Za = w.Za;
+    b.gxy = chain_fwd_supported(d) ? c.take<unsigned int>(N * L.ld_gl) : nullptr;
     w.Hd1 = c.take<float>(N * SP_DEC_H1); w.Hd2 = c.take<float>(N * SP_DEC_H2); w.S = c.take<float>(N * w.ld_s);
     w.dLog = c.take<float>(N * w.ld_s); w.dHd2 = c.take<float>(N * SP_DEC_H2); w.dHd1 = c.take<float>(N * SP_DEC_H1);
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
@@ -702,6 +703,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         a.w_obj2 = params + PL.lin[LIN_OBJ2].w;
         a.gedge = grads + PL.edge;
         a.x = x; a.I = d->I; a.Pp = d->P; a.ac = d->align_corners;
+        a.stamps = (st->flags & 2) ? c.w.stamps : nullptr;
         TRY(chain_bwd(a, c.s));
     } else {
     for (int t = c.T - 1; t >= 0; --t) {
