@@ -18,7 +18,7 @@ int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, 
 int render_sprite_act(float* S, int ld, int N, int per, int CH, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);
 int render_num_blocks(int B, int I);
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s);
-int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, hipStream_t s);
+int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, hipStream_t s);
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
@@ -121,7 +121,8 @@ struct Ws {
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
     float *feat, *dfeat;
     CellBufs cb;
-    float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;
+    float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;     // Hd*, dLog, dHd*: bf16 in bf16 mode
+    void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
     float *aux, *bce_partial, *kl_partial, *klp;
     unsigned long long* stamps;
     int ld_feat, ld_s;
@@ -188,8 +189,8 @@ static Ws carve(const SpairDims& d, void* base) {
     for (int i = 0; i < d.n_conv; ++i) {
         const ConvSpec& cs = PL.conv[i];
         const size_t n = (size_t)d.B * cs.hout * cs.hout * cs.cout;
-        w.act[i] = c.take<float>(n);
-        w.dact[i] = c.take<float>(n);
+        w.act[i] = reinterpret_cast<float*>(c.take_bytes(n * es));      // NHWC, bf16 in bf16 mode
+        w.dact[i] = reinterpret_cast<float*>(c.take_bytes(n * es));
     }
     w.ld_feat = round_up(d.F, 8);
     w.feat = c.take<float>(N * w.ld_feat);
@@ -214,8 +215,11 @@ static Ws carve(const SpairDims& d, void* base) {
     w.Za = c.take<float>(N * L.ld_rec);
     b.Za = w.Za;
     b.gxy = chain_fwd_supported(d) ? c.take<unsigned int>(N * L.ld_gl) : nullptr;
-    w.Hd1 = c.take<float>(N * SP_DEC_H1); w.Hd2 = c.take<float>(N * SP_DEC_H2); w.S = c.take<float>(N * w.ld_s);
-    w.dLog = c.take<float>(N * w.ld_s); w.dHd2 = c.take<float>(N * SP_DEC_H2); w.dHd1 = c.take<float>(N * SP_DEC_H1);
+    w.Hd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es)); w.Hd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es));
+    w.S = c.take<float>(N * w.ld_s);
+    w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
+    w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
+    w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
@@ -360,6 +364,27 @@ static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, i
     g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
     return spair_gemm_tn_impl(g, false, c.d.dtype, c.s);
 }
+// bf16-stored operand GEMMs (gemm16.hip)
+static int nt16(Ctx& c, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
+                const void* mask, int ldmask, int relu, const ConvDesc* conv = nullptr, const RowMap* cmap = nullptr) {
+    GemmNT g;
+    memset(&g, 0, sizeof(g));
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = B; g.ldb = ldb; g.C = reinterpret_cast<float*>(C); g.ldc = ldc; g.c_bf16 = c_bf16;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.mask = reinterpret_cast<const float*>(mask); g.ldmask = ldmask; g.mask_bf16 = 1; g.relu = relu;
+    if (conv) g.conv = *conv;
+    if (cmap) { g.cmap = *cmap; g.use_cmap = 1; }
+    return spair_gemm_nt16_impl(g, conv != nullptr, c.s);
+}
+static int tn16(Ctx& c, const void* A, int lda, int M, const void* B, int ldb, int N, bool b_bf16, float* C, int ldc, int R, float* colsum,
+                const ConvDesc* conv = nullptr, int cw_cin = 0, int cw_taps = 0) {
+    GemmTN g;
+    memset(&g, 0, sizeof(g));
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = reinterpret_cast<const float*>(B); g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = round_up(M, 8); g.N = round_up(N, b_bf16 ? 8 : 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
+    g.cw_cin = cw_cin; g.cw_taps = cw_taps;
+    if (conv) g.conv = *conv;
+    return spair_gemm_tn16_impl(g, conv != nullptr, b_bf16, c.s);
+}
 static const void* bptr(const void* base, size_t elem_off, int dtype) {
     return reinterpret_cast<const char*>(base) + elem_off * (dtype == SPAIR_BF16 ? 2 : 4);
 }
@@ -472,23 +497,28 @@ static ConvDesc fwd_desc(const ConvSpec& cs) {
 
 static int backbone_fwd(Ctx& c) {
     const SpairDims& d = c.d;
+    const int b16 = d.dtype == SPAIR_BF16;
     const int Ip = d.I + d.pad_pre + d.pad_post;
     TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, Ip, c.s));
     const ConvSpec& c0 = c.PL.conv[0];
-    TRY(misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, c.s));
+    TRY(misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, b16, c.s));
     for (int i = 1; i < c.PL.n_conv; ++i) {
         const ConvSpec& cs = c.PL.conv[i];
         const bool last = (i == c.PL.n_conv - 1);
         const int M = d.B * cs.hout * cs.hout, K = cs.k * cs.k * cs.cin;
         float* out = last ? c.w.feat : c.w.act[i];
         const int ldc = last ? c.w.ld_feat : cs.cout;
-        if (cs.k == 1) {
+        const ConvDesc cd = fwd_desc(cs);
+        if (b16) {   // activations stored as bf16; the feature map handed to the per-cell chain stays fp32
+            TRY(nt16(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, last ? 0 : 1, M, cs.cout, round_up(K, 8),
+                     c.params + cs.b, nullptr, 0, last ? 0 : 1, cs.k == 1 ? nullptr : &cd));
+        } else if (cs.k == 1) {
             TRY(nt(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, M, cs.cout, round_up(K, 8), c.params + cs.b, nullptr, 0, last ? 0 : 1));
         } else {
             GemmNT g;
             memset(&g, 0, sizeof(g));
             g.A = c.w.act[i - 1]; g.B = c.w.conv_wf[i]; g.ldb = round_up(K, 8); g.C = out; g.ldc = ldc; g.M = M; g.N = cs.cout; g.K = K;
-            g.bias = c.params + cs.b; g.relu = last ? 0 : 1; g.conv = fwd_desc(cs);
+            g.bias = c.params + cs.b; g.relu = last ? 0 : 1; g.conv = cd;
             ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
             TRY(spair_gemm_nt_impl(g, true, d.dtype, c.s));
         }
@@ -496,8 +526,53 @@ static int backbone_fwd(Ctx& c) {
     return SPAIR_OK;
 }
 
+static int backbone_bwd16(Ctx& c, float* grads) {
+    const SpairDims& d = c.d;
+    const int last = c.PL.n_conv - 1;
+    const int N = d.B * d.G * d.G;
+    TRY(spair_to_bf16(c.w.dfeat, c.w.ld_feat, c.w.dfeat16, c.w.ld_feat, N, c.w.ld_feat, c.s));
+    for (int i = last; i >= 1; --i) {
+        const ConvSpec& cs = c.PL.conv[i];
+        const int M = d.B * cs.hout * cs.hout;
+        const void* dout = (i == last) ? c.w.dfeat16 : (const void*)c.w.dact[i];
+        const int ldd = (i == last) ? c.w.ld_feat : cs.cout;
+        const void* in = c.w.act[i - 1];
+        const ConvDesc cd = fwd_desc(cs);
+        if (cs.k == 1) {
+            TRY(tn16(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, true, grads + cs.w, cs.cin, M, grads + cs.b));
+            const int Kd = round_up(cs.cout, 8);
+            TRY(nt16(c, dout, ldd, c.w.conv_wd[i][0], Kd, c.w.dact[i - 1], cs.cin, 1, M, cs.cin, Kd, nullptr, in, cs.cin, 0));
+        } else {
+            const int K = cs.k * cs.k * cs.cin;
+            TRY(tn16(c, dout, ldd, cs.cout, in, 0, K, true, grads + cs.w, K, M, grads + cs.b, &cd, cs.cin, cs.k * cs.k));
+            const int T = cs.k / cs.s;
+            for (int py = 0; py < cs.s; ++py)
+                for (int px = 0; px < cs.s; ++px) {
+                    const int Hc = (cs.hin - py + cs.s - 1) / cs.s, Wc = (cs.hin - px + cs.s - 1) / cs.s;
+                    if (Hc <= 0 || Wc <= 0) continue;
+                    ConvDesc dd;
+                    dd.Hin = cs.hout; dd.Win = cs.hout; dd.Cin = cs.cout; dd.Hout = Hc; dd.Wout = Wc; dd.kh = T; dd.kw = T;
+                    dd.sy = 1; dd.sx = 1; dd.dky = -1; dd.dkx = -1; dd.oy = 0; dd.ox = 0;
+                    RowMap rm;
+                    rm.Hout = Hc; rm.Wout = Wc; rm.Hc = cs.hin; rm.Wc = cs.hin; rm.osy = cs.s; rm.osx = cs.s; rm.ooy = py; rm.oox = px;
+                    TRY(nt16(c, dout, 0, c.w.conv_wd[i][py * cs.s + px], T * T * cs.cout, c.w.dact[i - 1], cs.cin, 1, d.B * Hc * Wc, cs.cin,
+                             T * T * cs.cout, nullptr, in, cs.cin, 0, &dd, &rm));
+                }
+        }
+    }
+    {   // first layer: A = d act0 (bf16), B gathered element-wise from the padded fp32 input
+        const ConvSpec& c0 = c.PL.conv[0];
+        const ConvDesc cd = fwd_desc(c0);
+        const int K = c0.k * c0.k * c0.cin;
+        TRY(tn16(c, c.w.dact[0], c0.cout, c0.cout, c.w.xpad, 0, K, false, grads + c0.w, K, d.B * c0.hout * c0.hout, grads + c0.b, &cd, c0.cin,
+                 c0.k * c0.k));
+    }
+    return SPAIR_OK;
+}
+
 static int backbone_bwd(Ctx& c, float* grads) {
     const SpairDims& d = c.d;
+    if (d.dtype == SPAIR_BF16) return backbone_bwd16(c, grads);
     const int last = c.PL.n_conv - 1;
     for (int i = last; i >= 1; --i) {
         const ConvSpec& cs = c.PL.conv[i];
@@ -626,17 +701,26 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     const int per = d->P * d->P * (d->C + 1);
     {
         ProfScope ps(PS_DECODER_FWD, c.s);
-        TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
-        TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
+        const int b16 = d->dtype == SPAIR_BF16;
+        const int K0 = round_up(PL.lin[LIN_DEC0].in, 8), K2 = round_up(PL.lin[LIN_DEC2].in, 8);
+        if (b16) {   // hidden activations stored as bf16
+            TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));
+            TRY(nt16(c, c.w.Za16, L.ld_rec, c.w.lin_wf[LIN_DEC0], K0, c.w.Hd1, SP_DEC_H1, 1, N, SP_DEC_H1, K0, params + PL.lin[LIN_DEC0].b, nullptr, 0, 1));
+            TRY(nt16(c, c.w.Hd1, SP_DEC_H1, c.w.lin_wf[LIN_DEC1], SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 1, N, SP_DEC_H2, SP_DEC_H1,
+                     params + PL.lin[LIN_DEC1].b, nullptr, 0, 1));
+        } else {
+            TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.Hd1, SP_DEC_H1, 0, N, params + PL.lin[LIN_DEC0].b, SP_DEC_H1, 1));
+            TRY(fwd_lin(c, LIN_DEC1, c.w.Hd1, SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 0, N, params + PL.lin[LIN_DEC1].b, SP_DEC_H2, 1));
+        }
         {   // decoder.out with the sprite sigmoid epilogue fused (models.py:485-492)
             ProfScope p2(PS_DEC2_FWD, c.s);
             GemmNT g;
             memset(&g, 0, sizeof(g));
-            const int K = round_up(PL.lin[LIN_DEC2].in, 8);
-            g.A = c.w.Hd2; g.lda = SP_DEC_H2; g.B = c.w.lin_wf[LIN_DEC2]; g.ldb = K; g.C = c.w.S; g.ldc = c.w.ld_s; g.M = N; g.N = per; g.K = K;
+            g.A = c.w.Hd2; g.lda = SP_DEC_H2; g.B = c.w.lin_wf[LIN_DEC2]; g.ldb = K2; g.C = c.w.S; g.ldc = c.w.ld_s; g.M = N; g.N = per; g.K = K2;
             g.bias = params + PL.lin[LIN_DEC2].b; g.sprite_ch = d->C + 1;
             g.obj_scale = d->obj_logit_scale; g.alpha_scale = d->alpha_logit_scale; g.alpha_bias = d->alpha_logit_bias;
-            TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
+            if (b16) TRY(spair_gemm_nt16_impl(g, false, c.s));
+            else TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
         }
     }
     // KL + render + loss
@@ -678,13 +762,25 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     const int N = L.N;
     const int per = d->P * d->P * (d->C + 1);
     // renderer -> d logits, d z_where, d z_pres, d z_depth
+    const int b16 = d->dtype == SPAIR_BF16;
     {
         ProfScope ps(PS_RENDER_BWD, c.s);
         TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
-                       d->alpha_logit_scale, c.s));
+                       d->alpha_logit_scale, b16, c.s));
     }
-    {   // decoder
+    if (b16) {   // decoder, bf16-stored activations and gradients
+        ProfScope ps(PS_DECODER_BWD, c.s);
+        const LinSpec &l2 = PL.lin[LIN_DEC2], &l1 = PL.lin[LIN_DEC1], &l0 = PL.lin[LIN_DEC0];
+        { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
+        { ProfScope p2(PS_DEC2_DGRAD, c.s);
+          TRY(nt16(c, c.w.dLog, c.w.ld_s, c.w.lin_wt[LIN_DEC2], round_up(per, 8), c.w.dHd2, SP_DEC_H2, 1, N, SP_DEC_H2, round_up(per, 8), nullptr,
+                   c.w.Hd2, SP_DEC_H2, 0)); }
+        TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
+        TRY(nt16(c, c.w.dHd2, SP_DEC_H2, c.w.lin_wt[LIN_DEC1], SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 1, N, SP_DEC_H1, SP_DEC_H2, nullptr, c.w.Hd1, SP_DEC_H1, 0));
+        TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
+        TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
+    } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }
         { ProfScope p2(PS_DEC2_DGRAD, c.s); TRY(bwd_lin(c, LIN_DEC2, per, c.w.dLog, c.w.ld_s, c.w.dHd2, SP_DEC_H2, 0, N, c.w.Hd2, SP_DEC_H2)); }

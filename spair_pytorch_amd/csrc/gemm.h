@@ -9,6 +9,7 @@ struct GemmNT {
     const float* bias;
     const float* mask; int ldmask;
     int relu, accumulate;
+    int c_bf16, mask_bf16;                // gemm16.hip: C stored as bf16; relu mask source is a bf16 tensor
     int sprite_ch;                        // >0: decoder epilogue (models.py:485-492): analytic sigmoid of scaled logits, alpha = last of sprite_ch
     float obj_scale, alpha_scale, alpha_bias;
     ConvDesc conv;
@@ -28,3 +29,7 @@ struct GemmTN {
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);
 int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s);
 int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s);
+// gemm16.hip: bf16-stored operands
+int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s);
+int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s);
+int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows, int cols, hipStream_t s);

@@ -1,0 +1,482 @@
+// bf16-STORED operand GEMMs (bf16 mode only): the backbone activations / gradients and the decoder's hidden
+// activations live in HBM as bf16, so the big GEMMs move half the bytes of gemm.hip's fp32-operand kernels and
+// stage 16-byte (8-element) chunks straight into LDS with no conversion.
+//   gemm_nt16 : C[M,N] = epi(A[M,K] . B[N,K]^T), A bf16 row-major or an NHWC conv gather (ConvDesc), B bf16 weights,
+//               C bf16 or fp32.  128x128x64 tiles, 4 waves (2x2, 64x64 each), LDS double-buffered: ONE barrier per
+//               K-tile, the next tile's global loads are in flight during the 32 MFMAs of the current one.
+//   gemm_tn16 : C[M,N] += sum_r A[r,M] . B[r,N] (weight gradients), A bf16, B bf16 (plain / conv gather) or fp32 gather
+//               (first layer, Cin = image channels); operands staged row-major, fragments through ds_read_b64_tr_b16;
+//               split over r with fp32 atomics; optional fused column sums of A (bias gradient); XCD-aware tile order.
+#include "common.h"
+#include "gemm.h"
+
+struct ConvRow16 { int b, y, x; };
+struct ConvTap16 { int ky, kx, ci; };
+
+__device__ __forceinline__ void crow_init(const ConvDesc& c, int m, ConvRow16& r) {
+    const int hw = c.Hout * c.Wout;
+    r.b = m / hw;
+    const int rem = m - r.b * hw;
+    r.y = rem / c.Wout;
+    r.x = rem - r.y * c.Wout;
+}
+__device__ __forceinline__ void crow_advance(const ConvDesc& c, ConvRow16& r, int step) {
+    r.x += step;
+    while (r.x >= c.Wout) { r.x -= c.Wout; ++r.y; }
+    while (r.y >= c.Hout) { r.y -= c.Hout; ++r.b; }
+}
+__device__ __forceinline__ void ctap_init(const ConvDesc& c, int k, ConvTap16& t) {
+    const int tap = k / c.Cin;
+    t.ci = k - tap * c.Cin;
+    t.ky = tap / c.kw;
+    t.kx = tap - t.ky * c.kw;
+}
+__device__ __forceinline__ void ctap_advance(const ConvDesc& c, ConvTap16& t, int step) {
+    t.ci += step;
+    while (t.ci >= c.Cin) {
+        t.ci -= c.Cin;
+        if (++t.kx == c.kw) { t.kx = 0; ++t.ky; }
+    }
+}
+// 8 consecutive k-elements of one tap (Cin % 8 == 0) of a bf16 NHWC tensor, zero outside
+__device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const ConvDesc& c, const ConvRow16& r, const ConvTap16& t) {
+    const int sy = r.y * c.sy + c.oy + t.ky * c.dky;
+    const int sx = r.x * c.sx + c.ox + t.kx * c.dkx;
+    if (sy < 0 || sy >= c.Hin || sx < 0 || sx >= c.Win) return make_uint4(0u, 0u, 0u, 0u);
+    const size_t off = (((size_t)r.b * c.Hin + sy) * c.Win + sx) * c.Cin + t.ci;
+    return *reinterpret_cast<const uint4*>(In + off);
+}
+
+__device__ __forceinline__ float bf16_bits_to_float(u16 v) { return __uint_as_float(((unsigned int)v) << 16); }
+
+template <bool ACONV, bool C16>
+__global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
+    constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
+    constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
+    constexpr int NA = BM * (BK / 8) / 256, NB = BN * (BK / 8) / 256;   // 16-byte chunks per thread: 4 + 4
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    __bf16* As0 = smem;                       // [2][BM*LD]
+    __bf16* Bs0 = smem + 2 * BM * LD;         // [2][BN*LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const u16* A = reinterpret_cast<const u16*>(g.A);
+    const u16* B = reinterpret_cast<const u16*>(g.B);
+
+    // staging coordinates: chunk f = tid + i*256 -> row f/8, k-chunk f%8 (the same k-chunk for all of a thread's chunks)
+    const int kq = tid & 7;
+    ConvRow16 a_cr[NA];
+    ConvTap16 a_ct;
+    bool a_ok[NA], b_ok[NB];
+    a_ct.ky = a_ct.kx = a_ct.ci = 0;
+    if (ACONV) ctap_init(g.conv, kq * 8, a_ct);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + i * 32;
+        a_ok[i] = (m0 + row) < g.M;
+        a_cr[i].b = a_cr[i].y = a_cr[i].x = 0;
+        if (ACONV && a_ok[i]) crow_init(g.conv, m0 + row, a_cr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + (tid >> 3) + i * 32) < g.N;
+
+    uint4 ra[NA], rb[NB];
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + kq * 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (tid >> 3) + i * 32;
+            if (a_ok[i] && k < g.K) {
+                if (ACONV) ra[i] = conv_load8(A, g.conv, a_cr[i], a_ct);
+                else ra[i] = *reinterpret_cast<const uint4*>(A + (size_t)(m0 + row) * g.lda + k);
+            } else {
+                ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (ACONV) ctap_advance(g.conv, a_ct, BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (tid >> 3) + i * 32;
+            rb[i] = (b_ok[i] && k < g.K) ? *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * g.ldb + k) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        __bf16* As = As0 + buf * BM * LD;
+        __bf16* Bs = Bs0 + buf * BN * LD;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[((tid >> 3) + i * 32) * LD + kq * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + i * 32) * LD + kq * 8]) = rb[i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) load_tiles((kt + 1) * BK);
+        const __bf16* As = As0 + (kt & 1) * BM * LD;
+        const __bf16* Bs = Bs0 + (kt & 1) * BN * LD;
+        const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + ks * 32 + kg]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + ks * 32 + kg]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles((kt + 1) & 1);   // the other buffer: last read one iteration ago, behind the previous barrier
+        __syncthreads();
+    }
+
+    // epilogue
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + rgrp + r;
+            if (m >= g.M) continue;
+            size_t crow;
+            if (g.use_cmap) {
+                const int hw = g.cmap.Hout * g.cmap.Wout;
+                const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
+                crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + g.cmap.ooy)) * g.cmap.Wc + (x * g.cmap.osx + g.cmap.oox);
+            } else {
+                crow = (size_t)m;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n >= g.N) continue;
+                float v = acc[i][j][r];
+                if (g.bias) v += g.bias[n];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) {
+                    bool on;
+                    if (g.mask_bf16) {
+                        const u16 h = reinterpret_cast<const u16*>(g.mask)[crow * g.ldmask + n];
+                        on = (h & 0x8000u) == 0 && (h & 0x7fffu) != 0;      // bf16 value > 0
+                    } else {
+                        on = g.mask[crow * g.ldmask + n] > 0.f;
+                    }
+                    v = on ? v : 0.f;
+                }
+                if (g.sprite_ch > 0) {
+                    const float t = ((n % g.sprite_ch) == g.sprite_ch - 1) ? v * g.alpha_scale + g.alpha_bias : v * g.obj_scale;
+                    v = 1.f / (expf(-t) + 1.f);
+                }
+                if (C16) reinterpret_cast<__bf16*>(g.C)[crow * g.ldc + n] = (__bf16)v;
+                else g.C[crow * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return SPAIR_ERR_SHAPE;
+    if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldb & 7)) return SPAIR_ERR_ALIGN;
+    if (conv && (g.conv.Cin & 7)) return SPAIR_ERR_ALIGN;
+    if (g.accumulate) return SPAIR_ERR_UNSUPPORTED;
+    constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
+    dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128));
+#define NT16_LAUNCH(AC, C16)                                                                                     \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16>), grid, dim3(256), lds, s, g);                              \
+    } while (0)
+    if (conv) { if (g.c_bf16) NT16_LAUNCH(true, true); else NT16_LAUNCH(true, false); }
+    else { if (g.c_bf16) NT16_LAUNCH(false, true); else NT16_LAUNCH(false, false); }
+#undef NT16_LAUNCH
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN (weight gradients) with bf16-stored A (and B)
+// ---------------------------------------------------------------------------------------------
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const __bf16* a0 = tile + (8 * g + q) * ld + c0 + 4 * p;
+    const __bf16* a1 = a0 + 4 * ld;
+    const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a0));
+    const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a1));
+    union { struct { v4s16_t lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+// B16: B is bf16 (plain rows or conv gather with Cin % 8 == 0); otherwise B is an fp32 conv gather (any Cin, scalar loads)
+template <bool BCONV, bool B16>
+__global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
+    constexpr int BM = 128, BN = 128, BK = 32, LDA = BM + 8, LDB = BN + 8;
+    constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
+    constexpr int NA = BK * (BM / 8) / 256;        // 2 chunks of 8 per thread
+    constexpr int NB16 = BK * (BN / 8) / 256;      // 2
+    constexpr int NB32 = BK * (BN / 4) / 256;      // 4 (fp32 gather, 4 elements per chunk)
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt_, nt_, sp_;
+    {
+        const int id = blockIdx.x, ntm = g.tiles_m, ntn = g.tiles_n;
+        if ((g.nsplit & 7) == 0) {   // XCD-aware: all tiles of one row split on one XCD (see gemm.hip)
+            const int xcd = id & 7, j = id >> 3;
+            mt_ = j % ntm; nt_ = (j / ntm) % ntn; sp_ = (j / (ntm * ntn)) * 8 + xcd;
+        } else {
+            mt_ = id % ntm; nt_ = (id / ntm) % ntn; sp_ = id / (ntm * ntn);
+        }
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int r_begin = sp_ * g.rows_per_split;
+    const int r_end = min(g.R, r_begin + g.rows_per_split);
+    const u16* A = reinterpret_cast<const u16*>(g.A);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // A chunks: f = tid + i*256 -> row kr = f / 16, column chunk mq = f % 16 (fixed per thread)
+    const int a_mq = tid & 15;
+    uint4 ra[NA];
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    const bool do_colsum = g.colsum_out != nullptr && nt_ == 0;
+    // B chunks
+    constexpr int NB = B16 ? NB16 : NB32;
+    uint4 rb16[NB16];
+    float4 rb32[NB32];
+    ConvRow16 b_cr[NB];
+    int b_tapoff[NB][4];
+    bool b_vec = true;
+    if (BCONV) {
+        b_vec = B16 ? true : (g.conv.Cin & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256;
+            const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
+            const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
+            crow_init(g.conv, min(r_begin + kr, g.R - 1), b_cr[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ConvTap16 t;
+                ctap_init(g.conv, min(n0 + nq * (B16 ? 8 : 4) + e, g.N - 1), t);
+                b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
+            }
+        }
+    }
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int kr = (tid >> 4) + i * 16;
+            const int r = r0 + kr, m = m0 + a_mq * 8;
+            ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const uint4*>(A + (size_t)r * g.lda + m) : make_uint4(0u, 0u, 0u, 0u);
+            if (do_colsum) {
+                const u16* h = reinterpret_cast<const u16*>(&ra[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += bf16_bits_to_float(h[e]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256;
+            const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
+            const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
+            const int r = r0 + kr, n = n0 + nq * (B16 ? 8 : 4);
+            const bool ok = r < r_end && n < g.N;
+            if constexpr (B16) {
+                const u16* Bp = reinterpret_cast<const u16*>(g.B);
+                if (!ok) rb16[i] = make_uint4(0u, 0u, 0u, 0u);
+                else if (BCONV) {
+                    const size_t base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
+                    rb16[i] = *reinterpret_cast<const uint4*>(Bp + base + b_tapoff[i][0]);
+                } else {
+                    rb16[i] = *reinterpret_cast<const uint4*>(Bp + (size_t)r * g.ldb + n);
+                }
+            } else {
+                const float* Bp = g.B;
+                if (!ok) rb32[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (BCONV) {
+                    const size_t base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
+                    if (b_vec) rb32[i] = *reinterpret_cast<const float4*>(Bp + base + b_tapoff[i][0]);
+                    else rb32[i] = make_float4(Bp[base + b_tapoff[i][0]], Bp[base + b_tapoff[i][1]], Bp[base + b_tapoff[i][2]], Bp[base + b_tapoff[i][3]]);
+                } else {
+                    rb32[i] = *reinterpret_cast<const float4*>(Bp + (size_t)r * g.ldb + n);
+                }
+            }
+            if (BCONV) crow_advance(g.conv, b_cr[i], BK);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[buf][((tid >> 4) + i * 16) * LDA + a_mq * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256;
+            if constexpr (B16) {
+                const int kr = f / (BN / 8), nq = f % (BN / 8);
+                *reinterpret_cast<uint4*>(&Bs[buf][kr * LDB + nq * 8]) = rb16[i];
+            } else {
+                const int kr = f / (BN / 4), nq = f % (BN / 4);
+                bf16x4 v;
+                v[0] = (__bf16)rb32[i].x; v[1] = (__bf16)rb32[i].y; v[2] = (__bf16)rb32[i].z; v[3] = (__bf16)rb32[i].w;
+                *reinterpret_cast<bf16x4*>(&Bs[buf][kr * LDB + nq * 4]) = v;
+            }
+        }
+    };
+
+    if (r_begin < r_end) {
+        load_tiles(r_begin);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+            const bool more = (r0 + BK) < r_end;
+            if (more) load_tiles(r0 + BK);
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_tr_frag16(As[buf], LDA, wm * WM + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = lds_tr_frag16(Bs[buf], LDB, wn * WN + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    if (do_colsum) {   // bias gradient: column sums of A over this block's rows, reduced in LDS, one atomic per column
+        __syncthreads();
+        float* scr = reinterpret_cast<float*>(&As[0][0]);      // 16 row groups x 128 columns of fp32 = 8 KB
+        const int grp = tid >> 4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) scr[grp * BM + a_mq * 8 + e] = csum[e];
+        __syncthreads();
+        for (int m = tid; m < BM; m += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += scr[q * BM + m];
+            if (m0 + m < g.Mstore) atomicAdd(&g.colsum_out[m0 + m], t);
+        }
+    }
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + rgrp + r;
+            if (m >= g.Mstore) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n >= g.Nstore) continue;
+                int nc = n;
+                if (g.cw_cin > 0) { const int tap = n / g.cw_cin, ci = n - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
+                atomicAdd(&g.C[(size_t)m * g.ldc + nc], acc[i][j][r]);
+            }
+        }
+}
+
+// A bf16 [R][lda]; B: bf16 (b_bf16) plain rows / conv gather, or fp32 conv gather / plain rows
+int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
+    if (g.Mstore <= 0) g.Mstore = g.M;
+    if (g.Nstore <= 0) g.Nstore = g.N;
+    if ((g.lda & 7) || (g.M & 7)) return SPAIR_ERR_ALIGN;
+    if (b_bf16 && ((g.N & 7) || (!conv && (g.ldb & 7)) || (conv && (g.conv.Cin & 7)))) return SPAIR_ERR_ALIGN;
+    if (!b_bf16 && ((g.N & 3) || (!conv && (g.ldb & 3)))) return SPAIR_ERR_ALIGN;
+    constexpr int BM = 128, BN = 128;
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    int nsplit = max(1, min(ceil_div(g.R, 512), ceil_div(1024, tiles)));
+    if (nsplit >= 8) nsplit = nsplit / 8 * 8;
+    int rps = round_up(ceil_div(g.R, nsplit), 32);
+    if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
+    g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
+    dim3 grid(g.tiles_m * g.tiles_n * nsplit);
+    if (conv) {
+        if (b_bf16) hipLaunchKernelGGL((gemm_tn16_kernel<true, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn16_kernel<true, false>), grid, dim3(256), 0, s, g);
+    } else {
+        if (b_bf16) hipLaunchKernelGGL((gemm_tn16_kernel<false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn16_kernel<false, false>), grid, dim3(256), 0, s, g);
+    }
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// fp32 -> bf16 row-major copy with leading dimensions (d feat for the backbone's backward pass)
+__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd, long long rows, int cols) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const long long r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    dst[r * ldd + c] = (__bf16)src[r * lds_ + c];
+}
+int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows, int cols, hipStream_t s) {
+    const long long n = rows * cols;
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds_, reinterpret_cast<__bf16*>(dst), ldd, rows, cols);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// ---- unit-level C ABI (bf16 tensors are passed as opaque device pointers) --------------------------------------------------
+extern "C" int spair_gemm_nt16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                               const void* relu_mask, int ldmask, int mask_bf16, int relu, int c_bf16, const int* conv13, const int* cmap8,
+                               void* stream) {
+    GemmNT g{};
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = B; g.ldb = ldb; g.C = reinterpret_cast<float*>(C); g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.mask = reinterpret_cast<const float*>(relu_mask); g.ldmask = ldmask; g.mask_bf16 = mask_bf16;
+    g.relu = relu; g.c_bf16 = c_bf16;
+    if (conv13) {
+        const int* p = conv13;
+        g.conv.Hin = p[0]; g.conv.Win = p[1]; g.conv.Cin = p[2]; g.conv.Hout = p[3]; g.conv.Wout = p[4]; g.conv.kh = p[5]; g.conv.kw = p[6];
+        g.conv.sy = p[7]; g.conv.sx = p[8]; g.conv.dky = p[9]; g.conv.dkx = p[10]; g.conv.oy = p[11]; g.conv.ox = p[12];
+    }
+    if (cmap8) {
+        g.use_cmap = 1;
+        g.cmap.Hout = cmap8[0]; g.cmap.Wout = cmap8[1]; g.cmap.Hc = cmap8[2]; g.cmap.Wc = cmap8[3];
+        g.cmap.osy = cmap8[4]; g.cmap.osx = cmap8[5]; g.cmap.ooy = cmap8[6]; g.cmap.oox = cmap8[7];
+    }
+    return spair_gemm_nt16_impl(g, conv13 != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int spair_gemm_tn16(const void* A, int lda, const void* B, int ldb, int b_bf16, float* C, int ldc, int M, int N, int R,
+                               const int* conv13, int cw_cin, int cw_taps, float* colsum_out, void* stream) {
+    GemmTN g{};
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = reinterpret_cast<const float*>(B); g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = round_up(M, 8); g.N = round_up(N, b_bf16 ? 8 : 4); g.Mstore = M; g.Nstore = N; g.R = R; g.cw_cin = cw_cin; g.cw_taps = cw_taps;
+    g.colsum_out = colsum_out;
+    if (conv13) {
+        const int* p = conv13;
+        g.conv.Hin = p[0]; g.conv.Win = p[1]; g.conv.Cin = p[2]; g.conv.Hout = p[3]; g.conv.Wout = p[4]; g.conv.kh = p[5]; g.conv.kw = p[6];
+        g.conv.sy = p[7]; g.conv.sx = p[8]; g.conv.dky = p[9]; g.conv.dkx = p[10]; g.conv.oy = p[11]; g.conv.ox = p[12];
+    }
+    return spair_gemm_tn16_impl(g, conv13 != nullptr, b_bf16 != 0, (hipStream_t)stream);
+}

@@ -168,7 +168,7 @@ int misc_export(const float* src, int ld, int col0, int ch, const int* cell_h, c
 // ---- backbone layer 0 (Cin = C, tiny K = k*k*C): direct kernels -------------------------------------
 // forward: out[m][co] = relu(bias[co] + sum_k w[co][k] * patch(m)[k]); weights in LDS; thread = (pixel, 4 channels)
 __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ xp, const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ out, int B, int Hin, int C, int k, int s, int Hout, int Cout) {
+                                                   float* __restrict__ out, int B, int Hin, int C, int k, int s, int Hout, int Cout, int out_bf16) {
     extern __shared__ float wsh[];   // [K0][Cout] transposed for conflict-free float4 reads
     const int K0 = k * k * C;
     for (int i = threadIdx.x; i < K0 * Cout; i += blockDim.x) {
@@ -193,17 +193,23 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ xp,
             }
         }
         acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-        *reinterpret_cast<float4*>(out + (size_t)m * Cout + cq * 4) = acc;
+        if (out_bf16) {
+            bf16x4 o;
+            o[0] = (__bf16)acc.x; o[1] = (__bf16)acc.y; o[2] = (__bf16)acc.z; o[3] = (__bf16)acc.w;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (size_t)m * Cout + cq * 4) = o;
+        } else {
+            *reinterpret_cast<float4*>(out + (size_t)m * Cout + cq * 4) = acc;
+        }
     }
 }
 int misc_conv0_fwd(const float* xp, const float* w, const float* bias, float* out, int B, int Hin, int C, int k, int s, int Hout,
-                   int Cout, hipStream_t st) {
+                   int Cout, int out_bf16, hipStream_t st) {
     if (Cout % 4) return SPAIR_ERR_ALIGN;
     const size_t lds = (size_t)k * k * C * Cout * sizeof(float);
     if (lds > 64 * 1024) return SPAIR_ERR_UNSUPPORTED;
     const long long total = (long long)B * Hout * Hout * (Cout / 4);
     const unsigned grid = (unsigned)min((long long)4096, (total + 255) / 256);
-    hipLaunchKernelGGL(k_conv0_fwd, dim3(grid), dim3(256), lds, st, xp, w, bias, out, B, Hin, C, k, s, Hout, Cout);
+    hipLaunchKernelGGL(k_conv0_fwd, dim3(grid), dim3(256), lds, st, xp, w, bias, out, B, Hin, C, k, s, Hout, Cout, out_bf16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

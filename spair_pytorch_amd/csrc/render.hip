@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_render_bwd(const float* __res
                                                               const float4* __restrict__ aux, const float* __restrict__ gloss,
                                                               float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
                                                               float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
-                                                              float obj_scale, float alpha_scale) {
+                                                              float obj_scale, float alpha_scale, int g_bf16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int PP2 = P * P * 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -267,7 +267,13 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_render_bwd(const float* __res
             o.y = dv.y * sv.y * (1.f - sv.y) * alpha_scale;
             o.z = dv.z * sv.z * (1.f - sv.z) * obj_scale;
             o.w = dv.w * sv.w * (1.f - sv.w) * alpha_scale;
-            *reinterpret_cast<float4*>(dlogits + (size_t)r * ld_g + e) = o;
+            if (g_bf16) {
+                bf16x4 ob;
+                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dlogits) + (size_t)r * ld_g + e) = ob;
+            } else {
+                *reinterpret_cast<float4*>(dlogits + (size_t)r * ld_g + e) = o;
+            }
         }
     }
 }
@@ -297,14 +303,14 @@ int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, c
 
 int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I,
-               int P, int ac, float obj_scale, float alpha_scale, hipStream_t s) {
+               int P, int ac, float obj_scale, float alpha_scale, int g_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if ((P * P * 2) % 4 || (ld_s & 3) || (ld_g & 3)) return SPAIR_ERR_ALIGN;
     const size_t lds = (size_t)RB_WAVES * P * P * 2 * 2 * sizeof(float);
     const int kgroups = (HW + RB_WAVES - 1) / RB_WAVES;
     hipLaunchKernelGGL(k_render_bwd, dim3(B * kgroups), dim3(64 * RB_WAVES), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
                        reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
-                       alpha_scale);
+                       alpha_scale, g_bf16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
@@ -320,5 +326,5 @@ extern "C" int spair_render_bwd(const float* sprites, int ld_s, const float* nbo
                                 float* ddepth, int B, int HW, int C, int I, int P, int align_corners, float obj_scale,
                                 float alpha_scale, void* stream) {
     return render_bwd(sprites, ld_s, nbox, pres, depth, 1, aux, grad_loss, dlogits, dnbox, dpres, ddepth, ld_s, B, HW, C, I, P,
-                      align_corners, obj_scale, alpha_scale, (hipStream_t)stream);
+                      align_corners, obj_scale, alpha_scale, 0, (hipStream_t)stream);
 }

@@ -133,3 +133,89 @@ def test_conv_fwd_dgrad_wgrad(dtype, B, Hin, Cin, Cout, k, s):
                     L.check(rc, "conv dgrad")
             ref_dx = xr.grad.permute(0, 2, 3, 1)
             assert (dX.cpu() - ref_dx).abs().max() <= 5e-5 * ref_dx.abs().max()
+
+
+# ---- bf16-stored operand kernels (gemm16.hip) -----------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,c16", [(300, 100, 128, 1), (9000, 256, 784 + 8, 0), (65536 // 8, 1568, 256, 0), (4096, 128, 2048, 1)])
+def test_gemm_nt16_plain(M, N, K, c16):
+    L = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)).cuda()
+    W = _bf(torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Y = _bf(torch.randn(M, N, generator=g)).cuda()
+    ldc = (N + 7) // 8 * 8
+    C = torch.zeros(M, ldc, device="cuda", dtype=torch.bfloat16 if c16 else torch.float32)
+    rc = L.lib().spair_gemm_nt16(L.ptr(A), K, L.ptr(W), K, L.ptr(C), ldc, M, N, K, L.ptr(bias), L.ptr(Y), N, 1, 1, c16, None, None, L.stream())
+    L.check(rc, "nt16")
+    ref = torch.relu(A.float().cpu() @ W.float().cpu().t() + bias.cpu()) * (Y.float().cpu() > 0)
+    got = C.float().cpu()[:, :N]
+    tol = 1.2e-2 if c16 else 2e-3
+    assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Hin,Cin,Cout,k,s", [(3, 34, 128, 128, 4, 2), (5, 22, 8, 40, 4, 2)])
+def test_conv16_fwd_dgrad_wgrad(B, Hin, Cin, Cout, k, s):
+    L = _lib()
+    g = torch.Generator().manual_seed(B + Hin + Cin)
+    x = _bf(torch.randn(B, Cin, Hin, Hin, generator=g)).float()
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).float()
+    bias = torch.randn(Cout, generator=g)
+    Hout = (Hin - k) // s + 1
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, bias, stride=s))
+    x16 = _bf(x.permute(0, 2, 3, 1)).cuda()
+    K = k * k * Cin
+    w16 = _bf(w.permute(0, 2, 3, 1).reshape(Cout, K)).cuda()
+    M = B * Hout * Hout
+    out = torch.zeros(M, Cout, device="cuda", dtype=torch.bfloat16)
+    conv = _i(Hin, Hin, Cin, Hout, Hout, k, k, s, s, 1, 1, 0, 0)
+    bias_d = bias.cuda()
+    L.check(L.lib().spair_gemm_nt16(L.ptr(x16), 0, L.ptr(w16), K, L.ptr(out), Cout, M, Cout, K, L.ptr(bias_d), None, 0, 0, 1, 1, conv, None, L.stream()), "conv16 fwd")
+    got = out.float().cpu().view(B, Hout, Hout, Cout).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() <= 1.2e-2 * max(1.0, ref.abs().max().item())
+    # weight gradient: A = dOut bf16, B = conv gather of x (bf16), fused bias gradient
+    go = _bf(torch.randn(B, Cout, Hout, Hout, generator=g)).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, None, stride=s).backward(go)
+    go16 = _bf(go.permute(0, 2, 3, 1).reshape(M, Cout)).cuda()
+    dW = torch.zeros(Cout, Cin, k, k, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x16), 0, 1, L.ptr(dW), K, Cout, K, M, conv, Cin, k * k, L.ptr(db), L.stream()), "conv16 wgrad")
+    assert (dW.cpu() - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
+    assert (db.cpu() - go.sum((0, 2, 3))).abs().max() <= 2e-3 * go.sum((0, 2, 3)).abs().max() + 1e-3
+    # fp32 gather for B (first backbone layer style): same result
+    x32 = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dW2 = torch.zeros(Cout, Cin, k, k, device="cuda")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x32), 0, 0, L.ptr(dW2), K, Cout, K, M, conv, Cin, k * k, None, L.stream()), "conv16 wgrad f32 B")
+    assert (dW2.cpu() - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
+    # data gradient by output-parity classes with relu mask and row remap
+    if k == 4 and s == 2:
+        mask = _bf(torch.randn(B, Hin, Hin, Cin, generator=g)).cuda()
+        dX = torch.zeros(B, Hin, Hin, Cin, device="cuda", dtype=torch.bfloat16)
+        for py in range(2):
+            for px in range(2):
+                wc = _bf(w[:, :, py::2, px::2].permute(1, 2, 3, 0).reshape(Cin, 4 * Cout)).cuda()
+                Hc, Wc = (Hin - py + 1) // 2, (Hin - px + 1) // 2
+                cd = _i(Hout, Hout, Cout, Hc, Wc, 2, 2, 1, 1, -1, -1, 0, 0)
+                cm = _i(Hc, Wc, Hin, Hin, 2, 2, py, px)
+                L.check(L.lib().spair_gemm_nt16(L.ptr(go16), 0, L.ptr(wc), 4 * Cout, L.ptr(dX), Cin, B * Hc * Wc, Cin, 4 * Cout, None,
+                                                L.ptr(mask), Cin, 1, 0, 1, cd, cm, L.stream()), "conv16 dgrad")
+        ref_dx = xr.grad.permute(0, 2, 3, 1) * (mask.float().cpu() > 0)
+        assert (dX.float().cpu() - ref_dx).abs().max() <= 1.2e-2 * ref_dx.abs().max()
+
+
+def test_gemm_tn16_plain():
+    L = _lib()
+    g = torch.Generator().manual_seed(5)
+    R, M, N = 5000, 1568, 256
+    A, B = _bf(torch.randn(R, M, generator=g)).cuda(), _bf(torch.randn(R, N, generator=g)).cuda()
+    C = torch.zeros(M, N, device="cuda")
+    cs = torch.zeros(M, device="cuda")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(A), M, L.ptr(B), N, 1, L.ptr(C), N, M, N, R, None, 0, 0, L.ptr(cs), L.stream()), "tn16")
+    ref = A.float().cpu().double().t() @ B.float().cpu().double()
+    assert (C.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert (cs.cpu().double() - A.float().cpu().double().sum(0)).abs().max() <= 1e-4 * A.float().cpu().double().sum(0).abs().max() + 1e-3

@@ -59,5 +59,35 @@ def main():
     print("decoder.out fwd NT [65536x256]x[1568x256]: %.3f ms  %.1f TFLOP/s" % (t, 2.0 * N * Nd * Kd / t / 1e9))
 
 
+def main16():
+    lib = L.lib()
+    B, Hin, Cin, Cout, k, s = 256, 70, 128, 128, 4, 2
+    Hout = (Hin - k) // s + 1
+    M = B * Hout * Hout
+    K = k * k * Cin
+    x = torch.randn(B, Hin, Hin, Cin, device="cuda").to(torch.bfloat16)
+    go = torch.randn(M, Cout, device="cuda").to(torch.bfloat16)
+    dW = torch.zeros(Cout, K, device="cuda")
+    conv = _i(Hin, Hin, Cin, Hout, Hout, k, k, s, s, 1, 1, 0, 0)
+    t = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(go), Cout, L.ptr(x), 0, 1, L.ptr(dW), K, Cout, K, M, conv, Cin, k * k, None, L.stream()), "tn16"))
+    print("conv1 wgrad tn16 (bf16 stored): %.3f ms  %.1f TFLOP/s" % (t, 2.0 * M * Cout * K / t / 1e9))
+    w = (torch.randn(Cout, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    out = torch.zeros(M, Cout, device="cuda", dtype=torch.bfloat16)
+    bias = torch.zeros(Cout, device="cuda")
+    t = timeit(lambda: L.check(lib.spair_gemm_nt16(L.ptr(x), 0, L.ptr(w), K, L.ptr(out), Cout, M, Cout, K, L.ptr(bias), None, 0, 0, 1, 1, conv, None, L.stream()), "nt16"))
+    print("conv1 fwd nt16 (bf16 stored): %.3f ms  %.1f TFLOP/s" % (t, 2.0 * M * Cout * K / t / 1e9))
+    N, Kd, Nd = 65536, 256, 1568
+    Hd = torch.randn(N, Kd, device="cuda").to(torch.bfloat16)
+    Wd = (torch.randn(Nd, Kd, device="cuda") / 16).to(torch.bfloat16)
+    S = torch.zeros(N, Nd, device="cuda")
+    t = timeit(lambda: L.check(lib.spair_gemm_nt16(L.ptr(Hd), Kd, L.ptr(Wd), Kd, L.ptr(S), Nd, N, Nd, Kd, None, None, 0, 0, 0, 0, None, None, L.stream()), "nt16"))
+    print("decoder.out fwd nt16 [65536x256]x[1568x256] -> fp32: %.3f ms  %.1f TFLOP/s" % (t, 2.0 * N * Nd * Kd / t / 1e9))
+    dL = torch.randn(N, Nd, device="cuda").to(torch.bfloat16)
+    dWd = torch.zeros(Nd, Kd, device="cuda")
+    t = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(dL), Nd, L.ptr(Hd), Kd, 1, L.ptr(dWd), Kd, Nd, Kd, N, None, 0, 0, None, L.stream()), "tn16"))
+    print("decoder.out wgrad tn16: %.3f ms  %.1f TFLOP/s" % (t, 2.0 * N * Nd * Kd / t / 1e9))
+
+
 if __name__ == "__main__":
+    main16()
     main()
