@@ -20,10 +20,19 @@ __device__ __forceinline__ void crow_init(const ConvDesc& c, int m, ConvRow16& r
     r.y = rem / c.Wout;
     r.x = rem - r.y * c.Wout;
 }
-__device__ __forceinline__ void crow_advance(const ConvDesc& c, ConvRow16& r, int step) {
+// Branch-free (selects only): a data-dependent loop or `if` between a global load and its use makes hipcc's wait insertion
+// fall back to s_waitcnt vmcnt(0) at the block boundaries, which serialises the software pipeline.  `wraps` = an upper bound
+// on how many output rows one step can cross (ceil(step / Wout) -- computed on the host side of the kernel, wave-uniform).
+__device__ __forceinline__ void crow_advance(const ConvDesc& c, ConvRow16& r, int step, int wraps) {
     r.x += step;
-    while (r.x >= c.Wout) { r.x -= c.Wout; ++r.y; }
-    while (r.y >= c.Hout) { r.y -= c.Hout; ++r.b; }
+    for (int k = 0; k < wraps; ++k) {            // uniform trip count
+        const bool w = r.x >= c.Wout;
+        r.x -= w ? c.Wout : 0;
+        r.y += w ? 1 : 0;
+    }
+    const bool h = r.y >= c.Hout;                // step < Hout*Wout: at most one image boundary per step
+    r.y -= h ? c.Hout : 0;
+    r.b += h ? 1 : 0;
 }
 __device__ __forceinline__ void ctap_init(const ConvDesc& c, int k, ConvTap16& t) {
     const int tap = k / c.Cin;
@@ -31,22 +40,30 @@ __device__ __forceinline__ void ctap_init(const ConvDesc& c, int k, ConvTap16& t
     t.ky = tap / c.kw;
     t.kx = tap - t.ky * c.kw;
 }
-__device__ __forceinline__ void ctap_advance(const ConvDesc& c, ConvTap16& t, int step) {
+__device__ __forceinline__ void ctap_advance(const ConvDesc& c, ConvTap16& t, int step, int wraps) {
     t.ci += step;
-    while (t.ci >= c.Cin) {
-        t.ci -= c.Cin;
-        if (++t.kx == c.kw) { t.kx = 0; ++t.ky; }
+    for (int k = 0; k < wraps; ++k) {            // uniform trip count = ceil(step / Cin)
+        const bool w = t.ci >= c.Cin;
+        t.ci -= w ? c.Cin : 0;
+        t.kx += w ? 1 : 0;
+        const bool v = t.kx >= c.kw;
+        t.kx = v ? 0 : t.kx;
+        t.ky += v ? 1 : 0;
     }
 }
 // 8 consecutive k-elements of one tap (Cin % 8 == 0) of a bf16 NHWC tensor, zero outside
-__device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const ConvDesc& c, const ConvRow16& r, const ConvTap16& t) {
+// `ok` folds the caller's row / k bounds; the load is always issued (clamped in-range address) and zeroed by a select
+__device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const ConvDesc& c, const ConvRow16& r, const ConvTap16& t, bool ok) {
     const int sy = r.y * c.sy + c.oy + t.ky * c.dky;
     const int sx = r.x * c.sx + c.ox + t.kx * c.dkx;
-    if (sy < 0 || sy >= c.Hin || sx < 0 || sx >= c.Win) return make_uint4(0u, 0u, 0u, 0u);
-    const size_t off = (((size_t)r.b * c.Hin + sy) * c.Win + sx) * c.Cin + t.ci;
-    return *reinterpret_cast<const uint4*>(In + off);
+    ok = ok && sy >= 0 && sy < c.Hin && sx >= 0 && sx < c.Win;
+    const int cy = min(max(sy, 0), c.Hin - 1), cx = min(max(sx, 0), c.Win - 1), cc = min(t.ci, c.Cin - 8);
+    const size_t off = (((size_t)r.b * c.Hin + cy) * c.Win + cx) * c.Cin + cc;
+    const uint4 v = *reinterpret_cast<const uint4*>(In + off);
+    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
 }
 
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float bf16_bits_to_float(u16 v) { return __uint_as_float(((unsigned int)v) << 16); }
 
 template <bool ACONV, bool C16>
@@ -76,29 +93,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         const int row = (tid >> 3) + i * 32;
         a_ok[i] = (m0 + row) < g.M;
         a_cr[i].b = a_cr[i].y = a_cr[i].x = 0;
-        if (ACONV && a_ok[i]) crow_init(g.conv, m0 + row, a_cr[i]);
+        if (ACONV) crow_init(g.conv, min(m0 + row, g.M - 1), a_cr[i]);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + (tid >> 3) + i * 32) < g.N;
 
     uint4 ra[NA], rb[NB];
+    const int tap_wraps = ACONV ? ceil_div_dev(BK, g.conv.Cin) : 0;
+    const int Mlast = g.M - 1, Nlast = g.N - 1, Klast = g.K - 8;
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq * 8;
+        const bool kok = k < g.K;
+        const int kc = min(k, Klast);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int row = (tid >> 3) + i * 32;
-            if (a_ok[i] && k < g.K) {
-                if (ACONV) ra[i] = conv_load8(A, g.conv, a_cr[i], a_ct);
-                else ra[i] = *reinterpret_cast<const uint4*>(A + (size_t)(m0 + row) * g.lda + k);
+            if (ACONV) {
+                ra[i] = conv_load8(A, g.conv, a_cr[i], a_ct, a_ok[i] && kok);
             } else {
-                ra[i] = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)min(m0 + row, Mlast) * g.lda + kc);
+                ra[i] = (a_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        if (ACONV) ctap_advance(g.conv, a_ct, BK);
+        if (ACONV) ctap_advance(g.conv, a_ct, BK, tap_wraps);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = (tid >> 3) + i * 32;
-            rb[i] = (b_ok[i] && k < g.K) ? *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * g.ldb + k) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 v = *reinterpret_cast<const uint4*>(B + (size_t)min(n0 + row, Nlast) * g.ldb + kc);
+            rb[i] = (b_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -289,17 +311,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             }
         }
     }
-    auto load_tiles = [&](int r0) {
+    const int row_wraps = BCONV ? ceil_div_dev(BK, g.conv.Wout) : 0;
+    const int Rlast = g.R - 1;
+    auto load_tiles = [&](int r0) {      // every load is issued unconditionally from a clamped address and zeroed by a select
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int kr = (tid >> 4) + i * 16;
             const int r = r0 + kr, m = m0 + a_mq * 8;
-            ra[i] = (r < r_end && m < g.M) ? *reinterpret_cast<const uint4*>(A + (size_t)r * g.lda + m) : make_uint4(0u, 0u, 0u, 0u);
-            if (do_colsum) {
-                const u16* h = reinterpret_cast<const u16*>(&ra[i]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) csum[e] += bf16_bits_to_float(h[e]);
-            }
+            const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)min(r, Rlast) * g.lda + min(m, g.M - 8));
+            ra[i] = (r < r_end && m < g.M) ? v : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -308,32 +328,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
             const int r = r0 + kr, n = n0 + nq * (B16 ? 8 : 4);
             const bool ok = r < r_end && n < g.N;
+            size_t base = 0;
+            if (BCONV) base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
             if constexpr (B16) {
                 const u16* Bp = reinterpret_cast<const u16*>(g.B);
-                if (!ok) rb16[i] = make_uint4(0u, 0u, 0u, 0u);
-                else if (BCONV) {
-                    const size_t base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
-                    rb16[i] = *reinterpret_cast<const uint4*>(Bp + base + b_tapoff[i][0]);
-                } else {
-                    rb16[i] = *reinterpret_cast<const uint4*>(Bp + (size_t)r * g.ldb + n);
-                }
+                const uint4 v = BCONV ? *reinterpret_cast<const uint4*>(Bp + base + b_tapoff[i][0])
+                                      : *reinterpret_cast<const uint4*>(Bp + (size_t)min(r, Rlast) * g.ldb + min(n, g.N - 8));
+                rb16[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             } else {
                 const float* Bp = g.B;
-                if (!ok) rb32[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                else if (BCONV) {
-                    const size_t base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
-                    if (b_vec) rb32[i] = *reinterpret_cast<const float4*>(Bp + base + b_tapoff[i][0]);
-                    else rb32[i] = make_float4(Bp[base + b_tapoff[i][0]], Bp[base + b_tapoff[i][1]], Bp[base + b_tapoff[i][2]], Bp[base + b_tapoff[i][3]]);
+                float4 v;
+                if (BCONV) {
+                    if (b_vec) v = *reinterpret_cast<const float4*>(Bp + base + b_tapoff[i][0]);     // wave-uniform choice
+                    else v = make_float4(Bp[base + b_tapoff[i][0]], Bp[base + b_tapoff[i][1]], Bp[base + b_tapoff[i][2]], Bp[base + b_tapoff[i][3]]);
                 } else {
-                    rb32[i] = *reinterpret_cast<const float4*>(Bp + (size_t)r * g.ldb + n);
+                    v = *reinterpret_cast<const float4*>(Bp + (size_t)min(r, Rlast) * g.ldb + min(n, g.N - 4));
                 }
+                rb32[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (BCONV) crow_advance(g.conv, b_cr[i], BK);
+            if (BCONV) crow_advance(g.conv, b_cr[i], BK, row_wraps);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[buf][((tid >> 4) + i * 16) * LDA + a_mq * 8]) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            *reinterpret_cast<uint4*>(&As[buf][((tid >> 4) + i * 16) * LDA + a_mq * 8]) = ra[i];
+            if (do_colsum) {
+                const u16* h = reinterpret_cast<const u16*>(&ra[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += bf16_bits_to_float(h[e]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
