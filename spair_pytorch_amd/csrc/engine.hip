@@ -510,6 +510,7 @@ static int backbone_fwd(Ctx& c) {
         const int ldc = last ? c.w.ld_feat : cs.cout;
         const ConvDesc cd = fwd_desc(cs);
         if (b16) {   // activations stored as bf16; the feature map handed to the per-cell chain stays fp32
+            ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
             TRY(nt16(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, last ? 0 : 1, M, cs.cout, round_up(K, 8),
                      c.params + cs.b, nullptr, 0, last ? 0 : 1, cs.k == 1 ? nullptr : &cd));
         } else if (cs.k == 1) {

@@ -81,45 +81,76 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     const u16* A = reinterpret_cast<const u16*>(g.A);
     const u16* B = reinterpret_cast<const u16*>(g.B);
 
-    // staging coordinates: chunk f = tid + i*256 -> row f/8, k-chunk f%8 (the same k-chunk for all of a thread's chunks)
+    // staging coordinates: chunk f = tid + i*256 -> row f/8, k-chunk f%8 (the same k-chunk for all of a thread's chunks).
+    // Address arithmetic is the bottleneck of a conv gather if done naively (a 64-bit multiply chain per 16-byte chunk made both
+    // conv kernels VALU-issue bound): every row's element offset is computed ONCE (32-bit), the tap's offset once per K tile, and a
+    // chunk's address is one add.  Tensors must stay below 2^31 elements (checked by the launcher).
     const int kq = tid & 7;
-    ConvRow16 a_cr[NA];
     ConvTap16 a_ct;
+    unsigned a_base[NA];                 // element offset of (b, y*sy+oy, x*sx+ox, 0) (conv) or of row m (plain)
+    int a_y[NA], a_x[NA];                // conv: y*sy+oy, x*sx+ox for the bounds test of data-gradient gathers
     bool a_ok[NA], b_ok[NB];
+    unsigned b_base[NB];
     a_ct.ky = a_ct.kx = a_ct.ci = 0;
     if (ACONV) ctap_init(g.conv, kq * 8, a_ct);
+    const bool need_bounds = ACONV && (g.conv.dky < 0 || g.conv.oy != 0 || g.conv.ox != 0 || g.conv.dkx < 0);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int row = (tid >> 3) + i * 32;
         a_ok[i] = (m0 + row) < g.M;
-        a_cr[i].b = a_cr[i].y = a_cr[i].x = 0;
-        if (ACONV) crow_init(g.conv, min(m0 + row, g.M - 1), a_cr[i]);
+        const int mr = min(m0 + row, g.M - 1);
+        a_y[i] = a_x[i] = 0;
+        if (ACONV) {
+            ConvRow16 cr;
+            crow_init(g.conv, mr, cr);
+            a_y[i] = cr.y * g.conv.sy + g.conv.oy;
+            a_x[i] = cr.x * g.conv.sx + g.conv.ox;
+            a_base[i] = (unsigned)(((cr.b * g.conv.Hin + a_y[i]) * g.conv.Win + a_x[i]) * g.conv.Cin);   // may wrap for negative taps: fixed by tapoff
+        } else {
+            a_base[i] = (unsigned)mr * (unsigned)g.lda;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + (tid >> 3) + i * 32) < g.N;
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid >> 3) + i * 32;
+        b_ok[i] = (n0 + row) < g.N;
+        b_base[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldb;
+    }
 
     uint4 ra[NA], rb[NB];
     const int tap_wraps = ACONV ? ceil_div_dev(BK, g.conv.Cin) : 0;
-    const int Mlast = g.M - 1, Nlast = g.N - 1, Klast = g.K - 8;
+    const int Klast = g.K - 8;
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq * 8;
         const bool kok = k < g.K;
-        const int kc = min(k, Klast);
+        const unsigned kc = (unsigned)min(k, Klast);
+        if (ACONV) {
+            const int dy = a_ct.ky * g.conv.dky, dx = a_ct.kx * g.conv.dkx;
+            const unsigned tapoff = (unsigned)((dy * g.conv.Win + dx) * g.conv.Cin + min(a_ct.ci, g.conv.Cin - 8));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = (tid >> 3) + i * 32;
-            if (ACONV) {
-                ra[i] = conv_load8(A, g.conv, a_cr[i], a_ct, a_ok[i] && kok);
-            } else {
-                const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)min(m0 + row, Mlast) * g.lda + kc);
+            for (int i = 0; i < NA; ++i) {
+                bool ok = a_ok[i] && kok;
+                unsigned off = a_base[i] + tapoff;
+                if (need_bounds) {      // wave-uniform: forward-geometry gathers never leave the tensor
+                    const int sy = a_y[i] + dy, sx = a_x[i] + dx;
+                    const bool in = sy >= 0 && sy < g.conv.Hin && sx >= 0 && sx < g.conv.Win;
+                    ok = ok && in;
+                    off = in ? off : 0u;
+                }
+                const uint4 v = *reinterpret_cast<const uint4*>(A + off);
+                ra[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+            ctap_advance(g.conv, a_ct, BK, tap_wraps);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (a_base[i] + kc));
                 ra[i] = (a_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        if (ACONV) ctap_advance(g.conv, a_ct, BK, tap_wraps);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int row = (tid >> 3) + i * 32;
-            const uint4 v = *reinterpret_cast<const uint4*>(B + (size_t)min(n0 + row, Nlast) * g.ldb + kc);
+            const uint4 v = *reinterpret_cast<const uint4*>(B + (b_base[i] + kc));
             rb[i] = (b_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -145,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
         if (more) load_tiles((kt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);      // loads issued here; nothing that consumes them may move above the MFMAs
         const __bf16* As = As0 + (kt & 1) * BM * LD;
         const __bf16* Bs = Bs0 + (kt & 1) * BN * LD;
         const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = (lane >> 4) * 8;
@@ -161,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) store_tiles((kt + 1) & 1);   // the other buffer: last read one iteration ago, behind the previous barrier
         __syncthreads();
     }
@@ -214,6 +247,8 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldb & 7)) return SPAIR_ERR_ALIGN;
     if (conv && (g.conv.Cin & 7)) return SPAIR_ERR_ALIGN;
     if (g.accumulate) return SPAIR_ERR_UNSUPPORTED;
+    if (!conv && (long long)g.M * g.lda >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;   // 32-bit element offsets
+    if ((long long)g.N * g.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128));
 #define NT16_LAUNCH(AC, C16)                                                                                     \
@@ -292,69 +327,104 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
     constexpr int NB = B16 ? NB16 : NB32;
     uint4 rb16[NB16];
     float4 rb32[NB32];
-    ConvRow16 b_cr[NB];
+    // Running 32-bit element offsets (see gemm_nt16): A advances by BK rows per tile; a conv-gathered B row (b,y,x) advances by BK
+    // output pixels with branch-free row / image wraps whose offset deltas are wave-uniform constants.
+    int b_x[NB], b_y[NB];
+    unsigned b_off[NB];
     int b_tapoff[NB][4];
+    bool b_nok[NB];
     bool b_vec = true;
-    if (BCONV) {
-        b_vec = B16 ? true : (g.conv.Cin & 3) == 0;
+    unsigned a_off[NA];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * 256;
-            const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
-            const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
-            crow_init(g.conv, min(r_begin + kr, g.R - 1), b_cr[i]);
+    for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(r_begin + (tid >> 4) + i * 16) * (unsigned)g.lda + (unsigned)min(m0 + a_mq * 8, g.M - 8);
+    const bool a_mok = (m0 + a_mq * 8) < g.M;
+    const unsigned a_last = (unsigned)(g.R - 1) * (unsigned)g.lda + (unsigned)min(m0 + a_mq * 8, g.M - 8);
+    const int row_wraps = BCONV ? ceil_div_dev(BK, g.conv.Wout) : 0;
+    const int d_step = BCONV ? BK * g.conv.sx * g.conv.Cin : BK * g.ldb;                                  // x += BK
+    const int d_row = BCONV ? (g.conv.sy * g.conv.Win - g.conv.Wout * g.conv.sx) * g.conv.Cin : 0;      // x -= Wout, y += 1
+    const int d_img = BCONV ? (g.conv.Hin - g.conv.Hout * g.conv.sy) * g.conv.Win * g.conv.Cin : 0;     // y -= Hout, b += 1
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + i * 256;
+        const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
+        const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
+        const int n = n0 + nq * (B16 ? 8 : 4);
+        b_nok[i] = n < g.N;
+        b_x[i] = b_y[i] = 0;
+        if (BCONV) {
+            b_vec = B16 ? true : (g.conv.Cin & 3) == 0;
+            ConvRow16 cr;
+            crow_init(g.conv, min(r_begin + kr, g.R - 1), cr);
+            b_x[i] = cr.x; b_y[i] = cr.y;
+            b_off[i] = (unsigned)(((cr.b * g.conv.Hin + cr.y * g.conv.sy + g.conv.oy) * g.conv.Win + cr.x * g.conv.sx + g.conv.ox) * g.conv.Cin);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ConvTap16 t;
-                ctap_init(g.conv, min(n0 + nq * (B16 ? 8 : 4) + e, g.N - 1), t);
+                ctap_init(g.conv, min(n + e, g.N - 1), t);
                 b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
             }
+        } else {
+            b_off[i] = (unsigned)(r_begin + kr) * (unsigned)g.ldb + (unsigned)min(n, g.N - (B16 ? 8 : 4));
+            b_tapoff[i][0] = b_tapoff[i][1] = b_tapoff[i][2] = b_tapoff[i][3] = 0;
         }
     }
-    const int row_wraps = BCONV ? ceil_div_dev(BK, g.conv.Wout) : 0;
-    const int Rlast = g.R - 1;
+    const unsigned b_lastrow = BCONV ? 0u : (unsigned)(g.R - 1) * (unsigned)g.ldb;
     auto load_tiles = [&](int r0) {      // every load is issued unconditionally from a clamped address and zeroed by a select
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int kr = (tid >> 4) + i * 16;
-            const int r = r0 + kr, m = m0 + a_mq * 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)min(r, Rlast) * g.lda + min(m, g.M - 8));
-            ra[i] = (r < r_end && m < g.M) ? v : make_uint4(0u, 0u, 0u, 0u);
+            const int r = r0 + (tid >> 4) + i * 16;
+            const uint4 v = *reinterpret_cast<const uint4*>(A + min(a_off[i], a_last));
+            ra[i] = (r < r_end && a_mok) ? v : make_uint4(0u, 0u, 0u, 0u);
+            a_off[i] += (unsigned)(BK * g.lda);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
             const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
-            const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
-            const int r = r0 + kr, n = n0 + nq * (B16 ? 8 : 4);
-            const bool ok = r < r_end && n < g.N;
-            size_t base = 0;
-            if (BCONV) base = (((size_t)b_cr[i].b * g.conv.Hin + b_cr[i].y * g.conv.sy + g.conv.oy) * g.conv.Win + b_cr[i].x * g.conv.sx + g.conv.ox) * g.conv.Cin;
+            const bool ok = (r0 + kr) < r_end && b_nok[i];
+            // rows past the end of the tensor (last split only) are clamped by construction for conv (crow_init clamps the start and
+            // the row test zeroes the value; offsets only ever move forward inside the allocation of the last image) and explicitly here
+            unsigned off = b_off[i];
+            if (!BCONV) off = min(off, b_lastrow + (unsigned)(g.ldb - (B16 ? 8 : 4)));
+            if (BCONV && !ok) off = 0u;
             if constexpr (B16) {
                 const u16* Bp = reinterpret_cast<const u16*>(g.B);
-                const uint4 v = BCONV ? *reinterpret_cast<const uint4*>(Bp + base + b_tapoff[i][0])
-                                      : *reinterpret_cast<const uint4*>(Bp + (size_t)min(r, Rlast) * g.ldb + min(n, g.N - 8));
+                const uint4 v = *reinterpret_cast<const uint4*>(Bp + off + (unsigned)b_tapoff[i][0]);
                 rb16[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             } else {
                 const float* Bp = g.B;
                 float4 v;
-                if (BCONV) {
-                    if (b_vec) v = *reinterpret_cast<const float4*>(Bp + base + b_tapoff[i][0]);     // wave-uniform choice
-                    else v = make_float4(Bp[base + b_tapoff[i][0]], Bp[base + b_tapoff[i][1]], Bp[base + b_tapoff[i][2]], Bp[base + b_tapoff[i][3]]);
-                } else {
-                    v = *reinterpret_cast<const float4*>(Bp + (size_t)min(r, Rlast) * g.ldb + min(n, g.N - 4));
-                }
+                if (b_vec) v = *reinterpret_cast<const float4*>(Bp + off + (unsigned)b_tapoff[i][0]);     // wave-uniform choice
+                else v = make_float4(Bp[off + (unsigned)b_tapoff[i][0]], Bp[off + (unsigned)b_tapoff[i][1]], Bp[off + (unsigned)b_tapoff[i][2]],
+                                     Bp[off + (unsigned)b_tapoff[i][3]]);
                 rb32[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (BCONV) crow_advance(g.conv, b_cr[i], BK, row_wraps);
+            // advance to the row BK further on
+            b_off[i] += (unsigned)d_step;
+            if (BCONV) {
+                b_x[i] += BK;
+                for (int kk = 0; kk < row_wraps; ++kk) {        // uniform trip count
+                    const bool w = b_x[i] >= g.conv.Wout;
+                    b_x[i] -= w ? g.conv.Wout : 0;
+                    b_y[i] += w ? 1 : 0;
+                    b_off[i] += w ? (unsigned)d_row : 0u;
+                }
+                const bool h = b_y[i] >= g.conv.Hout;
+                b_y[i] -= h ? g.conv.Hout : 0;
+                b_off[i] += h ? (unsigned)d_img : 0u;
+            }
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            *reinterpret_cast<uint4*>(&As[buf][((tid >> 4) + i * 16) * LDA + a_mq * 8]) = ra[i];
+            // opaque copies: whatever consumes the loaded registers is tied below the scheduling barrier that follows the MFMAs
+            // (otherwise the bf16 unpacking of the column sums is hoisted above them together with an s_waitcnt vmcnt(0))
+            uint4 av = ra[i];
+            asm volatile("" : "+v"(av.x), "+v"(av.y), "+v"(av.z), "+v"(av.w));
+            *reinterpret_cast<uint4*>(&As[buf][((tid >> 4) + i * 16) * LDA + a_mq * 8]) = av;
             if (do_colsum) {
-                const u16* h = reinterpret_cast<const u16*>(&ra[i]);
+                const u16* h = reinterpret_cast<const u16*>(&av);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum[e] += bf16_bits_to_float(h[e]);
             }
@@ -382,6 +452,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = (r0 + BK) < r_end;
             if (more) load_tiles(r0 + BK);
+            // pin the schedule: loads are ISSUED above, consumed (column sums, LDS stores) only below the MFMAs.  Without the two
+            // scheduling barriers hipcc hoists the bf16->fp32 column-sum math of the freshly loaded registers above the MFMAs and
+            // with it an s_waitcnt vmcnt(0): the whole load latency is then exposed in every iteration.
+            __builtin_amdgcn_sched_barrier(0);
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = lds_tr_frag16(As[buf], LDA, wm * WM + i * 16, lane);
@@ -392,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (more) store_tiles(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -437,9 +512,11 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if ((g.lda & 7) || (g.M & 7)) return SPAIR_ERR_ALIGN;
     if (b_bf16 && ((g.N & 7) || (!conv && (g.ldb & 7)) || (conv && (g.conv.Cin & 7)))) return SPAIR_ERR_ALIGN;
     if (!b_bf16 && ((g.N & 3) || (!conv && (g.ldb & 3)))) return SPAIR_ERR_ALIGN;
+    if ((long long)g.R * g.lda >= (1ll << 31) || (!conv && (long long)g.R * g.ldb >= (1ll << 31))) return SPAIR_ERR_UNSUPPORTED;   // 32-bit offsets
     constexpr int BM = 128, BN = 128;
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    int nsplit = max(1, min(ceil_div(g.R, 512), ceil_div(1024, tiles)));
+    // one full round of resident blocks: 256 CUs x 3 blocks (150 VGPRs, 35 KB LDS); a 4/3-round grid wastes a third of the time
+    int nsplit = max(1, min(ceil_div(g.R, 256), 768 / tiles));
     if (nsplit >= 8) nsplit = nsplit / 8 * 8;
     int rps = round_up(ceil_div(g.R, nsplit), 32);
     if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
