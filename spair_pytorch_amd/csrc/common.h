@@ -50,10 +50,20 @@ struct RowMap {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over the 64 lanes, result in every lane.  Four DPP steps give each 16-lane row its sum (no LDS traffic, unlike
+// __shfl_xor = ds_bpermute); the four row sums are then combined through scalar registers.
 __device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141>(v);     // row_half_mirror
+    v = dpp_add_<0x140>(v);     // row_mirror
+    const int i = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 
 // Sum over a 256-thread block (4 waves); result valid in every thread.

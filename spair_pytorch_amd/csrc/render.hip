@@ -38,10 +38,24 @@ __global__ __launch_bounds__(256) void k_sprite_act(float* __restrict__ S, int l
     *p = 1.f / (expf(-t) + 1.f);   // analytical sigmoid (modules.py:186-187)
 }
 
+// Source coordinate from the base (normalised) output coordinate -- the reference's own sequence (affine_grid, then
+// grid_sample's unnormalise).  Forward and backward MUST round identically: the compositing adjoint contains
+// (a*g - pre), which cancels to rounding level where one object dominates a pixel.
+__device__ __forceinline__ float src_from_base(float a, float b, float base, int nsrc, int ac, float& g) {
+    g = a * base + b;
+    return ac ? (g + 1.f) * 0.5f * (float)(nsrc - 1) : ((g + 1.f) * (float)nsrc - 1.f) * 0.5f;
+}
 __device__ __forceinline__ float src_of(float a, float b, int j, int nout, int nsrc, int ac) {
-    float c, m;
-    stn_src_coord(a, b, j, nout, nsrc, ac, false, c, m);
-    return c;
+    float g;
+    return src_from_base(a, b, stn_base(j, nout, ac), nsrc, ac, g);
+}
+// src_of() is affine in the output index: src_of(j) = c0 + j*slope.  The slope is formed analytically
+// (a difference of two src_of values would cancel ~5 digits).
+__device__ __forceinline__ void src_affine(float a, float b, int nout, int nsrc, int ac, float& c0, float& slope) {
+    const float bstep = ac ? (nout > 1 ? 2.f / (float)(nout - 1) : 0.f) : 2.f / (float)nout;
+    const float cm = ac ? 0.5f * (float)(nsrc - 1) : 0.5f * (float)nsrc;
+    slope = a * bstep * cm;
+    c0 = src_of(a, b, 0, nout, nsrc, ac);
 }
 
 __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
@@ -98,6 +112,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
         if (inside) {
             for (int ci = 0; ci < nc; ++ci) {
                 const Cand q = cand[ci];
+                // the reference's own formula (affine_grid then unnormalise), so recon and the saved pre-clamp value
+                // round like the oracle's
                 const float sx = src_of(q.ax, q.bx, px, I, P, ac);
                 const float sy = src_of(q.ay, q.by, py, I, P, ac);
                 if (!(sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P)) continue;
@@ -143,138 +159,247 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: one WAVE per object (4 objects of the same sample per workgroup).  Each wave keeps its sprite and the
-// sprite gradient in LDS, walks the object's pixel footprint, scatters tap gradients with ds_add_f32, reduces
-// d(z_where, pres, depth) with wave shuffles (no block barriers in the hot path) and writes dlogits once.
+// backward: one WORKGROUP (4 waves) per object, no atomics (LDS float atomics retire ~1 lane/clk on gfx950 and
+// were 60% of the first scatter kernel).  Two passes per object, both conflict-free:
+//   A  threads = pixels of the object's footprint: re-sample the sprite from a zero-bordered LDS copy that already
+//      holds (grey, alpha, importance) per texel -- no tap bounds tests -- form the three per-pixel adjoints,
+//      reduce d(z_where) in registers, park the adjoints in LDS.  The per-pixel aux record is prefetched one
+//      iteration ahead (the only global load in the loop);
+//   B  threads = sprite texels: each texel GATHERS the pixels whose bilinear hat covers it (the transpose of the
+//      4-tap scatter), accumulates d(pres, depth), applies sigmoid' and the logit scales and writes dlogits once.
+// The staged footprint is RB_CAP pixels; larger footprints are processed per texel tile (pixels on tile seams are
+// re-sampled; their z_where gradients are counted by the owning tile only), and a tile that pass B covers in one
+// sweep whose footprint still does not fit is streamed in row chunks with the texel sums held in registers.
+// LDS per workgroup is 26.7 KB at P=28, so 6 workgroups = 24 waves share a CU.
 // Workgroup -> sample mapping is XCD-aware: every object of sample b runs on XCD b%8, so the per-pixel aux map of a
 // sample (I*I*16 B) is only ever cached in one L2.
 // ---------------------------------------------------------------------------------------------
+#ifndef RB_WAVES
 #define RB_WAVES 4
-__global__ __launch_bounds__(64 * RB_WAVES) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
-                                                              const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
-                                                              const float4* __restrict__ aux, const float* __restrict__ gloss,
-                                                              float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
-                                                              float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
-                                                              float obj_scale, float alpha_scale, int g_bf16) {
+#endif
+#ifndef RB_CAP
+#define RB_CAP 1024
+#endif
+#define RB_T (64 * RB_WAVES)
+#define RB_TSH (RB_WAVES == 1 ? 6 : RB_WAVES == 2 ? 7 : RB_WAVES == 4 ? 8 : 9)
+__device__ __forceinline__ int rb_span(int T, float inv, int I) { return min((int)ceilf((float)(T + 1) * inv) + 3, I); }
+__device__ __forceinline__ int rb_lane_shift(int w) { return w <= 16 ? 4 : (w <= 32 ? 5 : 6); }
+// sweeps pass B needs for a TU x TV texel tile (a workgroup covers (RB_T/CW) rows x CW columns per sweep)
+__device__ __forceinline__ int rb_sweeps(int TU, int TV) {
+    const int sh = rb_lane_shift(TU), cw = 1 << sh, rsh = RB_TSH - sh, rows = 1 << rsh;
+    return ((TU + cw - 1) >> sh) * ((TV + rows - 1) >> rsh);
+}
+
+__global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
+                                                     const float4* __restrict__ aux, const float* __restrict__ gloss,
+                                                     float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
+                                                     float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
+                                                     float obj_scale, float alpha_scale, int g_bf16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int PP2 = P * P * 2;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* Ssh = sm + (size_t)wave * 2 * PP2;     // sprite (grey, alpha)
-    float* dSh = Ssh + PP2;                        // its gradient
-    // (sample, object) of this wave
-    const int kgroups = (HW + RB_WAVES - 1) / RB_WAVES;
-    int b, kg;
-    if ((B & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        b = (j % (B >> 3)) * 8 + xcd;
-        kg = j / (B >> 3);
-    } else {
-        b = blockIdx.x % B;
-        kg = blockIdx.x / B;
-    }
-    const int k = kg * RB_WAVES + wave;
-    const bool live = k < HW && kg < kgroups;
-    const int r = live ? k * B + b : 0;
+    __shared__ float red[RB_WAVES][6];
+    const int PS = P + 2, NTX = PS * PS;                     // zero-bordered sprite
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float4* Ssh = reinterpret_cast<float4*>(sm);             // (grey, alpha, importance, -)
+    float* pb = reinterpret_cast<float*>(Ssh + NTX);          // staged per-pixel adjoints [RB_CAP][3]
+    float* btab = pb + 3 * RB_CAP;                            // base coordinate of output index j (no division per pixel)
+    for (int e = tid; e < I; e += RB_T) btab[e] = stn_base(e, I, ac);
+    // (sample, object) of this workgroup: grid = (B, HW); consecutive workgroup ids walk the samples, so with B % 8 == 0
+    // every object of sample b lands on XCD b % 8
+    const int b = blockIdx.x, k = blockIdx.y;
+    const int r = k * B + b;
     const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
     const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
     const float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
-    if (live) {
-        for (int e = lane * 4; e < PP2; e += 256) {
-            *reinterpret_cast<float4*>(&Ssh[e]) = *reinterpret_cast<const float4*>(S + (size_t)r * ld_s + e);
-            *reinterpret_cast<float4*>(&dSh[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* auxb = aux + (size_t)b * I * I;
+    const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
+    if (P <= 32) {
+        // all loads are issued before the first LDS write
+        constexpr int RV = RB_T / 32;                         // rows per sweep
+        constexpr int NI = 32 / RV;
+        const float2* Sr = reinterpret_cast<const float2*>(S + (size_t)r * ld_s);
+        const int u = tid & 31;
+        float2 t[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = RV * i + (tid >> 5);
+            t[i] = Sr[min(v, P - 1) * P + min(u, P - 1)];
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = RV * i + (tid >> 5);
+            if (v < P && u < P) Ssh[(v + 1) * PS + u + 1] = make_float4(t[i].x, t[i].y, fmaxf(t[i].y * pd, 0.01f), 0.f);
+        }
+    } else {
+        const float2* Sr = reinterpret_cast<const float2*>(S + (size_t)r * ld_s);
+        for (int e = tid; e < P * P; e += RB_T) {
+            const float2 t = Sr[e];
+            const int v = e / P, u = e - v * P;
+            Ssh[(v + 1) * PS + u + 1] = make_float4(t.x, t.y, fmaxf(t.y * pd, 0.01f), 0.f);
+        }
+    }
+    for (int e = tid; e < PS; e += RB_T) {
+        Ssh[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Ssh[(PS - 1) * PS + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Ssh[e * PS] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Ssh[e * PS + PS - 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f, g_pr = 0.f, g_dp = 0.f;
-    if (live) {
-        // pixel footprint: source coord is affine in the pixel index; widen by 2 and test exactly below
-        const float sx0 = src_of(ax, bx, 0, I, P, ac), sxa = src_of(ax, bx, 1, I, P, ac) - sx0;
-        const float sy0 = src_of(ay, by, 0, I, P, ac), sya = src_of(ay, by, 1, I, P, ac) - sy0;
-        int X0 = (int)floorf((-1.f - sx0) / sxa) - 2, X1 = (int)ceilf(((float)P - sx0) / sxa) + 2;
-        int Y0 = (int)floorf((-1.f - sy0) / sya) - 2, Y1 = (int)ceilf(((float)P - sy0) / sya) + 2;
-        X0 = max(X0, 0); Y0 = max(Y0, 0); X1 = min(X1, I - 1); Y1 = min(Y1, I - 1);
-        const int fw = X1 - X0 + 1, fh = Y1 - Y0 + 1;
-        const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
-        const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
-        for (int idx = lane; idx < npx; idx += 64) {
-            const int py = Y0 + idx / fw, px = X0 + idx % fw;
-            const float sx = src_of(ax, bx, px, I, P, ac), sy = src_of(ay, by, py, I, P, ac);
-            if (!(sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P)) continue;
-            const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-            const float wx1 = sx - (float)x0, wy1 = sy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-            float G[4], A0[4], Mt[4], W[4];
-            bool ok[4];
-            float g = 0.f, a = 0.f, m = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
-                ok[t] = !(yy < 0 || yy >= P || xx < 0 || xx >= P);
-                W[t] = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
-                const float2 v = ok[t] ? *reinterpret_cast<const float2*>(&Ssh[(yy * P + xx) * 2]) : make_float2(0.f, 0.f);
-                G[t] = v.x;
-                A0[t] = v.y;
-                Mt[t] = ok[t] ? fmaxf(A0[t] * pd, 0.01f) : 0.f;
-                g += W[t] * G[t];
-                a += W[t] * (A0[t] * pr);
-                m += W[t] * Mt[t];
+    // source coordinate of pixel (px,py) ~ (sx0 + px*sxa, sy0 + py*sya), slopes > 0: used for index BOUNDS only (each
+    // bound keeps a spare pixel); the coordinates themselves come from src_from_base like the forward's
+    float sx0, sxa, sy0, sya;
+    src_affine(ax, bx, I, P, ac, sx0, sxa);
+    src_affine(ay, by, I, P, ac, sy0, sya);
+    const float isx = __builtin_amdgcn_rcpf(sxa), isy = __builtin_amdgcn_rcpf(sya);     // only used for (conservative) index bounds
+    const float cgx = -mult * ax, cgy = -mult * ay;           // d(source coord)/d(t) incl. the unnormalisation
+    // texel tile whose pixel footprint fits the staging buffer
+    int TU = P, TV = P;
+    while (rb_span(TU, isx, I) * rb_span(TV, isy, I) > RB_CAP && rb_sweeps(TU, TV) > 1) {
+        if (rb_span(TV, isy, I) >= rb_span(TU, isx, I) && TV > 1) TV = (TV + 1) >> 1;
+        else if (TU > 1) TU = (TU + 1) >> 1;
+        else TV = (TV + 1) >> 1;
+    }
+    for (int tv0 = 0; tv0 < P; tv0 += TV)
+    for (int tu0 = 0; tu0 < P; tu0 += TU) {
+        const int tu1 = min(tu0 + TU, P), tv1 = min(tv0 + TV, P);      // texel tile [tu0,tu1) x [tv0,tv1)
+        // pixels whose source coordinate lies in (tu0-1, tu1) x (tv0-1, tv1), one spare pixel either side
+        const int PX0 = max((int)floorf(((float)(tu0 - 1) - sx0) * isx), 0), PX1 = min((int)ceilf(((float)tu1 - sx0) * isx), I - 1);
+        const int PY0 = max((int)floorf(((float)(tv0 - 1) - sy0) * isy), 0), PY1 = min((int)ceilf(((float)tv1 - sy0) * isy), I - 1);
+        const int pw = PX1 - PX0 + 1, ph = PY1 - PY0 + 1;
+        const bool empty = pw <= 0 || ph <= 0;
+        const int rows_per = empty ? 1 : max(1, RB_CAP / pw);           // host guarantees I <= RB_CAP
+        const bool multi = !empty && ph > rows_per;                      // only reachable when pass B is a single sweep
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const int wsh = rb_lane_shift(pw), W = 1 << wsh, RPI = 64 >> wsh;
+        const int lx = lane & (W - 1), ly = lane >> wsh;
+        const int nxc = empty ? 1 : (pw + W - 1) >> wsh;
+        const int csh = rb_lane_shift(tu1 - tu0), CW = 1 << csh, CR = RB_T >> csh;
+        const int cu = tid & (CW - 1), cv = tid >> csh;
+        // z_where gradients are counted by the tile that owns the pixel: source coord in [tu0, tu1) x [tv0, tv1),
+        // the first / last tile also taking the half-covered border pixels
+        const float oxl = tu0 == 0 ? -1.f : (float)tu0, oxh = (float)tu1, oyl = tv0 == 0 ? -1.f : (float)tv0, oyh = (float)tv1;
+        for (int cy0 = PY0; cy0 <= (empty ? PY0 : PY1); cy0 += rows_per) {
+            const int cy1 = empty ? cy0 - 1 : min(cy0 + rows_per - 1, PY1);
+            // ---- pass A: a wave covers (64/W) rows x W columns per iteration; iterations are dealt round-robin to waves
+            const int nj = ((cy1 - cy0 + RPI) >> (6 - wsh)) * nxc;
+            auto pixel_of = [&](int j, int& px, int& py) {
+                const int yi = nxc == 1 ? j : j / nxc, xi = j - yi * nxc;
+                px = PX0 + (xi << wsh) + lx;
+                py = cy0 + yi * RPI + ly;
+            };
+            float4 avn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wave < nj) {
+                int px, py;
+                pixel_of(wave, px, py);
+                avn = auxb[min(py, cy1) * I + min(px, PX1)];
             }
-            const float4 av = aux[((size_t)b * I + py) * I + px];   // (dBCE/dpre, 1/D, pre, -)
-            const float go = av.x * gl, invD = av.y, pre = av.z;
-            const float Dm = m + 1e-9f;
-            const float d_g = go * a * Dm * invD;
-            const float d_a = go * g * Dm * invD;
-            const float d_m = go * (a * g - pre) * invD;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (!ok[t]) continue;
-                const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
-                const bool act = (A0[t] * pd) >= 0.01f;
-                atomicAdd(&dSh[(yy * P + xx) * 2], W[t] * d_g);
-                atomicAdd(&dSh[(yy * P + xx) * 2 + 1], W[t] * (d_a * pr + (act ? d_m * pd : 0.f)));
-                g_pr += W[t] * (d_a * A0[t] + (act ? d_m * A0[t] * dp : 0.f));
-                g_dp += act ? W[t] * d_m * A0[t] * pr : 0.f;
+#if defined(RB_EXP) && (RB_EXP & 4)
+            if (gl == 12345.f)
+#endif
+            for (int j = wave; j < nj; j += RB_WAVES) {
+                const float4 av = avn;                                   // (dBCE/dpre, 1/D, pre, -)
+                int px, py;
+                {
+                    pixel_of(min(j + RB_WAVES, nj - 1), px, py);
+                    avn = auxb[min(py, cy1) * I + min(px, PX1)];
+                }
+                pixel_of(j, px, py);
+                if (py > cy1 || px > PX1) continue;
+                float gxn, gyn;
+                const float sx = src_from_base(ax, bx, btab[px], P, ac, gxn), sy = src_from_base(ay, by, btab[py], P, ac, gyn);
+                const bool inside = sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P;
+                const float fx = fminf(fmaxf(floorf(sx), -1.f), (float)(P - 1)), fy = fminf(fmaxf(floorf(sy), -1.f), (float)(P - 1));
+                const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const float4* t = Ssh + ((int)fy + 1) * PS + (int)fx + 1;
+                const float4 t0 = t[0], t1 = t[1], t2 = t[PS], t3 = t[PS + 1];
+                // separable bilinear: x first, then y; the y-derivative is (bottom - top)
+                const float gT = t0.x * wx0 + t1.x * wx1, gB = t2.x * wx0 + t3.x * wx1;
+                const float aT = t0.y * wx0 + t1.y * wx1, aB = t2.y * wx0 + t3.y * wx1;
+                const float mT = t0.z * wx0 + t1.z * wx1, mB = t2.z * wx0 + t3.z * wx1;
+                const float g = gT * wy0 + gB * wy1, a = (aT * wy0 + aB * wy1) * pr, m = mT * wy0 + mB * wy1;
+                const float go = inside ? av.x * gl * av.y : 0.f;       // dBCE/dpre / D
+                const float Dm = m + 1e-9f;
+                const float d_g = go * a * Dm;
+                const float d_a = go * g * Dm;                           // wrt (alpha*pres)
+                const float d_m = go * (a * g - av.z);
+                float* q = pb + ((py - cy0) * pw + (px - PX0)) * 3;
+                q[0] = d_g; q[1] = d_a; q[2] = d_m;
+                if (!(sx >= oxl && sx < oxh && sy >= oyl && sy < oyh)) continue;
+                const float dap = d_a * pr;
+                const float dgx = (t1.x - t0.x) * wy0 + (t3.x - t2.x) * wy1, dax = (t1.y - t0.y) * wy0 + (t3.y - t2.y) * wy1,
+                            dmx = (t1.z - t0.z) * wy0 + (t3.z - t2.z) * wy1;
+                const float g_sx = d_g * dgx + dap * dax + d_m * dmx;               // d/d(source x), pixel units
+                const float g_sy = d_g * (gB - gT) + dap * (aB - aT) + d_m * (mB - mT);
+                g_tx += g_sx; g_xs = fmaf(g_sx, gxn, g_xs);              // scaled by cgx / cgy after the loop
+                g_ty += g_sy; g_ys = fmaf(g_sy, gyn, g_ys);
             }
-            // gradient wrt the source coordinate (taps outside the sprite are zeros)
-            const float At[4] = {A0[0] * pr, A0[1] * pr, A0[2] * pr, A0[3] * pr};
-            const float dgx = (G[1] - G[0]) * wy0 + (G[3] - G[2]) * wy1, dgy = (G[2] - G[0]) * wx0 + (G[3] - G[1]) * wx1;
-            const float dax = (At[1] - At[0]) * wy0 + (At[3] - At[2]) * wy1, day = (At[2] - At[0]) * wx0 + (At[3] - At[1]) * wx1;
-            const float dmx = (Mt[1] - Mt[0]) * wy0 + (Mt[3] - Mt[2]) * wy1, dmy = (Mt[2] - Mt[0]) * wx0 + (Mt[3] - Mt[1]) * wx1;
-            const float g_gx = (d_g * dgx + d_a * dax + d_m * dmx) * mult;   // d/d(normalised source x)
-            const float g_gy = (d_g * dgy + d_a * day + d_m * dmy) * mult;
-            const float gxn = ax * stn_base(px, I, ac) + bx, gyn = ay * stn_base(py, I, ac) + by;
-            g_tx += -g_gx * ax; g_xs += -g_gx * gxn * ax;     // g = (X - t)/s
-            g_ty += -g_gy * ay; g_ys += -g_gy * gyn * ay;
+            __syncthreads();
+            // ---- pass B: threads = texels of the tile, (RB_T/CW) rows x CW columns; gather the pixels under each hat
+            const bool last = empty || cy1 == PY1;
+            for (int ub = tu0; ub < tu1; ub += CW) {
+                const int u = ub + cu;
+                const int xa = max(PX0, (int)floorf(((float)(u - 1) - sx0) * isx) + 1), xe = min(PX1, (int)ceilf(((float)(u + 1) - sx0) * isx) - 1);
+                for (int vb = tv0; vb < tv1; vb += CR) {
+                    const int v = vb + cv;
+                    if (u >= tu1 || v >= tv1) continue;
+                    const int ya = max(cy0, (int)floorf(((float)(v - 1) - sy0) * isy) + 1), ye = min(cy1, (int)ceilf(((float)(v + 1) - sy0) * isy) - 1);
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#if defined(RB_EXP) && (RB_EXP & 8)
+                    if (gl == 12345.f)
+#endif
+                    for (int py = ya; py <= ye; ++py) {
+                        float gdum;
+                        const float wy = fmaxf(1.f - fabsf(src_from_base(ay, by, btab[py], P, ac, gdum) - (float)v), 0.f);
+                        const float* q = pb + ((py - cy0) * pw - PX0) * 3;
+                        for (int px = xa; px <= xe; ++px) {
+                            const float w = wy * fmaxf(1.f - fabsf(src_from_base(ax, bx, btab[px], P, ac, gdum) - (float)u), 0.f);
+                            s0 = fmaf(w, q[px * 3], s0);
+                            s1 = fmaf(w, q[px * 3 + 1], s1);
+                            s2 = fmaf(w, q[px * 3 + 2], s2);
+                        }
+                    }
+                    if (multi) { a0 += s0; a1 += s1; a2 += s2; s0 = a0; s1 = a1; s2 = a2; }
+                    if (!last) continue;
+                    const float4 sv = Ssh[(v + 1) * PS + u + 1];
+                    const bool act = (sv.y * pd) >= 0.01f;                   // importance not clamped
+                    const float s2a = act ? s2 * sv.y : 0.f;
+                    g_pr += s1 * sv.y + s2a * dp;
+                    g_dp += s2a * pr;
+                    // through the analytical sigmoid and the logit scales (models.py:485-492)
+                    const int e = (v * P + u) * 2;
+                    const float ox = s0 * sv.x * (1.f - sv.x) * obj_scale;
+                    const float oy = (s1 * pr + (act ? s2 * pd : 0.f)) * sv.y * (1.f - sv.y) * alpha_scale;
+                    if (g_bf16) {
+                        __bf16 ob[2] = {(__bf16)ox, (__bf16)oy};
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(dlogits) + (size_t)r * ld_g + e) = *reinterpret_cast<unsigned*>(ob);
+                    } else {
+                        *reinterpret_cast<float2*>(dlogits + (size_t)r * ld_g + e) = make_float2(ox, oy);
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
-    g_tx = wave_reduce_sum(g_tx); g_ty = wave_reduce_sum(g_ty);
-    g_xs = wave_reduce_sum(g_xs); g_ys = wave_reduce_sum(g_ys);
+    g_tx = wave_reduce_sum(g_tx) * cgx; g_ty = wave_reduce_sum(g_ty) * cgy;
+    g_xs = wave_reduce_sum(g_xs) * cgx; g_ys = wave_reduce_sum(g_ys) * cgy;
     g_pr = wave_reduce_sum(g_pr); g_dp = wave_reduce_sum(g_dp);
-    if (live && lane == 0) {
-        *reinterpret_cast<float4*>(dnbox + (size_t)r * 4) = make_float4(2.f * g_tx, 2.f * g_ty, g_xs, g_ys);
-        dpres[r] = g_pr;
-        ddepth[r] = g_dp;
+    if (lane == 0) {
+        red[wave][0] = g_tx; red[wave][1] = g_ty; red[wave][2] = g_xs; red[wave][3] = g_ys; red[wave][4] = g_pr; red[wave][5] = g_dp;
     }
     __syncthreads();
-    // through the analytical sigmoid and the logit scales (models.py:485-492)
-    if (live) {
-        for (int e = lane * 4; e < PP2; e += 256) {
-            const float4 sv = *reinterpret_cast<const float4*>(&Ssh[e]);
-            const float4 dv = *reinterpret_cast<const float4*>(&dSh[e]);
-            float4 o;
-            o.x = dv.x * sv.x * (1.f - sv.x) * obj_scale;
-            o.y = dv.y * sv.y * (1.f - sv.y) * alpha_scale;
-            o.z = dv.z * sv.z * (1.f - sv.z) * obj_scale;
-            o.w = dv.w * sv.w * (1.f - sv.w) * alpha_scale;
-            if (g_bf16) {
-                bf16x4 ob;
-                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dlogits) + (size_t)r * ld_g + e) = ob;
-            } else {
-                *reinterpret_cast<float4*>(dlogits + (size_t)r * ld_g + e) = o;
-            }
+    if (tid == 0) {
+        float o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            o[i] = 0.f;
+            for (int w = 0; w < RB_WAVES; ++w) o[i] += red[w][i];
         }
+        *reinterpret_cast<float4*>(dnbox + (size_t)r * 4) = make_float4(2.f * o[0], 2.f * o[1], o[2], o[3]);
+        dpres[r] = o[4];
+        ddepth[r] = o[5];
     }
 }
 
@@ -305,10 +430,11 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I,
                int P, int ac, float obj_scale, float alpha_scale, int g_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
-    if ((P * P * 2) % 4 || (ld_s & 3) || (ld_g & 3)) return SPAIR_ERR_ALIGN;
-    const size_t lds = (size_t)RB_WAVES * P * P * 2 * 2 * sizeof(float);
-    const int kgroups = (HW + RB_WAVES - 1) / RB_WAVES;
-    hipLaunchKernelGGL(k_render_bwd, dim3(B * kgroups), dim3(64 * RB_WAVES), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
+    if ((ld_s & 1) || (ld_g & 1)) return SPAIR_ERR_ALIGN;
+    if (I > RB_CAP || (long long)I * I > 0x7fffffffLL / 4 || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)(P + 2) * (P + 2) * 4 + 3 * RB_CAP + I) * sizeof(float);
+    if (lds > 65536) return SPAIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_render_bwd, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
                        reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
                        alpha_scale, g_bf16);
     SPAIR_CHECK_LAUNCH();
