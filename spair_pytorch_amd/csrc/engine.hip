@@ -123,6 +123,7 @@ struct Ws {
     CellBufs cb;
     float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;     // Hd*, dLog, dHd*: bf16 in bf16 mode
     void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
+    float* tn_part;                                     // split-K partial tiles of the weight-gradient GEMMs
     float *aux, *bce_partial, *kl_partial, *klp;
     unsigned long long* stamps;
     int ld_feat, ld_s;
@@ -220,6 +221,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
     w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
     w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
+    w.tn_part = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
@@ -382,6 +384,7 @@ static int tn16(Ctx& c, const void* A, int lda, int M, const void* B, int ldb, i
     g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = reinterpret_cast<const float*>(B); g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = round_up(M, 8); g.N = round_up(N, b_bf16 ? 8 : 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
     g.cw_cin = cw_cin; g.cw_taps = cw_taps;
+    g.part = c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
     if (conv) g.conv = *conv;
     return spair_gemm_tn16_impl(g, conv != nullptr, b_bf16, c.s);
 }

@@ -25,7 +25,11 @@ struct GemmTN {
     int rows_per_split, nsplit, tiles_m, tiles_n;   // filled by the launcher
     float* colsum_out;      // optional: += column sums of A (bias gradient), fused into the same pass
     ConvDesc conv;
+    // optional split-K scratch: each block stores its fp32 tile with plain coalesced stores to part[split][tile][128][128]
+    // and a second kernel sums the splits and does C += sum (no atomics).  NULL / too small -> fp32 atomics into C.
+    float* part; long long part_cap;    // capacity in floats
 };
+#define SPAIR_TN_PART_FLOATS (768ll * 128 * 128)     // 768 resident blocks x one 128x128 tile
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);
 int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s);
 int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s);

@@ -487,6 +487,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+    if (g.part) {
+        // split-K partial: plain stores, 64 B per 16 lanes; summed by k_tn_reduce
+        float* pt = g.part + ((size_t)sp_ * (g.tiles_m * g.tiles_n) + (size_t)nt_ * g.tiles_m + mt_) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wm * WM + i * 16 + rgrp + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pt[ml * BN + wn * WN + j * 16 + col_l] = acc[i][j][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -502,6 +515,43 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
                 atomicAdd(&g.C[(size_t)m * g.ldc + nc], acc[i][j][r]);
             }
         }
+}
+
+// Second stage of the split-K weight gradient: C[m][col(n)] += sum over splits of part[split][tile][m][n].
+// One thread per (m, 4 consecutive n): coalesced float4 reads of every split, one read-modify-write of C.
+__global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g) {
+    constexpr int BM = 128, BN = 128;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int tile = idx >> 12, e = idx & 4095;                // 128*128/4 = 4096 float4 per tile
+    if (tile >= tiles) return;
+    const int ml = e >> 5, nl = (e & 31) * 4;
+    const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
+    const int m = mt * BM + ml, n = nt * BN + nl;
+    if (m >= g.Mstore || n >= g.Nstore) return;
+    const float* pt = g.part + (size_t)tile * (BM * BN) + ml * BN + nl;
+    const size_t sstride = (size_t)tiles * (BM * BN);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int sp = 0;
+    for (; sp + 1 < g.nsplit; sp += 2) {
+        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+        const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 1) * sstride);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (sp < g.nsplit) {
+        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nn = n + q;
+        if (nn >= g.Nstore) break;
+        int nc = nn;
+        if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
+        g.C[(size_t)m * g.ldc + nc] += v[q];
+    }
 }
 
 // A bf16 [R][lda]; B: bf16 (b_bf16) plain rows / conv gather, or fp32 conv gather / plain rows
@@ -522,6 +572,7 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
     g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
     dim3 grid(g.tiles_m * g.tiles_n * nsplit);
+    if (g.part && (long long)grid.x * BM * BN > g.part_cap) g.part = nullptr;     // scratch too small: atomics
     if (conv) {
         if (b_bf16) hipLaunchKernelGGL((gemm_tn16_kernel<true, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_tn16_kernel<true, false>), grid, dim3(256), 0, s, g);
@@ -530,6 +581,10 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_tn16_kernel<false, false>), grid, dim3(256), 0, s, g);
     }
     SPAIR_CHECK_LAUNCH();
+    if (g.part) {
+        hipLaunchKernelGGL(k_tn_reduce, dim3(g.tiles_m * g.tiles_n * 16), dim3(256), 0, s, g);
+        SPAIR_CHECK_LAUNCH();
+    }
     return SPAIR_OK;
 }
 
