@@ -364,6 +364,7 @@ static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, i
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = round_up(M, 4); g.N = round_up(N, 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
+    // (split-K partial tiles do not pay here: N-contiguous atomics on 1-3 tiles are cheaper than the extra pass)
     return spair_gemm_tn_impl(g, false, c.d.dtype, c.s);
 }
 // bf16-stored operand GEMMs (gemm16.hip)

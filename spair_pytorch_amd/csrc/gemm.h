@@ -29,9 +29,10 @@ struct GemmTN {
     // and a second kernel sums the splits and does C += sum (no atomics).  NULL / too small -> fp32 atomics into C.
     float* part; long long part_cap;    // capacity in floats
 };
-#define SPAIR_TN_PART_FLOATS (768ll * 128 * 128)     // 768 resident blocks x one 128x128 tile
+#define SPAIR_TN_PART_FLOATS (1536ll * 128 * 128)    // up to 1536 blocks x one 128x128 tile (100 MB)
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);
 int spair_gemm_tn_impl(GemmTN g, bool conv, int dtype, hipStream_t s);
+int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s);   // second stage of a split-K TN GEMM that wrote g.part
 int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStream_t s);
 // gemm16.hip: bf16-stored operands
 int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s);

@@ -591,6 +591,19 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+    if (g.part) {
+        // split-K partial: plain stores, summed by k_tn_reduce
+        float* pt = g.part + ((size_t)sp_ * (g.tiles_m * g.tiles_n) + (size_t)nt_ * g.tiles_m + mt_) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wm * WM + i * 16 + rgrp + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pt[ml * BN + wn * WN + j * 16 + col_l] = acc[i][j][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -608,6 +621,48 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
         }
 }
 
+// Second stage of the split-K weight gradient: C[m][col(n)] += sum over splits of part[split][tile][m][n].
+// One thread per (m, 4 consecutive n): coalesced float4 reads of every split, one read-modify-write of C.
+__global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
+    const int tiles = g.tiles_m * g.tiles_n, per = bm * bn / 4, bn4 = bn / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int tile = idx / per, e = idx - tile * per;
+    if (tile >= tiles) return;
+    const int ml = e / bn4, nl = (e - ml * bn4) * 4;
+    const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
+    const int m = mt * bm + ml, n = nt * bn + nl;
+    if (m >= g.Mstore || n >= g.Nstore) return;
+    const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
+    const size_t sstride = (size_t)tiles * (bm * bn);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int sp = 0;
+    for (; sp + 1 < g.nsplit; sp += 2) {
+        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+        const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 1) * sstride);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (sp < g.nsplit) {
+        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nn = n + q;
+        if (nn >= g.Nstore) break;
+        int nc = nn;
+        if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
+        g.C[(size_t)m * g.ldc + nc] += v[q];
+    }
+}
+int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s) {
+    const long long n4 = (long long)g.tiles_m * g.tiles_n * bm * bn / 4;
+    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g, bm, bn);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
 template <int BM, int BN>
 static int launch_tn_bf16(GemmTN g, bool conv, hipStream_t s) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
@@ -617,9 +672,11 @@ static int launch_tn_bf16(GemmTN g, bool conv, hipStream_t s) {
     if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
     g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
     dim3 grid(g.tiles_m * g.tiles_n * nsplit);
+    if (g.part && (long long)grid.x * BM * BN > g.part_cap) g.part = nullptr;     // scratch too small: atomics
     if (conv) hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
     SPAIR_CHECK_LAUNCH();
+    if (g.part) return spair_tn_reduce(g, BM, BN, s);
     return SPAIR_OK;
 }
 

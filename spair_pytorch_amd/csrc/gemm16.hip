@@ -517,43 +517,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         }
 }
 
-// Second stage of the split-K weight gradient: C[m][col(n)] += sum over splits of part[split][tile][m][n].
-// One thread per (m, 4 consecutive n): coalesced float4 reads of every split, one read-modify-write of C.
-__global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g) {
-    constexpr int BM = 128, BN = 128;
-    const int tiles = g.tiles_m * g.tiles_n;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int tile = idx >> 12, e = idx & 4095;                // 128*128/4 = 4096 float4 per tile
-    if (tile >= tiles) return;
-    const int ml = e >> 5, nl = (e & 31) * 4;
-    const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
-    const int m = mt * BM + ml, n = nt * BN + nl;
-    if (m >= g.Mstore || n >= g.Nstore) return;
-    const float* pt = g.part + (size_t)tile * (BM * BN) + ml * BN + nl;
-    const size_t sstride = (size_t)tiles * (BM * BN);
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    int sp = 0;
-    for (; sp + 1 < g.nsplit; sp += 2) {
-        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
-        const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 1) * sstride);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-    }
-    if (sp < g.nsplit) {
-        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    }
-    const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int nn = n + q;
-        if (nn >= g.Nstore) break;
-        int nc = nn;
-        if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
-        g.C[(size_t)m * g.ldc + nc] += v[q];
-    }
-}
-
 // A bf16 [R][lda]; B: bf16 (b_bf16) plain rows / conv gather, or fp32 conv gather / plain rows
 int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
@@ -581,10 +544,7 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_tn16_kernel<false, false>), grid, dim3(256), 0, s, g);
     }
     SPAIR_CHECK_LAUNCH();
-    if (g.part) {
-        hipLaunchKernelGGL(k_tn_reduce, dim3(g.tiles_m * g.tiles_n * 16), dim3(256), 0, s, g);
-        SPAIR_CHECK_LAUNCH();
-    }
+    if (g.part) return spair_tn_reduce(g, BM, BN, s);
     return SPAIR_OK;
 }
 
