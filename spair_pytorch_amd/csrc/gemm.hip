@@ -622,31 +622,40 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
 }
 
 // Second stage of the split-K weight gradient: C[m][col(n)] += sum over splits of part[split][tile][m][n].
-// One thread per (m, 4 consecutive n): coalesced float4 reads of every split, one read-modify-write of C.
+// A workgroup owns 32 float4 elements; its 8 thread groups each sum every 8th split (coalesced 512 B rows), the
+// groups are combined through LDS and group 0 does the one read-modify-write of C.
 __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
+    __shared__ float4 red[8][32];
     const int tiles = g.tiles_m * g.tiles_n, per = bm * bn / 4, bn4 = bn / 4;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + el;
     const int tile = idx / per, e = idx - tile * per;
-    if (tile >= tiles) return;
     const int ml = e / bn4, nl = (e - ml * bn4) * 4;
     const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
     const int m = mt * bm + ml, n = nt * bn + nl;
-    if (m >= g.Mstore || n >= g.Nstore) return;
-    const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
-    const size_t sstride = (size_t)tiles * (bm * bn);
+    const bool live = tile < tiles && m < g.Mstore && n < g.Nstore;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    int sp = 0;
-    for (; sp + 1 < g.nsplit; sp += 2) {
-        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
-        const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 1) * sstride);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    if (live) {
+        const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
+        const size_t sstride = (size_t)tiles * (bm * bn);
+        int sp = sl;
+        for (; sp + 8 < g.nsplit; sp += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+            const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 8) * sstride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (sp < g.nsplit) {
+            const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
     }
-    if (sp < g.nsplit) {
-        const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    }
-    const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+    red[sl][el] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (sl != 0 || !live) return;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float4 t = red[q][el]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int nn = n + q;
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
 }
 int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s) {
     const long long n4 = (long long)g.tiles_m * g.tiles_n * bm * bn / 4;
-    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g, bm, bn);
+    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, g, bm, bn);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

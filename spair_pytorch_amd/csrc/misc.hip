@@ -202,9 +202,68 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ xp,
         }
     }
 }
+// Single-channel 4x4 specialisation (the reference's grey-scale stem): workgroup = one output row of one sample, the
+// 4 input rows staged in LDS, the 16x4 weights of a thread's channel quad held in registers, thread = (pixel group,
+// channel quad) so a pixel's 128 channels leave as one contiguous 256 B (bf16) / 512 B (fp32) store.  HBM-write bound.
+__global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict__ xp, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int Hin, int s,
+                                                        int Hout, int Cout, int out_bf16) {
+    extern __shared__ float xs[];    // [4][Hin]
+    const int oy = blockIdx.x, b = blockIdx.y;
+    const int q = Cout >> 2, groups = 256 / q;
+    const int cq = threadIdx.x % q, pg = threadIdx.x / q;
+    for (int i = threadIdx.x; i < 4 * Hin; i += 256) {
+        const int ky = i / Hin, x = i - ky * Hin;
+        xs[i] = xp[((size_t)b * Hin + oy * s + ky) * Hin + x];
+    }
+    float4 wr[16];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(w + (size_t)cq * 4 * 16);     // 4 channels x 16 taps, contiguous
+        float4 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = w4[i];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {      // t[c*4 + tq] holds taps 4tq..4tq+3 of channel c
+            wr[tq * 4 + 0] = make_float4(t[tq].x, t[4 + tq].x, t[8 + tq].x, t[12 + tq].x);
+            wr[tq * 4 + 1] = make_float4(t[tq].y, t[4 + tq].y, t[8 + tq].y, t[12 + tq].y);
+            wr[tq * 4 + 2] = make_float4(t[tq].z, t[4 + tq].z, t[8 + tq].z, t[12 + tq].z);
+            wr[tq * 4 + 3] = make_float4(t[tq].w, t[4 + tq].w, t[8 + tq].w, t[12 + tq].w);
+        }
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + cq * 4);
+    __syncthreads();
+    if (pg >= groups) return;
+    const size_t mrow = ((size_t)b * Hout + oy) * Hout;
+    for (int ox = pg; ox < Hout; ox += groups) {
+        float4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const float xv = xs[ky * Hin + ox * s + kx];
+                const float4 wv = wr[ky * 4 + kx];
+                acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y); acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+            }
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        if (out_bf16) {
+            bf16x4 o;
+            o[0] = (__bf16)acc.x; o[1] = (__bf16)acc.y; o[2] = (__bf16)acc.z; o[3] = (__bf16)acc.w;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (mrow + ox) * Cout + cq * 4) = o;
+        } else {
+            *reinterpret_cast<float4*>(out + (mrow + ox) * Cout + cq * 4) = acc;
+        }
+    }
+}
+
 int misc_conv0_fwd(const float* xp, const float* w, const float* bias, float* out, int B, int Hin, int C, int k, int s, int Hout,
                    int Cout, int out_bf16, hipStream_t st) {
     if (Cout % 4) return SPAIR_ERR_ALIGN;
+    if (C == 1 && k == 4 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0 && B <= 65535 && (size_t)4 * Hin * sizeof(float) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_conv0_fwd_c1k4, dim3(Hout, B), dim3(256), (size_t)4 * Hin * sizeof(float), st, xp, w, bias, out, Hin, s,
+                           Hout, Cout, out_bf16);
+        SPAIR_CHECK_LAUNCH();
+        return SPAIR_OK;
+    }
     const size_t lds = (size_t)k * k * C * Cout * sizeof(float);
     if (lds > 64 * 1024) return SPAIR_ERR_UNSUPPORTED;
     const long long total = (long long)B * Hout * Hout * (Cout / 4);
