@@ -95,6 +95,25 @@ int spair_gemm_nt_conv(const float* In, const int* conv13, const void* B, int ld
 int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
                        int N, int R, int dtype, void* stream);
 int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
+/* bf16-STORED operand GEMMs (the bf16 mode's activations and gradients live in HBM as bf16; same roles as above).
+ * spair_gemm_nt16: C = epi(A * B^T), A bf16 [M][lda] or an NHWC conv gather (conv13), B bf16 [N][ldb], C bf16 (c_bf16)
+ *   or fp32; relu_mask bf16 (mask_bf16) or fp32; cmap8 remaps output rows (stride-2 conv data gradient by parity class).
+ * spair_gemm_tn16: C += A^T * B over R rows, A bf16 [R][lda], B bf16 rows / bf16 or fp32 conv gather; cw_cin/cw_taps store
+ *   columns in OIHW order; colsum_out += column sums of A (bias gradient).  scratch (optional, >= blocks*128*128 floats):
+ *   split-K partial tiles + a reduce pass instead of fp32 atomics (modules.py:59-64,124-165 autograd). */
+int spair_gemm_nt16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                    const float* bias, const void* relu_mask, int ldmask, int mask_bf16, int relu, int c_bf16,
+                    const int* conv13, const int* cmap8, void* stream);
+int spair_gemm_tn16(const void* A, int lda, const void* B, int ldb, int b_bf16, float* C, int ldc, int M, int N,
+                    int R, const int* conv13, int cw_cin, int cw_taps, float* colsum_out, float* scratch,
+                    long long scratch_floats, void* stream);
+/* weight + bias gradient of the single-channel 4x4 stem conv with 128 filters (Backbone layer 0, modules.py:59-64):
+ * dY bf16 [B*Hout*Hout][128], xpad fp32 [B][Hin][Hin]; dW [128][1][4][4] and db [128] are accumulated;
+ * scratch >= 512*128*32 floats */
+int spair_stem_wgrad16(const void* dY, const float* xpad, float* dW, float* db, float* scratch,
+                       long long scratch_floats, int B, int Hin, int stride, int Hout, void* stream);
+/* fp32 [rows][ld_src] -> bf16 [rows][ld_dst] (round to nearest even), first `cols` columns */
+int spair_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long long rows, int cols, void* stream);
 /* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);
  * row r samples image x[r % B], nbox[r] = (xt,yt,xs,ys) */
 int spair_stn_glimpse_fwd(const float* x, const float* nbox, int B, float* glimpse, int ld_gl, int R, int C,

@@ -569,8 +569,13 @@ static int backbone_bwd16(Ctx& c, float* grads) {
         const ConvSpec& c0 = c.PL.conv[0];
         const ConvDesc cd = fwd_desc(c0);
         const int K = c0.k * c0.k * c0.cin;
-        TRY(tn16(c, c.w.dact[0], c0.cout, c0.cout, c.w.xpad, 0, K, false, grads + c0.w, K, d.B * c0.hout * c0.hout, grads + c0.b, &cd, c0.cin,
-                 c0.k * c0.k));
+        if (c0.cin == 1 && c0.k == 4 && c0.cout == 128) {
+            TRY(spair_stem_wgrad16_impl(c.w.dact[0], c.w.xpad, grads + c0.w, grads + c0.b, c.w.tn_part, SPAIR_TN_PART_FLOATS, d.B, c0.hin,
+                                        c0.s, c0.hout, c.s));
+        } else {
+            TRY(tn16(c, c.w.dact[0], c0.cout, c0.cout, c.w.xpad, 0, K, false, grads + c0.w, K, d.B * c0.hout * c0.hout, grads + c0.b, &cd,
+                     c0.cin, c0.k * c0.k));
+        }
     }
     return SPAIR_OK;
 }

@@ -517,6 +517,128 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient (single input channel, 4x4 kernel, 128 output channels):
+//   dW[co][t] += sum_m dY[m][co] * patch(m)[t],   db[co] += sum_m dY[m][co]
+// is a [128 x 16] GEMM over 1.25 M pixels -- through the generic 128x128 TN tile 7/8 of the B gather and of the MFMAs
+// would be padding.  Here a workgroup streams its pixel range in chunks of 32: dY rows (bf16, 256 B each) go to LDS as
+// they are, the 32x16 patch values are gathered from the padded fp32 input and stored as bf16 with a 17th column of
+// ones (the bias gradient rides along as one more output column), both operands are read back as transposed fragments.
+// HBM bound on the single read of dY.  Partials per workgroup, summed by k_stem_wgrad_reduce (no atomics).
+// ---------------------------------------------------------------------------------------------
+#define STEM_NB 512
+__global__ __launch_bounds__(256) void k_stem_wgrad16(const __bf16* __restrict__ dY, const float* __restrict__ xp, float* __restrict__ part,
+                                                      int B, int Hin, int s, int Hout, long long M, int chunks_per_block) {
+    constexpr int CO = 128, LDA = CO + 8, LDB = 32 + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][32 * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][32 * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m_begin = (long long)blockIdx.x * chunks_per_block * 32;
+    const long long m_end = min(M, m_begin + (long long)chunks_per_block * 32);
+    // constant part of B: column 16 = 1 (bias gradient), 17..31 = 0
+    for (int i = tid; i < 2 * 32 * 16; i += 256) {
+        const int bufi = i >> 9, r = (i >> 4) & 31, cI = 16 + (i & 15);
+        Bs[bufi][r * LDB + cI] = (__bf16)((i & 15) == 0 ? 1.f : 0.f);
+    }
+    // A loader: thread -> (row = tid>>3, 16 channels at (tid&7)*16)
+    const int a_row = tid >> 3, a_c = (tid & 7) * 16;
+    // B loader: thread -> (pixel = tid>>3, taps 2*(tid&7), +1): same ky, kx = even
+    const int b_px = tid >> 3, b_t = (tid & 7) * 2, b_ky = b_t >> 2, b_kx = b_t & 3;
+    // running (b, oy, ox) of this thread's pixel
+    long long mp = m_begin + b_px;
+    int pb = (int)(mp / ((long long)Hout * Hout));
+    int prem = (int)(mp - (long long)pb * Hout * Hout);
+    int poy = prem / Hout, pox = prem - poy * Hout;
+    uint4 ra0, ra1;
+    float rb0, rb1;
+    auto load = [&](long long m0) {
+        const long long ma = m0 + a_row;
+        if (ma < M) {
+            const uint4* src = reinterpret_cast<const uint4*>(dY + (size_t)ma * CO + a_c);
+            ra0 = src[0]; ra1 = src[1];
+        } else {
+            ra0 = make_uint4(0, 0, 0, 0); ra1 = ra0;
+        }
+        const int bb = min(pb, B - 1);                  // tail pixels: any finite value (their dY rows are zero)
+        const float* row = xp + ((size_t)bb * Hin + poy * s + b_ky) * Hin + pox * s + b_kx;
+        rb0 = row[0]; rb1 = row[1];
+        pox += 32;
+        while (pox >= Hout) { pox -= Hout; ++poy; }
+        while (poy >= Hout) { poy -= Hout; ++pb; }
+    };
+    auto store = [&](int buf) {
+        *reinterpret_cast<uint4*>(&As[buf][a_row * LDA + a_c]) = ra0;
+        *reinterpret_cast<uint4*>(&As[buf][a_row * LDA + a_c + 8]) = ra1;
+        __bf16 v[2] = {(__bf16)rb0, (__bf16)rb1};
+        *reinterpret_cast<unsigned*>(&Bs[buf][b_px * LDB + b_t]) = *reinterpret_cast<unsigned*>(v);
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m_begin < m_end) {
+        load(m_begin);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long m0 = m_begin; m0 < m_end; m0 += 32) {
+            const bool more = (m0 + 32) < m_end;
+            if (more) load(m0 + 32);
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = lds_tr_frag16(As[buf], LDA, wave * 32 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = lds_tr_frag16(Bs[buf], LDB, j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (more) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    float* pt = part + (size_t)blockIdx.x * CO * 32;
+    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pt[(wave * 32 + i * 16 + rgrp + r) * 32 + j * 16 + col_l] = acc[i][j][r];
+}
+// dW[co][0..15] += sum_blocks part[blk][co][0..15]; db[co] += sum_blocks part[blk][co][16].  Workgroup = one channel.
+__global__ __launch_bounds__(256) void k_stem_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ dW,
+                                                           float* __restrict__ db) {
+    __shared__ float red[8][32];
+    const int co = blockIdx.x, n = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float t = 0.f;
+    for (int blk = grp; blk < nblk; blk += 8) t += part[((size_t)blk * 128 + co) * 32 + n];
+    red[grp][n] = t;
+    __syncthreads();
+    if (grp != 0 || n > 16) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += red[q][n];
+    if (n < 16) dW[co * 16 + n] += v;
+    else if (db) db[co] += v;
+}
+int spair_stem_wgrad16_impl(const void* dY, const float* xp, float* dW, float* db, float* part, long long part_cap, int B, int Hin,
+                            int s_, int Hout, hipStream_t s) {
+    const long long M = (long long)B * Hout * Hout;
+    if (part == nullptr || part_cap < (long long)STEM_NB * 128 * 32) return SPAIR_ERR_UNSUPPORTED;
+    if ((Hout - 1) * s_ + 4 > Hin) return SPAIR_ERR_SHAPE;
+    const long long chunks = (M + 31) / 32;
+    const int nblk = (int)min((long long)STEM_NB, chunks);
+    const int cpb = (int)((chunks + nblk - 1) / nblk);
+    hipLaunchKernelGGL(k_stem_wgrad16, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const __bf16*>(dY), xp, part, B, Hin, s_, Hout, M, cpb);
+    SPAIR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(128), dim3(256), 0, s, part, nblk, dW, db);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
 // A bf16 [R][lda]; B: bf16 (b_bf16) plain rows / conv gather, or fp32 conv gather / plain rows
 int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
@@ -585,8 +707,10 @@ extern "C" int spair_gemm_nt16(const void* A, int lda, const void* B, int ldb, v
 }
 
 extern "C" int spair_gemm_tn16(const void* A, int lda, const void* B, int ldb, int b_bf16, float* C, int ldc, int M, int N, int R,
-                               const int* conv13, int cw_cin, int cw_taps, float* colsum_out, void* stream) {
+                               const int* conv13, int cw_cin, int cw_taps, float* colsum_out, float* scratch, long long scratch_floats,
+                               void* stream) {
     GemmTN g{};
+    g.part = scratch; g.part_cap = scratch_floats;
     g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = reinterpret_cast<const float*>(B); g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = round_up(M, 8); g.N = round_up(N, b_bf16 ? 8 : 4); g.Mstore = M; g.Nstore = N; g.R = R; g.cw_cin = cw_cin; g.cw_taps = cw_taps;
     g.colsum_out = colsum_out;
@@ -596,4 +720,12 @@ extern "C" int spair_gemm_tn16(const void* A, int lda, const void* B, int ldb, i
         g.conv.sy = p[7]; g.conv.sx = p[8]; g.conv.dky = p[9]; g.conv.dkx = p[10]; g.conv.oy = p[11]; g.conv.ox = p[12];
     }
     return spair_gemm_tn16_impl(g, conv13 != nullptr, b_bf16 != 0, (hipStream_t)stream);
+}
+
+extern "C" int spair_stem_wgrad16(const void* dY, const float* xpad, float* dW, float* db, float* scratch, long long scratch_floats, int B,
+                                  int Hin, int stride, int Hout, void* stream) {
+    return spair_stem_wgrad16_impl(dY, xpad, dW, db, scratch, scratch_floats, B, Hin, stride, Hout, (hipStream_t)stream);
+}
+extern "C" int spair_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long long rows, int cols, void* stream) {
+    return spair_to_bf16(src, ld_src, dst, ld_dst, rows, cols, (hipStream_t)stream);
 }

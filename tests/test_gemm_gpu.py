@@ -184,14 +184,22 @@ def test_conv16_fwd_dgrad_wgrad(B, Hin, Cin, Cout, k, s):
     go16 = _bf(go.permute(0, 2, 3, 1).reshape(M, Cout)).cuda()
     dW = torch.zeros(Cout, Cin, k, k, device="cuda")
     db = torch.zeros(Cout, device="cuda")
-    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x16), 0, 1, L.ptr(dW), K, Cout, K, M, conv, Cin, k * k, L.ptr(db), L.stream()), "conv16 wgrad")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x16), 0, 1, L.ptr(dW), K, Cout, K, M, conv, Cin, k * k, L.ptr(db), None, 0, L.stream()), "conv16 wgrad")
     assert (dW.cpu() - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
     assert (db.cpu() - go.sum((0, 2, 3))).abs().max() <= 2e-3 * go.sum((0, 2, 3)).abs().max() + 1e-3
     # fp32 gather for B (first backbone layer style): same result
     x32 = x.permute(0, 2, 3, 1).contiguous().cuda()
     dW2 = torch.zeros(Cout, Cin, k, k, device="cuda")
-    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x32), 0, 0, L.ptr(dW2), K, Cout, K, M, conv, Cin, k * k, None, L.stream()), "conv16 wgrad f32 B")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x32), 0, 0, L.ptr(dW2), K, Cout, K, M, conv, Cin, k * k, None, None, 0, L.stream()), "conv16 wgrad f32 B")
     assert (dW2.cpu() - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
+    # split-K through partial tiles + reduce pass (what the training step uses) instead of atomics; accumulates into dW3
+    scratch = torch.empty(1536 * 128 * 128, device="cuda")
+    dW3 = torch.ones(Cout, Cin, k, k, device="cuda")
+    db3 = torch.zeros(Cout, device="cuda")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(go16), Cout, L.ptr(x16), 0, 1, L.ptr(dW3), K, Cout, K, M, conv, Cin, k * k, L.ptr(db3), L.ptr(scratch),
+                                    ctypes.c_longlong(scratch.numel()), L.stream()), "conv16 wgrad split-K reduce")
+    assert (dW3.cpu() - 1.0 - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
+    assert (db3.cpu() - go.sum((0, 2, 3))).abs().max() <= 2e-3 * go.sum((0, 2, 3)).abs().max() + 1e-3
     # data gradient by output-parity classes with relu mask and row remap
     if k == 4 and s == 2:
         mask = _bf(torch.randn(B, Hin, Hin, Cin, generator=g)).cuda()
@@ -215,7 +223,31 @@ def test_gemm_tn16_plain():
     A, B = _bf(torch.randn(R, M, generator=g)).cuda(), _bf(torch.randn(R, N, generator=g)).cuda()
     C = torch.zeros(M, N, device="cuda")
     cs = torch.zeros(M, device="cuda")
-    L.check(L.lib().spair_gemm_tn16(L.ptr(A), M, L.ptr(B), N, 1, L.ptr(C), N, M, N, R, None, 0, 0, L.ptr(cs), L.stream()), "tn16")
+    L.check(L.lib().spair_gemm_tn16(L.ptr(A), M, L.ptr(B), N, 1, L.ptr(C), N, M, N, R, None, 0, 0, L.ptr(cs), None, 0, L.stream()), "tn16")
     ref = A.float().cpu().double().t() @ B.float().cpu().double()
     assert (C.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
     assert (cs.cpu().double() - A.float().cpu().double().sum(0)).abs().max() <= 1e-4 * A.float().cpu().double().sum(0).abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("B,Hin", [(3, 142), (2, 54)])
+def test_stem_wgrad16_vs_torch(B, Hin):
+    """Backbone layer 0 (1 -> 128 channels, 4x4, stride 2): dedicated weight/bias gradient kernel vs torch autograd."""
+    L = _lib()
+    g = torch.Generator().manual_seed(Hin)
+    Cout, k, s = 128, 4, 2
+    Hout = (Hin - k) // s + 1
+    M = B * Hout * Hout
+    x = torch.rand(B, 1, Hin, Hin, generator=g)
+    go = _bf(torch.randn(B, Cout, Hout, Hout, generator=g)).float()
+    w = torch.zeros(Cout, 1, k, k, requires_grad=True)
+    torch.nn.functional.conv2d(_bf(x).float(), w, None, stride=s).backward(go)     # the kernel rounds the patches to bf16
+    go16 = _bf(go.permute(0, 2, 3, 1).reshape(M, Cout)).cuda()
+    xd = x.reshape(B, Hin, Hin).contiguous().cuda()
+    dW = torch.full((Cout, 1, k, k), 0.5, device="cuda")     # accumulated into
+    db = torch.zeros(Cout, device="cuda")
+    scratch = torch.empty(512 * 128 * 32, device="cuda")
+    L.check(L.lib().spair_stem_wgrad16(L.ptr(go16), L.ptr(xd), L.ptr(dW), L.ptr(db), L.ptr(scratch), ctypes.c_longlong(scratch.numel()),
+                                       B, Hin, s, Hout, L.stream()), "stem wgrad")
+    assert (dW.cpu() - 0.5 - w.grad).abs().max() <= 2e-3 * w.grad.abs().max()
+    ref_db = go.sum((0, 2, 3))
+    assert (db.cpu() - ref_db).abs().max() <= 2e-3 * ref_db.abs().max() + 1e-3
