@@ -43,7 +43,8 @@ typedef struct SpairStep {
     float count_prior_prob;    /* 1/(1+exp(-log(v+1e-6))), models.py:186-188 */
     float kl_scale;            /* 1/(B*world_size): batch-mean of the KL terms (models.py:553) */
     int train;                 /* 1: keep what backward needs */
-    int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps */
+    int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps;
+                                * bit 2: no helper stream (every kernel on the caller's stream) */
 } SpairStep;
 
 /* ---- parameter / workspace layout -------------------------------------------------------- */

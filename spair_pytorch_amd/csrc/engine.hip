@@ -313,6 +313,37 @@ struct Ctx {
     std::vector<int> dstart;
 };
 
+// ---- helper stream --------------------------------------------------------------------------------
+// Stages that do not depend on each other are issued on a second HIP stream (its own hardware queue) so that
+// latency-bound kernels (the per-sample chain: one workgroup per CU, the count-KL scan: one wave per sample) share the
+// chip with throughput kernels (weight-gradient GEMMs, decoder, renderer).  Fork/join is by events only, so the
+// caller's stream still sees the whole step in order and the step stays capturable in a hipGraph.
+// SpairStep.flags bit 2 disables it (everything on the caller's stream).
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[4];
+    int dev = -1;
+};
+static SideStream g_side;
+static int side_stream(SideStream*& out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    if (g_side.s == nullptr || g_side.dev != dev) {
+        if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        g_side.dev = dev;
+    }
+    out = &g_side;
+    return SPAIR_OK;
+}
+// everything enqueued on `to` after this call runs after everything enqueued on `from` before it
+static int stream_link(hipStream_t from, hipStream_t to, hipEvent_t e) {
+    if (hipEventRecord(e, from) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    if (hipStreamWaitEvent(to, e, 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    return SPAIR_OK;
+}
+
 static void fill_diag(Ctx& c) {
     const int G = c.d.G;
     c.T = 3 * G - 2;
@@ -705,6 +736,16 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     }
     { ProfScope ps(PS_BACKBONE_FWD, c.s); TRY(backbone_fwd(c)); }
     { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
+    // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer
+    SideStream* side = nullptr;
+    if (!(st->flags & 4)) TRY(side_stream(side));
+    {
+        hipStream_t ks = side ? side->s : c.s;
+        if (side) TRY(stream_link(c.s, ks, side->ev[0]));
+        { ProfScope ps(PS_COUNT_KL, ks); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, ks)); }
+        TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, ks));
+        if (side && hipEventRecord(side->ev[1], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    }
     // decoder (models.py:474-492)
     const ParamLayout& PL = c.PL;
     const int N = L.N;
@@ -734,14 +775,13 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         }
     }
     // KL + render + loss
-    { ProfScope ps(PS_COUNT_KL, c.s); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, c.s)); }
     {
         ProfScope ps(PS_RENDER_FWD, c.s);
         TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
                        c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s));
     }
+    if (side && hipStreamWaitEvent(c.s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
     ProfScope psl(PS_LOSS, c.s);
-    TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, c.s));
     TRY(loss_finalize(c.w.bce_partial, render_num_blocks(d->B, d->I), c.w.kl_partial, loss_gauss_kl_blocks(L), c.w.klp, d->B,
                       st->kl_scale, d->vae_beta, loss_out, c.s));
     return SPAIR_OK;
@@ -779,17 +819,25 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
                        d->alpha_logit_scale, b16, c.s));
     }
-    if (b16) {   // decoder, bf16-stored activations and gradients
-        ProfScope ps(PS_DECODER_BWD, c.s);
+    SideStream* side = nullptr;
+    if (!(st->flags & 4)) TRY(side_stream(side));
+    hipStream_t const main_s = c.s;
+    if (b16) {   // decoder, bf16-stored activations and gradients: the data-gradient chain stays on the caller's stream, the three
+                 // weight gradients go to the helper stream and overlap with the (latency-bound) per-cell backward chain
         const LinSpec &l2 = PL.lin[LIN_DEC2], &l1 = PL.lin[LIN_DEC1], &l0 = PL.lin[LIN_DEC0];
+        {
+            ProfScope ps(PS_DECODER_BWD, c.s);
+            { ProfScope p2(PS_DEC2_DGRAD, c.s);
+              TRY(nt16(c, c.w.dLog, c.w.ld_s, c.w.lin_wt[LIN_DEC2], round_up(per, 8), c.w.dHd2, SP_DEC_H2, 1, N, SP_DEC_H2, round_up(per, 8), nullptr,
+                       c.w.Hd2, SP_DEC_H2, 0)); }
+            TRY(nt16(c, c.w.dHd2, SP_DEC_H2, c.w.lin_wt[LIN_DEC1], SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 1, N, SP_DEC_H1, SP_DEC_H2, nullptr, c.w.Hd1, SP_DEC_H1, 0));
+            TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
+        }
+        if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; }
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
-        { ProfScope p2(PS_DEC2_DGRAD, c.s);
-          TRY(nt16(c, c.w.dLog, c.w.ld_s, c.w.lin_wt[LIN_DEC2], round_up(per, 8), c.w.dHd2, SP_DEC_H2, 1, N, SP_DEC_H2, round_up(per, 8), nullptr,
-                   c.w.Hd2, SP_DEC_H2, 0)); }
         TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
-        TRY(nt16(c, c.w.dHd2, SP_DEC_H2, c.w.lin_wt[LIN_DEC1], SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 1, N, SP_DEC_H1, SP_DEC_H2, nullptr, c.w.Hd1, SP_DEC_H1, 0));
         TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
-        TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
+        if (side) { if (hipEventRecord(side->ev[1], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH; c.s = main_s; }
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }
@@ -835,6 +883,8 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(cells_dfeat_edge(L, P, grads + PL.edge, c.s));
     }
     prof_end(ps_cells, c.s);
+    // the per-cell weight gradients (helper stream) and the backbone backward (caller's stream) both hang off the chain only
+    if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
     const int ps_wg = prof_begin(PS_CELLS_WGRAD, c.s);
     // weight gradients of the per-cell nets: one long-K GEMM per layer over all N rows
     TRY(wgrad_lin(c, LIN_BOX0, P.dHb1, SP_LDH, P.Xb, L.ld_xb, grads, N));
@@ -852,7 +902,13 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(wgrad_lin(c, LIN_OBJ1, P.dHo2, SP_LDH, P.Ho1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
     prof_end(ps_wg, c.s);
+    if (side) {
+        if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        c.s = main_s;
+        if (b16 && hipStreamWaitEvent(main_s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;   // split-K scratch is free again
+    }
     { ProfScope ps(PS_BACKBONE_BWD, c.s); TRY(backbone_bwd(c, grads)); }
+    if (side && hipStreamWaitEvent(main_s, side->ev[3], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // join
     return SPAIR_OK;
 }
 
