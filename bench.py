@@ -159,19 +159,38 @@ def main():
     h1 = (h0 - c1[0]) // c1[1] + 1
     conv1_flop = 2.0 * B * h1 * h1 * c1[2] * (c1[0] * c1[0] * d.conv_c[0])
     dec_out_flop = 2.0 * N * 256 * (P2 * 2)
+    # per-cell chain (k_chain_fwd / k_chain_bwd): arithmetic intensity ~50 flop/B, far left of the ridge (312 flop/B),
+    # so HBM is the roofline that bounds it.  Algorithmic bytes per row: what the kernel MUST move --
+    # forward: every layer input it has to keep for the weight-gradient GEMMs + latents/records + the glimpse derivative
+    # pairs; backward: relu masks + records + glimpse derivatives in, every layer-output gradient + d feat out.
+    A, NPc, Fc = d.A, d.NP, d.F
+    REC = 4 + A + 2                                                        # record [box4 | attr A | depth | pres]
+    box_in = Fc + 4 * REC                                                  # features + 4 neighbour records
+    z_in, glim = box_in + NPc + 4 + A, P2
+    o_in = z_in + 1
+    hid = 2 * 100 + (256 + 128) + 2 * 100 + 2 * 100                       # relu outputs of the four nets
+    fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)        # stores + (features, noise) loads
+    outs = (100 + 100 + 8 + NPc) + (256 + 128 + 2 * A) + (100 + 100 + 2 + NPc) + (100 + 100 + 1)
+    bwd_row = 4 * (hid + REC + glim + 32) + 4 * (outs + Fc)
+    chain_flop = 2.0 * N * (box_in * 100 + 100 * 100 + 100 * (8 + NPc) + glim * 256 + 256 * 128 + 128 * 2 * A
+                            + z_in * 100 + 100 * 100 + 100 * (2 + NPc) + o_in * 100 + 100 * 100 + 100)
     kernels = {}
 
-    def add(name, bound, work, unit_scale, peak, unit):
-        if name in avg and avg[name] > 0:
-            ach = work / (avg[name] * 1e-3) / unit_scale
-            kernels[name] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_ms=avg[name], traffic=None)
+    def add(name, bound, work, unit_scale, peak, unit, slot=None, **extra):
+        slot = slot or name
+        if slot in avg and avg[slot] > 0:
+            ach = work / (avg[slot] * 1e-3) / unit_scale
+            kernels[name] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_ms=avg[slot], traffic=None, **extra)
 
+    add("chain_bwd", "hbm", N * bwd_row, 1e9, HBM_PEAK_GBS, "GB/s", slot="cells_bwd", mfma_tflops=chain_flop / (avg.get("cells_bwd", 1) * 1e-3) / 1e12)
+    add("chain_fwd", "hbm", N * fwd_row, 1e9, HBM_PEAK_GBS, "GB/s", slot="cells_fwd", mfma_tflops=chain_flop / (avg.get("cells_fwd", 1) * 1e-3) / 1e12)
     add("render_fwd", "hbm", render_fwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
     add("render_bwd", "hbm", render_bwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
     add("conv1_fwd", "mfma", conv1_flop, 1e12, peak_f, "TFLOP/s")
     add("dec_out_fwd", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
     add("dec_out_dgrad", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
-    add("dec_out_wgrad", "mfma", dec_out_flop, 1e12, MFMA_PEAK_TFLOPS["f32"], "TFLOP/s")   # wgrad runs fp32 MFMA this round
+    # (decoder / per-cell weight gradients run on the helper stream beside the chain: their event times include the
+    #  overlap and are not per-kernel durations -- see profiles/ for the rocprofv3 kernel stats)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     roof = dict(kernels[dominant], kernel=dominant) if dominant else None
 

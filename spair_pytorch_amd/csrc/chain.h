@@ -18,5 +18,8 @@ struct ChainArgs {
 };
 
 int chain_fwd_supported(const SpairDims& d);
+// 1 when the fused forward kernel samples glimpses from an fp16 LDS copy of the image (the per-wavefront reference path then
+// rounds pixels the same way, so the two paths stay comparable to rounding level)
+int chain_image_fp16(const SpairDims& d);
 int chain_fwd(const ChainArgs& a, hipStream_t s);
 int chain_bwd(const ChainArgs& a, hipStream_t s);

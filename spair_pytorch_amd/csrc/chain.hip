@@ -119,7 +119,24 @@ __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restri
 
 }  // namespace
 
+// Everything a stage needs besides the streamed weights is in LDS before the stage starts: biases, the edge element, the
+// cell tables and (IMG) the sample's image are loaded once per workgroup, the next wavefront's features and noise are
+// fetched one wavefront ahead.  A global load inside a stage costs a full L2/HBM round trip on the critical path of a
+// 46 x 19-stage dependent chain (measured ~0.5-1 us per stage) and, gfx9 counting loads and stores on one in-order
+// counter, also drains the weight ring.
+constexpr int BIAS_OFF[CW_COUNT] = {0, 112, 224, 336, 592, 720, 832, 944, 1056, 1168, 1280, 1392};
+constexpr int BIAS_CNT[CW_COUNT] = {100, 100, NP + 8, 256, 128, 2 * A_, 100, 100, NP + 2, 100, 100, 1};
+constexpr int BIAS_TOT = 1408;
+constexpr int IMG_MAX = 128;              // side of the largest image staged in LDS (fp16)
+
+template <bool IMG>
 __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float bias_sh[BIAS_TOT];
+    __shared__ __attribute__((aligned(16))) float edge_sh[REC];
+    __shared__ __attribute__((aligned(16))) float feat_sh[MT][F];
+    __shared__ __attribute__((aligned(16))) float noise_sh[MT][REC];      // [eps_box 4 | eps_attr A | eps_depth | u_pres]
+    __shared__ unsigned short cell_hw[32 * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 img_sh[IMG ? IMG_MAX * IMG_MAX : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Xc[MT * LD_XC];
     __shared__ __attribute__((aligned(16))) __bf16 XtZ[MT * LD_XT];
     __shared__ __attribute__((aligned(16))) __bf16 XtO[MT * LD_XT];
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ float nb_sh[MT][4];
     __shared__ int row_r[MT], row_h[MT], row_w[MT], row_cp[MT];
     __shared__ int dstart_sh[3 * 32 + 2];
-    __shared__ int nbr_sh[32 * 32 * 4];
+    __shared__ short nbr_sh[32 * 32 * 4];
 
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
@@ -148,8 +165,61 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     for (int i = tid; i < MT * LD_H; i += NTH) { Ha[i] = (__bf16)0.f; Hb[i] = (__bf16)0.f; }
     for (int i = tid; i < MT * LD_O; i += NTH) Ost[i] = 0.f;
     for (int i = tid; i <= T; i += NTH) dstart_sh[i] = P.diag_start[i];
-    for (int i = tid; i < L.HW * 4; i += NTH) nbr_sh[i] = P.nbr[i];
+    for (int i = tid; i < L.HW * 4; i += NTH) nbr_sh[i] = (short)P.nbr[i];
+    for (int i = tid; i < L.HW; i += NTH) cell_hw[i] = (unsigned short)((P.cell_h[i] << 8) | P.cell_w[i]);
+    for (int i = tid; i < REC; i += NTH) edge_sh[i] = P.edge[i];
+#pragma unroll
+    for (int l = 0; l < CW_COUNT; ++l)
+        for (int i = tid; i < BIAS_CNT[l]; i += NTH) bias_sh[BIAS_OFF[l] + i] = a.bias[l][i];
+    if constexpr (IMG) {
+        const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)b * a.I * a.I);
+        for (int i = tid; i < a.I * a.I / 4; i += NTH) {
+            const float4 v = src[i];
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<h4*>(&img_sh[i * 4]) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        }
+    }
     __syncthreads();
+
+    // features and noise of wavefront tn, fetched into registers one wavefront ahead and parked in LDS at the end of the
+    // current one: thread -> (row, 4 features) and 2 x (row, noise slot)
+    float4 pf_feat = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pf_noise[2] = {0.f, 0.f};
+    auto prefetch = [&](int tn, int tidv) {
+        const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
+        if (tidv < MT * (F / 4)) {
+            const int row = tidv / (F / 4), c4 = (tidv - row * (F / 4)) * 4;
+            const int hw = cell_hw[c0n + min(row, ncn - 1)];
+            pf_feat = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + (hw >> 8)) * G + (hw & 255)) * P.ld_feat + c4);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tidv + q * NTH;
+            if (i < MT * REC) {
+                const int row = i / REC, j = i - row * REC;
+                const int hw = cell_hw[c0n + min(row, ncn - 1)];
+                const size_t cell = (size_t)(hw >> 8) * G + (hw & 255);
+                const float* src = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
+                                   : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
+                                   : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
+                                                 : P.u_pres + (size_t)b * G * G;
+                pf_noise[q] = src[cell];
+            }
+        }
+    };
+    auto park = [&](int tidv) {
+        if (tidv < MT * (F / 4)) {
+            const int row = tidv / (F / 4), c4 = (tidv - row * (F / 4)) * 4;
+            *reinterpret_cast<float4*>(&feat_sh[row][c4]) = pf_feat;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tidv + q * NTH;
+            if (i < MT * REC) noise_sh[i / REC][i % REC] = pf_noise[q];
+        }
+    };
+    prefetch(0, tid);
+    park(tid);
 
     WPipe pipe;
     pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
@@ -167,12 +237,14 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         float (*rec_cur)[REC] = recs[t & 3];
         if (tid < MT) {
             const int cp = c0 + min(tid, nc - 1);
+            const int hw = cell_hw[cp];
             row_cp[tid] = cp;
             row_r[tid] = cp * L.B + b;
-            row_h[tid] = P.cell_h[cp];
-            row_w[tid] = P.cell_w[cp];
+            row_h[tid] = hw >> 8;
+            row_w[tid] = hw & 255;
         }
-        lds_barrier();
+        lds_barrier();                       // also orders park() of the previous wavefront before S0's reads
+        prefetch(min(t + 1, T - 1), tid);
         CH_STAMP();
         // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread
         for (int idx = tid; idx < MT * (KC / 4); idx += NTH) {
@@ -180,7 +252,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < nc && c4 < F + CTX) {
                 if (c4 < F) {
-                    v = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + c4);
+                    v = *reinterpret_cast<const float4*>(&feat_sh[row][c4]);
                 } else {
                     const int s = (c4 - F) / REC, j = (c4 - F) - s * REC;
                     const int nbc = nbr_sh[row_cp[row] * 4 + s];
@@ -188,7 +260,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                         const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);      // UL: t-3, U: t-2, UR and L: t-1
                         v = *reinterpret_cast<const float4*>(&recs[(t - dt) & 3][nbc - dstart_sh[t - dt]][j]);
                     } else {
-                        v = *reinterpret_cast<const float4*>(P.edge + j);
+                        v = *reinterpret_cast<const float4*>(&edge_sh[j]);
                     }
                 }
                 const size_t r = row_r[row];
@@ -207,7 +279,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -215,7 +287,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -223,7 +295,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, acc, wave, lane);
             pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
-            wg_store<7, false>(acc, a.bias[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -239,7 +311,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             const size_t r = row_r[tid];
             float eps[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) eps[k] = P.eps_box[(((size_t)b * 4 + k) * G + h) * G + w];
+            for (int k = 0; k < 4; ++k) eps[k] = noise_sh[tid][k];
             const BoxFwd o = box_forward(&Ost[tid * LD_O + NP], eps, H, h, w);
             float* st = P.stat + r * SP_LDSTAT;
 #pragma unroll
@@ -265,12 +337,15 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             const int i = e / a.Pp, j0 = e - i * a.Pp;          // P % 4 == 0: the 4 elements share the row i
             float iy, my;
             stn_src_coord(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, i, a.Pp, a.I, a.ac, true, iy, my);
-            const float* img = a.x + (size_t)b * a.I * a.I;
             const int y0 = (int)floorf(iy);
             const float wy1 = iy - (float)y0, wy0 = 1.f - wy1;
             const bool yin = (y0 + 1) < a.I;
-            const float* r0p = img + y0 * a.I;
-            const float* r1p = img + (yin ? y0 + 1 : y0) * a.I;
+            const int r0o = y0 * a.I, r1o = (yin ? y0 + 1 : y0) * a.I;
+            const float* img = a.x + (size_t)b * a.I * a.I;
+            auto px = [&](int o) -> float {
+                if constexpr (IMG) return (float)img_sh[o];
+                else return img[o];
+            };
             float out[4];
             unsigned int gxy[4];
 #pragma unroll
@@ -281,7 +356,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const float wx1 = ix - (float)x0, wx0 = 1.f - wx1;
                 const int x1 = ((x0 + 1) < a.I) ? x0 + 1 : x0;
                 const float m1 = ((x0 + 1) < a.I) ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
-                const float v00 = r0p[x0], v01 = m1 * r0p[x1], v10 = n1 * r1p[x0], v11 = m1 * n1 * r1p[x1];
+                const float v00 = px(r0o + x0), v01 = m1 * px(r0o + x1), v10 = n1 * px(r1o + x0), v11 = m1 * n1 * px(r1o + x1);
                 out[q] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
                 // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
                 const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
@@ -304,8 +379,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<25, 16, 8>(a.w[CW_ENC0], pipe, wave, lane);
             wg_gemm<25, 0, 16, 8>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store<16, true, 0>(acc0, a.bias[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
-            wg_store<16, true, 8>(acc1, a.bias[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
+            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
+            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -313,7 +388,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
-            wg_store<8, true>(acc, a.bias[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane);
+            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -321,7 +396,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
-            wg_store<7, false>(acc, a.bias[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -329,7 +404,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         for (int idx = tid; idx < nc * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
             const size_t r = row_r[row];
-            const float eps = P.eps_attr[(((size_t)b * A_ + j) * G + row_h[row]) * G + row_w[row]];
+            const float eps = noise_sh[row][4 + j];
             float sd, attr;
             attr_forward(Ost[row * LD_O + j], Ost[row * LD_O + A_ + j], eps, sd, attr);
             rec_cur[row][4 + j] = attr;
@@ -348,7 +423,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -356,7 +431,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -364,7 +439,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
-            wg_store<7, false>(acc, a.bias[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -377,7 +452,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
             const size_t r = row_r[tid];
-            const float eps = P.eps_depth[((size_t)b * G + h) * G + w];
+            const float eps = noise_sh[tid][4 + A_];
             float mu, sd, depth;
             depth_forward(Ost[tid * LD_O + NP], Ost[tid * LD_O + NP + 1], eps, H, mu, sd, depth);
             float* st = P.stat + r * SP_LDSTAT;
@@ -395,7 +470,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -403,7 +478,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, acc, wave, lane);
             pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
-            wg_store<7, true>(acc, a.bias[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -411,20 +486,21 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 1>(Hb, LD_H, nullptr, 0, a.w[CW_OBJ2], pipe, acc, wave, lane);
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
-            wg_store<1, false>(acc, a.bias[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
+            wg_store<1, false>(acc, bias_sh + BIAS_OFF[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
             const size_t r = row_r[tid];
-            const float u = P.u_pres[((size_t)b * G + h) * G + w];
+            const float u = noise_sh[tid][4 + A_ + 1];
             const float pres = pres_forward(Ost[tid * LD_O], u, H);
             rec_cur[tid][REC - 1] = pres;
             P.rec[r * L.ld_rec + REC - 1] = pres;
             P.z_pres[((size_t)b * G + h) * G + w] = pres;
         }
         lds_barrier();
+        park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
         CH_STAMP();
     }
 }
@@ -861,8 +937,11 @@ int chain_fwd_supported(const SpairDims& d) {
            (d.G + 1) / 2 <= MT && d.G >= 2;
 }
 
+int chain_image_fp16(const SpairDims& d) { return chain_fwd_supported(d) && d.I <= IMG_MAX && (d.I * d.I) % 4 == 0; }
+
 int chain_fwd(const ChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_fwd, dim3(a.L.B), dim3(NTH), 0, s, a);
+    if (a.I <= IMG_MAX && (a.I * a.I) % 4 == 0) hipLaunchKernelGGL(k_chain_fwd<true>, dim3(a.L.B), dim3(NTH), 0, s, a);
+    else hipLaunchKernelGGL(k_chain_fwd<false>, dim3(a.L.B), dim3(NTH), 0, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

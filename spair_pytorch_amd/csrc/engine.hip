@@ -13,8 +13,8 @@
 #include "chain.h"
 
 // kernels in other translation units
-int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, hipStream_t s);
-int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, int ld, float* dnbox, int r0, int R, int C, int I, int P, int ac, hipStream_t s);
+int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, int px16, hipStream_t s);
+int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, int ld, float* dnbox, int r0, int R, int C, int I, int P, int ac, int px16, hipStream_t s);
 int render_sprite_act(float* S, int ld, int N, int per, int CH, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);
 int render_num_blocks(int B, int I);
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s);
@@ -701,7 +701,7 @@ static int cells_fwd(Ctx& c) {
         TRY(fwd_lin(c, LIN_BOXH1, P.Hb2, SP_LDH, P.Ob, L.ld_ob, r0, R, c.w.bias_boxh, L.NP + 8, 0));
         TRY(cells_box_sample(L, P, c.H, r0, R, c.s));
         // z_what
-        { ProfScope ps(PS_STN_FWD, c.s); TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, c.s)); }
+        { ProfScope ps(PS_STN_FWD, c.s); TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, chain_image_fp16(c.d), c.s)); }
         TRY(fwd_lin(c, LIN_ENC0, P.glimpse, L.ld_gl, P.He1, SP_ENC_H1, r0, R, pr + PL.lin[LIN_ENC0].b, SP_ENC_H1, 1));
         TRY(fwd_lin(c, LIN_ENC1, P.He1, SP_ENC_H1, P.He2, SP_ENC_H2, r0, R, pr + PL.lin[LIN_ENC1].b, SP_ENC_H2, 1));
         TRY(fwd_lin(c, LIN_ENC2, P.He2, SP_ENC_H2, P.Oe, L.ld_oe, r0, R, pr + PL.lin[LIN_ENC2].b, 2 * L.A, 0));
@@ -874,7 +874,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         TRY(bwd_lin(c, LIN_ENC2, 2 * L.A, P.dOe, L.ld_oe, P.dHe2, SP_ENC_H2, r0, R, P.He2, SP_ENC_H2));
         TRY(bwd_lin(c, LIN_ENC1, SP_ENC_H2, P.dHe2, SP_ENC_H2, P.dHe1, SP_ENC_H1, r0, R, P.He1, SP_ENC_H1));
         TRY(bwd_lin(c, LIN_ENC0, SP_ENC_H1, P.dHe1, SP_ENC_H1, P.dGl, L.ld_gl, r0, R, nullptr, 0));
-        TRY(stn_glimpse_bwd(x, P.nbox, L.B, P.dGl, L.ld_gl, P.g_nbox_stn, r0, R, d->C, d->I, d->P, d->align_corners, c.s));
+        TRY(stn_glimpse_bwd(x, P.nbox, L.B, P.dGl, L.ld_gl, P.g_nbox_stn, r0, R, d->C, d->I, d->P, d->align_corners, chain_image_fp16(*d), c.s));
         TRY(cells_bwd_box(L, P, c.H, r0, R, c.s));
         TRY(bwd_lin(c, LIN_BOXH1, L.NP + 8, P.dOb, L.ld_ob, P.dHb2, SP_LDH, r0, R, P.Hb2, SP_LDH));
         TRY(bwd_lin(c, LIN_BOX1, SP_H, P.dHb2, SP_LDH, P.dHb1, SP_LDH, r0, R, P.Hb1, SP_LDH));

@@ -6,9 +6,12 @@
 #include "stn_math.h"
 
 // one thread per glimpse element; row r reads image b = r % B
+// px16: round every pixel through fp16 first -- what the fused per-cell kernel (bf16 mode) sees from its LDS copy of the image
+__device__ __forceinline__ float stn_px(const float* img, int o, int px16) { const float v = img[o]; return px16 ? (float)(_Float16)v : v; }
+
 __global__ __launch_bounds__(256) void k_stn_glimpse_fwd(const float* __restrict__ x, const float* __restrict__ nbox, int B,
                                                          float* __restrict__ out, int ld, int r0, int R, int C, int I, int P,
-                                                         int ac) {
+                                                         int ac, int px16) {
     const int per = C * P * P;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)R * per) return;
@@ -24,17 +27,17 @@ __global__ __launch_bounds__(256) void k_stn_glimpse_fwd(const float* __restrict
     const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
     const float wx1 = ix - (float)x0, wy1 = iy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
     const bool xin = (x0 + 1) < I, yin = (y0 + 1) < I;   // x0,y0 are in [0, I-1] after the border clip
-    const float v00 = img[y0 * I + x0];
-    const float v01 = xin ? img[y0 * I + x0 + 1] : 0.f;
-    const float v10 = yin ? img[(y0 + 1) * I + x0] : 0.f;
-    const float v11 = (xin && yin) ? img[(y0 + 1) * I + x0 + 1] : 0.f;
+    const float v00 = stn_px(img, y0 * I + x0, px16);
+    const float v01 = xin ? stn_px(img, y0 * I + x0 + 1, px16) : 0.f;
+    const float v10 = yin ? stn_px(img, (y0 + 1) * I + x0, px16) : 0.f;
+    const float v11 = (xin && yin) ? stn_px(img, (y0 + 1) * I + x0 + 1, px16) : 0.f;
     out[(size_t)r * ld + e] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
 }
 
 // one 256-thread block per row: reduce d(xt,yt,xs,ys) over the C*P*P glimpse elements
 __global__ __launch_bounds__(256) void k_stn_glimpse_bwd(const float* __restrict__ x, const float* __restrict__ nbox, int B,
                                                          const float* __restrict__ dgl, int ld, float* __restrict__ dnbox,
-                                                         int r0, int C, int I, int P, int ac) {
+                                                         int r0, int C, int I, int P, int ac, int px16) {
     __shared__ float red[4];
     const int r = r0 + blockIdx.x, b = r % B;
     const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
@@ -49,10 +52,10 @@ __global__ __launch_bounds__(256) void k_stn_glimpse_bwd(const float* __restrict
         const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
         const float wx1 = ix - (float)x0, wy1 = iy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const bool xin = (x0 + 1) < I, yin = (y0 + 1) < I;
-        const float v00 = img[y0 * I + x0];
-        const float v01 = xin ? img[y0 * I + x0 + 1] : 0.f;
-        const float v10 = yin ? img[(y0 + 1) * I + x0] : 0.f;
-        const float v11 = (xin && yin) ? img[(y0 + 1) * I + x0 + 1] : 0.f;
+        const float v00 = stn_px(img, y0 * I + x0, px16);
+        const float v01 = xin ? stn_px(img, y0 * I + x0 + 1, px16) : 0.f;
+        const float v10 = yin ? stn_px(img, (y0 + 1) * I + x0, px16) : 0.f;
+        const float v11 = (xin && yin) ? stn_px(img, (y0 + 1) * I + x0 + 1, px16) : 0.f;
         const float g = dgl[(size_t)r * ld + e];
         const float gix = g * ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;   // d/d ix (pixel units) * d ix/d gx
         const float giy = g * ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
@@ -71,27 +74,27 @@ __global__ __launch_bounds__(256) void k_stn_glimpse_bwd(const float* __restrict
     }
 }
 
-int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac,
+int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, int px16,
                     hipStream_t s) {
     if (R <= 0) return SPAIR_ERR_SHAPE;
     const long long total = (long long)R * C * P * P;
-    hipLaunchKernelGGL(k_stn_glimpse_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, nbox, B, out, ld, r0, R, C, I, P, ac);
+    hipLaunchKernelGGL(k_stn_glimpse_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, nbox, B, out, ld, r0, R, C, I, P, ac, px16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
 int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, int ld, float* dnbox, int r0, int R, int C, int I,
-                    int P, int ac, hipStream_t s) {
+                    int P, int ac, int px16, hipStream_t s) {
     if (R <= 0) return SPAIR_ERR_SHAPE;
-    hipLaunchKernelGGL(k_stn_glimpse_bwd, dim3(R), dim3(256), 0, s, x, nbox, B, dgl, ld, dnbox, r0, C, I, P, ac);
+    hipLaunchKernelGGL(k_stn_glimpse_bwd, dim3(R), dim3(256), 0, s, x, nbox, B, dgl, ld, dnbox, r0, C, I, P, ac, px16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
 
 extern "C" int spair_stn_glimpse_fwd(const float* x, const float* nbox, int B, float* glimpse, int ld_gl, int R, int C, int I,
                                      int P, int align_corners, void* stream) {
-    return stn_glimpse_fwd(x, nbox, B, glimpse, ld_gl, 0, R, C, I, P, align_corners, (hipStream_t)stream);
+    return stn_glimpse_fwd(x, nbox, B, glimpse, ld_gl, 0, R, C, I, P, align_corners, 0, (hipStream_t)stream);
 }
 extern "C" int spair_stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dglimpse, int ld_gl, float* dnbox,
                                      int R, int C, int I, int P, int align_corners, void* stream) {
-    return stn_glimpse_bwd(x, nbox, B, dglimpse, ld_gl, dnbox, 0, R, C, I, P, align_corners, (hipStream_t)stream);
+    return stn_glimpse_bwd(x, nbox, B, dglimpse, ld_gl, dnbox, 0, R, C, I, P, align_corners, 0, (hipStream_t)stream);
 }
