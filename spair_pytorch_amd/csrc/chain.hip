@@ -574,8 +574,8 @@ __device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uin
 // overflow the 6-bit vmcnt counter, which serialises the wave) and parked in LDS as one byte per element.
 constexpr int MK_H = 112, MK_ROW = 5 * MK_H + 128 + 256;        // per-row mask bytes: Ho1 Hz2 Hz1 Hb2 Hb1 | He2 | He1
 constexpr int MK_HO1 = 0, MK_HZ2 = MK_H, MK_HZ1 = 2 * MK_H, MK_HB2 = 3 * MK_H, MK_HB1 = 4 * MK_H, MK_HE2 = 5 * MK_H, MK_HE1 = 5 * MK_H + 128;
-constexpr int MK_F4_ROW = 5 * 25 + 32 + 64;                     // float4 loads per row
-constexpr int MK_PER_THREAD = (MT * MK_F4_ROW + NTH - 1) / NTH;
+constexpr int MK_LOADS = 9;                                     // float4 loads per thread and wavefront
+static_assert(NTH == 512, "the mask prefetch maps 512 threads onto 16 rows");
 
 template <int KT, int NT>
 __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned char* mk, int ldh,
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ int cons_sh[MT][4], nbr_row[MT][4];
     __shared__ int dstart_sh[3 * 32 + 2];
+    __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
 
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
     const float ks = H.kl_scale * (*P.gloss);
+    if (tid < SP_H) wobj_sh[tid] = a.w_obj2[tid];
 
     for (int i = tid; i < MT * LD_H; i += NTH) { Aa[i] = (__bf16)0.f; Ab[i] = (__bf16)0.f; }
     for (int i = tid; i < 4 * MT * LD_R; i += NTH) (&ring[0][0][0])[i] = 0.f;
@@ -656,21 +658,24 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
-        float4 mkq[MK_PER_THREAD];
+        // One static, branch-free global_load per (layer, thread): a pointer picked from a runtime-indexed table degrades to FLAT
+        // loads behind a branch, and hipcc then waits vmcnt(0)+lgkmcnt(0) after every one of them (7 serialised HBM round trips,
+        // measured 6 us per wavefront).  Rows >= nc re-read row nc-1 (their masks are never used).
+        float4 mkq[MK_LOADS];
         {
-            const float* mbase[7] = {P.Ho1, P.Hz2, P.Hz1, P.Hb2, P.Hb1, P.He2, P.He1};
-            const int mld[7] = {SP_LDH, SP_LDH, SP_LDH, SP_LDH, SP_LDH, SP_ENC_H2, SP_ENC_H1};
-#pragma unroll
-            for (int q = 0; q < MK_PER_THREAD; ++q) {
-                const int idx = tid + q * NTH;
-                mkq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < MT * MK_F4_ROW) {
-                    const int row = idx / MK_F4_ROW, c = idx - row * MK_F4_ROW;
-                    const int layer = c < 125 ? c / 25 : (c < 157 ? 5 : 6);
-                    const int q4 = c < 125 ? c - layer * 25 : (c < 157 ? c - 125 : c - 157);
-                    if (row < nc) mkq[q] = *reinterpret_cast<const float4*>(mbase[layer] + (size_t)row_r[row] * mld[layer] + q4 * 4);
-                }
-            }
+            const int r100 = min(tid / 25, MT - 1), q100 = tid - (tid / 25) * 25;          // 100-wide layers: 16 x 25 float4
+            const size_t rr100 = (size_t)row_r[min(r100, nc - 1)];
+            mkq[0] = *reinterpret_cast<const float4*>(P.Ho1 + rr100 * SP_LDH + q100 * 4);
+            mkq[1] = *reinterpret_cast<const float4*>(P.Hz2 + rr100 * SP_LDH + q100 * 4);
+            mkq[2] = *reinterpret_cast<const float4*>(P.Hz1 + rr100 * SP_LDH + q100 * 4);
+            mkq[3] = *reinterpret_cast<const float4*>(P.Hb2 + rr100 * SP_LDH + q100 * 4);
+            mkq[4] = *reinterpret_cast<const float4*>(P.Hb1 + rr100 * SP_LDH + q100 * 4);
+            mkq[5] = *reinterpret_cast<const float4*>(P.Ho2 + rr100 * SP_LDH + q100 * 4);
+            const size_t rr128 = (size_t)row_r[min(tid >> 5, nc - 1)];                     // He2: 16 x 32 float4
+            mkq[6] = *reinterpret_cast<const float4*>(P.He2 + rr128 * SP_ENC_H2 + (tid & 31) * 4);
+            const size_t rr256a = (size_t)row_r[min(tid >> 6, nc - 1)], rr256b = (size_t)row_r[min(8 + (tid >> 6), nc - 1)];   // He1: 16 x 64
+            mkq[7] = *reinterpret_cast<const float4*>(P.He1 + rr256a * SP_ENC_H1 + (tid & 63) * 4);
+            mkq[8] = *reinterpret_cast<const float4*>(P.He1 + rr256b * SP_ENC_H1 + (tid & 63) * 4);
         }
         unsigned int gxy_pf[7][4];
 #pragma unroll
@@ -721,30 +726,36 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        // park the prefetched relu masks in LDS (one byte per element); first consumer is two stages away
-#pragma unroll
-        for (int q = 0; q < MK_PER_THREAD; ++q) {
-            const int idx = tid + q * NTH;
-            if (idx < MT * MK_F4_ROW) {
-                const int row = idx / MK_F4_ROW, c = idx - row * MK_F4_ROW;
-                const int layer = c < 125 ? c / 25 : (c < 157 ? 5 : 6);
-                const int q4 = c < 125 ? c - layer * 25 : (c < 157 ? c - 125 : c - 157);
-                const int off = (layer < 5 ? layer * MK_H : (layer == 5 ? MK_HE2 : MK_HE1)) + q4 * 4;
-                const unsigned int pk = (mkq[q].x > 0.f ? 1u : 0u) | (mkq[q].y > 0.f ? 0x100u : 0u) | (mkq[q].z > 0.f ? 0x10000u : 0u) |
-                                        (mkq[q].w > 0.f ? 0x1000000u : 0u);
-                *reinterpret_cast<unsigned int*>(&mk_sh[row * MK_ROW + off]) = pk;
+        // park the prefetched relu masks in LDS (one byte per element); first consumer is the next stage
+        {
+            auto pack = [](const float4& v) {
+                return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 0x100u : 0u) | (v.z > 0.f ? 0x10000u : 0u) | (v.w > 0.f ? 0x1000000u : 0u);
+            };
+            if (tid < MT * 25) {
+                const int row = tid / 25, q4 = tid - row * 25;
+                unsigned char* m = mk_sh + row * MK_ROW + q4 * 4;
+                *reinterpret_cast<unsigned int*>(m + MK_HO1) = pack(mkq[0]);
+                *reinterpret_cast<unsigned int*>(m + MK_HZ2) = pack(mkq[1]);
+                *reinterpret_cast<unsigned int*>(m + MK_HZ1) = pack(mkq[2]);
+                *reinterpret_cast<unsigned int*>(m + MK_HB2) = pack(mkq[3]);
+                *reinterpret_cast<unsigned int*>(m + MK_HB1) = pack(mkq[4]);
             }
+            *reinterpret_cast<unsigned int*>(mk_sh + (tid >> 5) * MK_ROW + MK_HE2 + (tid & 31) * 4) = pack(mkq[6]);
+            *reinterpret_cast<unsigned int*>(mk_sh + (tid >> 6) * MK_ROW + MK_HE1 + (tid & 63) * 4) = pack(mkq[7]);
+            *reinterpret_cast<unsigned int*>(mk_sh + (8 + (tid >> 6)) * MK_ROW + MK_HE1 + (tid & 63) * 4) = pack(mkq[8]);
         }
-        // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu
-        for (int idx = tid; idx < MT * SP_H; idx += NTH) {
-            const int row = idx / SP_H, n = idx - row * SP_H;
-            float v = 0.f;
-            if (row < nc) {
-                const size_t r = row_r[row];
-                v = (P.Ho2[r * SP_LDH + n] > 0.f) ? dOo_sh[row] * a.w_obj2[n] : 0.f;
-                P.dHo2[r * SP_LDH + n] = v;
-            }
-            Aa[row * LD_H + n] = (__bf16)v;
+        // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu: the thread that prefetched a float4 of Ho2 produces those 4
+        // elements (no LDS round trip for this mask)
+        if (tid < MT * 25) {
+            const int row = tid / 25, q4 = tid - row * 25;
+            const float4 w = *reinterpret_cast<const float4*>(&wobj_sh[q4 * 4]);
+            const float d = row < nc ? dOo_sh[row] : 0.f;
+            const float4 v = make_float4(mkq[5].x > 0.f ? d * w.x : 0.f, mkq[5].y > 0.f ? d * w.y : 0.f, mkq[5].z > 0.f ? d * w.z : 0.f,
+                                         mkq[5].w > 0.f ? d * w.w : 0.f);
+            if (row < nc) *reinterpret_cast<float4*>(P.dHo2 + (size_t)row_r[row] * SP_LDH + q4 * 4) = v;
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + q4 * 4]) = o;
         }
         lds_barrier();
         CB_STAMP();

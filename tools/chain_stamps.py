@@ -29,7 +29,7 @@ for i in range(19):
     print("%-8s %7.2f" % (names[i], d[:, i].mean() * tick_ns / 1e3))
 print("step-to-step (incl. loop overhead): %.2f us" % (np.diff(st[:, 0]).mean() * tick_ns / 1e3))
 
-NB = int(os.environ.get("NB_STAGES", "21"))
+NB = int(os.environ.get("NB_STAGES", "20"))
 out2 = torch.zeros(4096, dtype=torch.int64, device="cuda")
 L.check(L.lib().spair_chain_stamps(ctypes.byref(e["dims"]), L.ptr(e["workspace"]), L.ptr(out2), 4096, L.stream()), "stamps")
 sb = out2.cpu().numpy()[2048:2048 + T * NB].reshape(T, NB).astype(np.float64)
