@@ -574,7 +574,11 @@ __device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uin
 // overflow the 6-bit vmcnt counter, which serialises the wave) and parked in LDS as one byte per element.
 constexpr int MK_H = 112, MK_ROW = 5 * MK_H + 128 + 256;        // per-row mask bytes: Ho1 Hz2 Hz1 Hb2 Hb1 | He2 | He1
 constexpr int MK_HO1 = 0, MK_HZ2 = MK_H, MK_HZ1 = 2 * MK_H, MK_HB2 = 3 * MK_H, MK_HB1 = 4 * MK_H, MK_HE2 = 5 * MK_H, MK_HE1 = 5 * MK_H + 128;
-constexpr int MK_LOADS = 9;                                     // float4 loads per thread and wavefront
+constexpr int MK_LOADS = 9;
+// backward bundle row (floats): encoder output [mean A | logstd A] (104) | sd_attr (56) | g_attr from the decoder (56) | eps_attr (56)
+// | nbox 4 | g_nbox 4 | box logstd 4 | stat 12 | eps_box 4 | eps_depth, z_pres, g_pres, obj logit, g_depth, depth mean, depth logstd
+constexpr int BD_OE = 0, BD_SD = 104, BD_GA = 160, BD_EA = 216, BD_NB = 272, BD_GNB = 276, BD_OBL = 280, BD_ST = 284, BD_EB = 296,
+              BD_EPSD = 300, BD_ZP = 301, BD_GPR = 302, BD_OO = 303, BD_GDR = 304, BD_OZ0 = 305, BD_OZ1 = 306, BD_W = 308;                                     // float4 loads per thread and wavefront
 static_assert(NTH == 512, "the mask prefetch maps 512 threads onto 16 rows");
 
 template <int KT, int NT>
@@ -608,6 +612,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char mk_sh[MT * MK_ROW];
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ int cons_sh[MT][4], nbr_row[MT][4];
+    // per-row scalars and vectors of the wavefront, fetched one wavefront AHEAD with coalesced loads and parked here: no global
+    // load is left inside a stage (each one cost a full HBM round trip on the critical path: 1.5-3 us in the pres / depth / attr /
+    // box stages).  Row layout (floats): see BD_* below.
+    __shared__ __attribute__((aligned(16))) float bundle_sh[MT][BD_W];
+    __shared__ __attribute__((aligned(16))) int ibundle_sh[MT][8];           // consumers[4] | neighbours[4]
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
 
@@ -629,6 +638,56 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     if (tid < REC) edge_acc[tid] = 0.f;
     __syncthreads();
 
+    // ---- bundle prefetch: thread (row = tid>>5, l = tid&31) owns two 16-byte and two 4-byte items of that row.  Bases, strides
+    // and LDS slots are fixed per thread (computed once here); only the row index changes per wavefront.
+    const int brow = tid0 >> 5, bl = tid0 & 31;
+    const float *v0_base, *v1_base, *s1_base;
+    int v0_ld, v0_dst, v1_ld, v1_dst, v1_cp = 0, s1_stride, s1_dst, s1_row;
+    if (bl < 26) { v0_base = P.Oe + bl * 4; v0_ld = L.ld_oe; v0_dst = BD_OE + bl * 4; }
+    else { v0_base = P.sd_attr + (bl - 26) * 4; v0_ld = L.ld_rec; v0_dst = BD_SD + (bl - 26) * 4; }
+    if (bl < 8) { v1_base = P.sd_attr + (6 + bl) * 4; v1_ld = L.ld_rec; v1_dst = BD_SD + (6 + bl) * 4; }
+    else if (bl < 22) { v1_base = P.g_attr_r + (bl - 8) * 4; v1_ld = L.ld_rec; v1_dst = BD_GA + (bl - 8) * 4; }
+    else if (bl == 22) { v1_base = P.nbox; v1_ld = 4; v1_dst = BD_NB; }
+    else if (bl == 23) { v1_base = P.g_nbox_r; v1_ld = 4; v1_dst = BD_GNB; }
+    else if (bl == 24) { v1_base = P.Ob + NP + 4; v1_ld = L.ld_ob; v1_dst = BD_OBL; }
+    else if (bl < 28) { v1_base = P.stat + (bl - 25) * 4; v1_ld = SP_LDSTAT; v1_dst = BD_ST + (bl - 25) * 4; }
+    else if (bl == 28) { v1_base = reinterpret_cast<const float*>(P.cons); v1_ld = 4; v1_dst = 0; v1_cp = 1; }
+    else { v1_base = reinterpret_cast<const float*>(P.nbr); v1_ld = 4; v1_dst = 4; v1_cp = 1; }      // lanes 29..31 (30, 31 do not park)
+    const float* s0_base = P.eps_attr + ((size_t)b * A_ + bl) * G * G;                                  // eps_attr channel bl
+    const int s0_dst = BD_EA + bl;
+    if (bl < 18) { s1_base = P.eps_attr + ((size_t)b * A_ + 32 + bl) * G * G; s1_stride = 1; s1_row = 0; s1_dst = BD_EA + 32 + bl; }
+    else if (bl < 22) { s1_base = P.eps_box + ((size_t)b * 4 + (bl - 18)) * G * G; s1_stride = 1; s1_row = 0; s1_dst = BD_EB + (bl - 18); }
+    else if (bl == 22) { s1_base = P.eps_depth + (size_t)b * G * G; s1_stride = 1; s1_row = 0; s1_dst = BD_EPSD; }
+    else if (bl == 23) { s1_base = P.rec + (REC - 1); s1_stride = L.ld_rec; s1_row = 1; s1_dst = BD_ZP; }
+    else if (bl == 24) { s1_base = P.g_pres_r; s1_stride = 1; s1_row = 1; s1_dst = BD_GPR; }
+    else if (bl == 25) { s1_base = P.Oo; s1_stride = L.ld_oo; s1_row = 1; s1_dst = BD_OO; }
+    else if (bl == 26) { s1_base = P.g_depth_r; s1_stride = 1; s1_row = 1; s1_dst = BD_GDR; }
+    else if (bl == 27) { s1_base = P.Oz + NP; s1_stride = L.ld_oz; s1_row = 1; s1_dst = BD_OZ0; }
+    else { s1_base = P.Oz + NP + 1; s1_stride = L.ld_oz; s1_row = 1; s1_dst = BD_OZ1; }                 // lanes 28..31 (29..31 do not park)
+    float4 pf_v0, pf_v1;
+    float pf_s0, pf_s1;
+    auto hlo_of = [&](int tt) { return max(0, (tt - G + 2) >> 1); };       // first grid row on diagonal tt (cells ordered by h)
+    auto bundle_fetch = [&](int tn) {
+        const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
+        const int k = min(brow, ncn - 1);
+        const int cpn = c0n + k, h = hlo_of(tn) + k, w = tn - 2 * h;
+        const size_t rn = (size_t)cpn * L.B + b, cell = (size_t)h * G + w;
+        pf_v0 = *reinterpret_cast<const float4*>(v0_base + rn * v0_ld);
+        pf_v1 = *reinterpret_cast<const float4*>(v1_base + (v1_cp ? (size_t)cpn : rn) * v1_ld);
+        pf_s0 = s0_base[cell];
+        pf_s1 = s1_base[(s1_row ? rn : cell) * s1_stride];
+    };
+    auto bundle_park = [&]() {
+        *reinterpret_cast<float4*>(&bundle_sh[brow][v0_dst]) = pf_v0;
+        if (v1_cp) { if (bl < 30) *reinterpret_cast<float4*>(&ibundle_sh[brow][v1_dst]) = pf_v1; }
+        else *reinterpret_cast<float4*>(&bundle_sh[brow][v1_dst]) = pf_v1;
+        bundle_sh[brow][s0_dst] = pf_s0;
+        if (bl < 29) bundle_sh[brow][s1_dst] = pf_s1;
+    };
+    bundle_fetch(T - 1);
+    bundle_park();
+    __syncthreads();
+
     int stamp_j = 2048;
 #define CB_STAMP() do { if (a.stamps && b == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int t = T - 1; t >= 0; --t) {
@@ -640,21 +699,22 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         const int nc = dstart_sh[t + 1] - c0;
         float (*slot)[LD_R] = ring[t & 3];
         if (tid < MT) {
-            const int cp = c0 + min(tid, nc - 1);
-            const int r = cp * L.B + b;
-            row_r[tid] = r;
-            row_h[tid] = P.cell_h[cp];
-            row_w[tid] = P.cell_w[cp];
-            zp_sh[tid] = P.rec[(size_t)r * L.ld_rec + REC - 1];
+            const int k = min(tid, nc - 1);
+            const int cp = c0 + k, h = hlo_of(t) + k;
+            row_r[tid] = cp * L.B + b;
+            row_h[tid] = h;
+            row_w[tid] = t - 2 * h;
+            zp_sh[tid] = bundle_sh[tid][BD_ZP];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cons_sh[tid][k] = P.cons[cp * 4 + k];
-                nbr_row[tid][k] = P.nbr[cp * 4 + k];
-                nb_sh[tid][k] = P.nbox[(size_t)r * 4 + k];
-                gnb[tid][k] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                cons_sh[tid][q] = ibundle_sh[tid][q];
+                nbr_row[tid][q] = ibundle_sh[tid][4 + q];
+                nb_sh[tid][q] = bundle_sh[tid][BD_NB + q];
+                gnb[tid][q] = 0.f;
             }
         }
         lds_barrier();
+        bundle_fetch(max(t - 1, 0));         // next wavefront's bundle: in flight for the whole step, parked in the last stage
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
@@ -707,10 +767,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             const int row = tid >> 5, l = tid & 31;
             float kl = 0.f;
             if (row < nc) {
-                const size_t r = row_r[row];
-                const float* st = P.stat + r * SP_LDSTAT;
+                const float* bd = bundle_sh[row];
+                const float* st = bd + BD_ST;
                 for (int j = l; j < A_; j += 32)
-                    kl += kl_gauss(P.Oe[r * L.ld_oe + j], P.sd_attr[r * L.ld_rec + j], H.prior_mean[4], H.prior_std[4]);
+                    kl += kl_gauss(bd[BD_OE + j], bd[BD_SD + j], H.prior_mean[4], H.prior_std[4]);
                 if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], H.prior_mean[l], H.prior_std[l]);
                 if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], H.prior_mean[5], H.prior_std[5]);
             }
@@ -718,8 +778,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             for (int o = 16; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
             if (row < nc && l == 0) {
                 const size_t r = row_r[row];
-                const float d = pres_backward(grec[row][REC - 1] + P.g_pres_r[r], zp_sh[row], P.stat[r * SP_LDSTAT + ST_PZ], kl,
-                                              P.Oo[r * L.ld_oo], ks, H);
+                const float* bd = bundle_sh[row];
+                const float d = pres_backward(grec[row][REC - 1] + bd[BD_GPR], zp_sh[row], bd[BD_ST + ST_PZ], kl, bd[BD_OO], ks, H);
                 dOo_sh[row] = d;
                 P.dOo[r * L.ld_oo] = d;
             }
@@ -785,10 +845,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             float d_mu = 0.f, d_ls = 0.f;
             if (tid < nc) {
                 const size_t r = row_r[tid];
-                const float* st = P.stat + r * SP_LDSTAT;
-                const float eps = P.eps_depth[((size_t)b * G + row_h[tid]) * G + row_w[tid]];
-                const float g_depth = grec[tid][4 + A_] + tailO[tid][NP + 4 + A_] + P.g_depth_r[r];
-                depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], P.Oz[r * L.ld_oz + NP + 1], eps, zp_sh[tid], ks, H, d_mu, d_ls);
+                const float* bd = bundle_sh[tid];
+                const float* st = bd + BD_ST;
+                const float eps = bd[BD_EPSD];
+                const float g_depth = grec[tid][4 + A_] + tailO[tid][NP + 4 + A_] + bd[BD_GDR];
+                depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], bd[BD_OZ1], eps, zp_sh[tid], ks, H, d_mu, d_ls);
                 P.dOz[r * L.ld_oz + NP] = d_mu;
                 P.dOz[r * L.ld_oz + NP + 1] = d_ls;
             }
@@ -821,9 +882,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             float d_mean = 0.f, d_ls = 0.f;
             if (row < nc) {
                 const size_t r = row_r[row];
-                const float g = grec[row][4 + j] + tailZ[row][NP + 4 + j] + tailO[row][NP + 4 + j] + P.g_attr_r[r * L.ld_rec + j];
-                const float eps = P.eps_attr[(((size_t)b * A_ + j) * G + row_h[row]) * G + row_w[row]];
-                attr_backward(g, P.Oe[r * L.ld_oe + j], P.sd_attr[r * L.ld_rec + j], P.Oe[r * L.ld_oe + A_ + j], eps, zp_sh[row], ks, H, d_mean, d_ls);
+                const float* bd = bundle_sh[row];
+                const float g = grec[row][4 + j] + tailZ[row][NP + 4 + j] + tailO[row][NP + 4 + j] + bd[BD_GA + j];
+                attr_backward(g, bd[BD_OE + j], bd[BD_SD + j], bd[BD_OE + A_ + j], bd[BD_EA + j], zp_sh[row], ks, H, d_mean, d_ls);
                 P.dOe[r * L.ld_oe + j] = d_mean;
                 P.dOe[r * L.ld_oe + A_ + j] = d_ls;
             }
@@ -889,15 +950,16 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             float dlat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (tid < nc) {
                 const size_t r = row_r[tid];
-                const float* st = P.stat + r * SP_LDSTAT;
+                const float* bd = bundle_sh[tid];
+                const float* st = bd + BD_ST;
                 float gn[4], gb[4], eps[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    gn[k] = gnb[tid][k] + P.g_nbox_r[r * 4 + k];
+                    gn[k] = gnb[tid][k] + bd[BD_GNB + k];
                     gb[k] = grec[tid][k] + tailZ[tid][NP + k] + tailO[tid][NP + k];
-                    eps[k] = P.eps_box[(((size_t)b * 4 + k) * G + row_h[tid]) * G + row_w[tid]];
+                    eps[k] = bd[BD_EB + k];
                 }
-                box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, P.Ob + r * L.ld_ob + NP + 4, zp_sh[tid], ks, H, dlat);
+                box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, bd + BD_OBL, zp_sh[tid], ks, H, dlat);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) P.dOb[r * L.ld_ob + NP + k] = dlat[k];
             }
@@ -931,6 +993,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 if (nbr_row[row][s] < 0) atomicAdd(&edge_acc[(n - F) - s * REC], v);
             }
         }
+        bundle_park();                       // every reader of this wavefront's bundle is behind the BOX0 barrier
         lds_barrier();
         CB_STAMP();
     }
