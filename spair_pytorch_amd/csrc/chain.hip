@@ -619,6 +619,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) int ibundle_sh[MT][8];           // consumers[4] | neighbours[4]
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
+    __shared__ float prior_sh[12];          // prior mean[6] | std[6]: a lane-indexed read of the kernel-argument struct would be a
+                                            // global load + vmcnt(0) wait in the middle of the prefetch window
 
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
@@ -630,6 +632,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     const int G = L.G, T = 3 * G - 2;
     const float ks = H.kl_scale * (*P.gloss);
     if (tid < SP_H) wobj_sh[tid] = a.w_obj2[tid];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { prior_sh[i] = H.prior_mean[i]; prior_sh[6 + i] = H.prior_std[i]; }
+    }
 
     for (int i = tid; i < MT * LD_H; i += NTH) { Aa[i] = (__bf16)0.f; Ab[i] = (__bf16)0.f; }
     for (int i = tid; i < 4 * MT * LD_R; i += NTH) (&ring[0][0][0])[i] = 0.f;
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = (lane >> 4) * 4 + rr;
-                gxy_pf[j][rr] = (row < nc && e < GLN) ? P.gxy[(size_t)row_r[row] * L.ld_gl + e] : 0u;
+                gxy_pf[j][rr] = P.gxy[(size_t)row_r[min(row, nc - 1)] * L.ld_gl + min(e, GLN - 1)];     // branch-free; unused lanes re-read
             }
         }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
@@ -770,9 +776,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float* bd = bundle_sh[row];
                 const float* st = bd + BD_ST;
                 for (int j = l; j < A_; j += 32)
-                    kl += kl_gauss(bd[BD_OE + j], bd[BD_SD + j], H.prior_mean[4], H.prior_std[4]);
-                if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], H.prior_mean[l], H.prior_std[l]);
-                if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], H.prior_mean[5], H.prior_std[5]);
+                    kl += kl_gauss(bd[BD_OE + j], bd[BD_SD + j], prior_sh[4], prior_sh[6 + 4]);
+                if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], prior_sh[l], prior_sh[6 + l]);
+                if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], prior_sh[5], prior_sh[6 + 5]);
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
