@@ -123,7 +123,7 @@ struct Ws {
     CellBufs cb;
     float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;     // Hd*, dLog, dHd*: bf16 in bf16 mode
     void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
-    float* tn_part;                                     // split-K partial tiles of the weight-gradient GEMMs
+    float *tn_part, *tn_part2;                          // split-K partial tiles of the weight-gradient GEMMs (caller's / helper stream)
     float *aux, *bce_partial, *kl_partial, *klp;
     unsigned long long* stamps;
     int ld_feat, ld_s;
@@ -222,6 +222,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
     w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
     w.tn_part = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
+    w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
@@ -310,6 +311,7 @@ struct Ctx {
     hipStream_t s;
     int T;                 // number of wavefront diagonals
     int use_chain;         // fused persistent per-cell kernels (bf16, reference network sizes)
+    float* tn_scratch = nullptr;   // split-K scratch override while work is being issued on the helper stream
     std::vector<int> dstart;
 };
 
@@ -416,7 +418,7 @@ static int tn16(Ctx& c, const void* A, int lda, int M, const void* B, int ldb, i
     g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = reinterpret_cast<const float*>(B); g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = round_up(M, 8); g.N = round_up(N, b_bf16 ? 8 : 4); g.Mstore = M; g.Nstore = N; g.R = R; g.colsum_out = colsum;
     g.cw_cin = cw_cin; g.cw_taps = cw_taps;
-    g.part = c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
+    g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
     if (conv) g.conv = *conv;
     return spair_gemm_tn16_impl(g, conv != nullptr, b_bf16, c.s);
 }
@@ -833,11 +835,11 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
             TRY(nt16(c, c.w.dHd2, SP_DEC_H2, c.w.lin_wt[LIN_DEC1], SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 1, N, SP_DEC_H1, SP_DEC_H2, nullptr, c.w.Hd1, SP_DEC_H1, 0));
             TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
         }
-        if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; }
+        if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; c.tn_scratch = c.w.tn_part2; }
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
         TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
         TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
-        if (side) { if (hipEventRecord(side->ev[1], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH; c.s = main_s; }
+        if (side) { c.s = main_s; c.tn_scratch = nullptr; }
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }
@@ -905,7 +907,6 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     if (side) {
         if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
         c.s = main_s;
-        if (b16 && hipStreamWaitEvent(main_s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;   // split-K scratch is free again
     }
     { ProfScope ps(PS_BACKBONE_BWD, c.s); TRY(backbone_bwd(c, grads)); }
     if (side && hipStreamWaitEvent(main_s, side->ev[3], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // join
