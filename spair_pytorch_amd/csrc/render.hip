@@ -296,9 +296,6 @@ __global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S
                 pixel_of(wave, px, py);
                 avn = auxb[min(py, cy1) * I + min(px, PX1)];
             }
-#if defined(RB_EXP) && (RB_EXP & 4)
-            if (gl == 12345.f)
-#endif
             for (int j = wave; j < nj; j += RB_WAVES) {
                 const float4 av = avn;                                   // (dBCE/dpre, 1/D, pre, -)
                 int px, py;
@@ -347,9 +344,6 @@ __global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S
                     if (u >= tu1 || v >= tv1) continue;
                     const int ya = max(cy0, (int)floorf(((float)(v - 1) - sy0) * isy) + 1), ye = min(cy1, (int)ceilf(((float)(v + 1) - sy0) * isy) - 1);
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#if defined(RB_EXP) && (RB_EXP & 8)
-                    if (gl == 12345.f)
-#endif
                     for (int py = ya; py <= ye; ++py) {
                         float gdum;
                         const float wy = fmaxf(1.f - fabsf(src_from_base(ay, by, btab[py], P, ac, gdum) - (float)v), 0.f);

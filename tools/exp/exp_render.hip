@@ -1,4 +1,8 @@
-// Scratch timing harness for k_render_bwd variants (not part of the product).  hipcc -DRB_EXP=n
+// Stand-alone timing harness for k_render_bwd at BASELINE config-2 shapes (developer tool, not part of the product):
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ispair_pytorch_amd/csrc [-DRB_WAVES=n -DRB_CAP=n] tools/exp/exp_render.hip -o build/exp_rb
+#ifndef RB_EXP
+#define RB_EXP 0
+#endif
 #include "../../spair_pytorch_amd/csrc/render.hip"
 #include <cstdio>
 #include <vector>
