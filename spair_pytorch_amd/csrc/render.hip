@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     float num = 0.f, den = 0.f;
+    const float bX = stn_base(min(px, I - 1), I, ac), bY = stn_base(min(py, I - 1), I, ac);   // this pixel's base coordinate, once
     for (int k0 = 0; k0 < HW; k0 += RCH) {
         // ---- cull RCH objects against this tile
         const int k = k0 + threadIdx.x;
@@ -108,32 +109,47 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
         if (threadIdx.x == 0) ncand_sh = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
         const int nc = ncand_sh;
-        // ---- accumulate the surviving objects at this thread's pixel
-        if (inside) {
-            for (int ci = 0; ci < nc; ++ci) {
+        // ---- accumulate the surviving objects at this thread's pixel.  Branch-free and software-pipelined: the four taps of
+        // candidate ci+1 are in flight while candidate ci is composited (taps outside the sprite / pixels the object does not
+        // cover read a clamped texel with weight 0).  With a `continue` per tap every load sat behind its own wait and the
+        // kernel spent 80 % of its wave cycles parked (SQ_WAIT_ANY).
+        if (inside && nc > 0) {
+            float2 tv[4], tn[4];
+            float tw[4], twn[4];
+            float prs = 0.f, pdd = 0.f, prs_n = 0.f, pdd_n = 0.f;
+            auto fetch = [&](int ci, float2 (&v)[4], float (&w)[4], float& pr_, float& pd_) {
                 const Cand q = cand[ci];
-                // the reference's own formula (affine_grid then unnormalise), so recon and the saved pre-clamp value
-                // round like the oracle's
-                const float sx = src_of(q.ax, q.bx, px, I, P, ac);
-                const float sy = src_of(q.ay, q.by, py, I, P, ac);
-                if (!(sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P)) continue;
-                const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-                const float wx1 = sx - (float)x0, wy1 = sy - (float)y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                float gdum;
+                const float sx = src_from_base(q.ax, q.bx, bX, P, ac, gdum), sy = src_from_base(q.ay, q.by, bY, P, ac, gdum);
+                const bool cov = sx > -1.f && sx < (float)P && sy > -1.f && sy < (float)P;
+                const float fx = floorf(sx), fy = floorf(sy);
+                const int x0 = (int)fminf(fmaxf(fx, -1.f), (float)(P - 1)), y0 = (int)fminf(fmaxf(fy, -1.f), (float)(P - 1));
+                const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
                 const float* sp = S + (size_t)q.row * ld_s;
-                const float pd = q.pres * q.depth;
-                float g = 0.f, a = 0.f, m = 0.f;
+                pr_ = q.pres; pd_ = q.pres * q.depth;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
-                    if (yy < 0 || yy >= P || xx < 0 || xx >= P) continue;
-                    const float w = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
-                    const float2 v = *reinterpret_cast<const float2*>(sp + (yy * P + xx) * 2);
-                    g += w * v.x;
-                    a += w * (v.y * q.pres);
-                    m += w * fmaxf(v.y * pd, 0.01f);
+                    const bool ok = cov && yy >= 0 && yy < P && xx >= 0 && xx < P;
+                    w[t] = ok ? ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0) : 0.f;
+                    v[t] = *reinterpret_cast<const float2*>(sp + (min(max(yy, 0), P - 1) * P + min(max(xx, 0), P - 1)) * 2);
+                }
+            };
+            fetch(0, tv, tw, prs, pdd);
+            for (int ci = 0; ci < nc; ++ci) {
+                fetch(min(ci + 1, nc - 1), tn, twn, prs_n, pdd_n);
+                float g = 0.f, a = 0.f, m = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    g += tw[t] * tv[t].x;
+                    a += tw[t] * (tv[t].y * prs);
+                    m += tw[t] * fmaxf(tv[t].y * pdd, 0.01f);
                 }
                 num += g * a * (m + 1e-9f);
                 den += m;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { tv[t] = tn[t]; tw[t] = twn[t]; }
+                prs = prs_n; pdd = pdd_n;
             }
         }
         __syncthreads();
