@@ -14,6 +14,9 @@ struct GemmNT {
     float obj_scale, alpha_scale, alpha_bias;
     ConvDesc conv;
     RowMap cmap; int use_cmap;
+    // gemm16.hip: nz > 1 batches the nz = osy*osx output-parity classes of a strided conv data-gradient in ONE launch
+    // (blockIdx.z = py*osx + px picks the weight matrix Bz[z] and the row-map offsets); all classes must have the same size.
+    int nz; const void* Bz[4];
 };
 struct GemmTN {
     const float* A; int lda;

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const u16* A = reinterpret_cast<const u16*>(g.A);
-    const u16* B = reinterpret_cast<const u16*>(g.B);
+    const int zq = g.nz > 1 ? (int)blockIdx.z : 0;
+    const u16* B = reinterpret_cast<const u16*>(g.nz > 1 ? g.Bz[zq] : g.B);
+    const int cm_ooy = g.nz > 1 ? zq / g.cmap.osx : g.cmap.ooy, cm_oox = g.nz > 1 ? zq - (zq / g.cmap.osx) * g.cmap.osx : g.cmap.oox;
 
     // staging coordinates: chunk f = tid + i*256 -> row f/8, k-chunk f%8 (the same k-chunk for all of a thread's chunks).
     // Address arithmetic is the bottleneck of a conv gather if done naively (a 64-bit multiply chain per 16-byte chunk made both
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
             if (g.use_cmap) {
                 const int hw = g.cmap.Hout * g.cmap.Wout;
                 const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
-                crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + g.cmap.ooy)) * g.cmap.Wc + (x * g.cmap.osx + g.cmap.oox);
+                crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + cm_ooy)) * g.cmap.Wc + (x * g.cmap.osx + cm_oox);
             } else {
                 crow = (size_t)m;
             }
@@ -250,7 +252,8 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     if (!conv && (long long)g.M * g.lda >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;   // 32-bit element offsets
     if ((long long)g.N * g.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
-    dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128));
+    if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
+    dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), g.nz > 1 ? g.nz : 1);
 #define NT16_LAUNCH(AC, C16)                                                                                     \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
