@@ -113,6 +113,17 @@ int spair_gemm_tn16(const void* A, int lda, const void* B, int ldb, int b_bf16, 
  * scratch >= 512*128*32 floats */
 int spair_stem_wgrad16(const void* dY, const float* xpad, float* dW, float* db, float* scratch,
                        long long scratch_floats, int B, int Hin, int stride, int Hout, void* stream);
+/* Fused stack of L <= 4 1x1 convolutions on bf16 NHWC activations with 128 channels (Backbone's trailing 1x1 layers + conv_out,
+ * modules.py:59-64,107-111).  Host arrays of L device pointers.
+ * fwd: Y_l = relu(Y_{l-1} W_l^T + b_l); W[l] bf16 [cout_l][ldw_l]; Y[l] bf16 [M][128] for l < L-1; the last layer has no relu and
+ *      writes fp32 Ylast [M][ldlast] (cout_{L-1} <= 128 columns).
+ * bwd: layers in BACKWARD order; dX_l = (dX_{l-1} Wd_l^T) * [gate_l > 0]; dY bf16 [M][ldd] (kd valid columns), Wd[l] bf16
+ *      [128][ldw_l] = W transposed, gate[l] = the layer's forward INPUT (bf16 [M][128]), dX[l] bf16 [M][128]. */
+int spair_conv1x1_stack_fwd16(const void* X, const void* const* W, const int* ldw, const int* cout,
+                              const float* const* bias, void* const* Y, float* Ylast, int ldlast, int M, int L,
+                              void* stream);
+int spair_conv1x1_stack_bwd16(const void* dY, int ldd, int kd, const void* const* Wd, const int* ldw, const int* cout,
+                              const void* const* gate, void* const* dX, int M, int L, void* stream);
 /* fp32 [rows][ld_src] -> bf16 [rows][ld_dst] (round to nearest even), first `cols` columns */
 int spair_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long long rows, int cols, void* stream);
 /* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);

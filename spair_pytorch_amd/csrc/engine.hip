@@ -532,6 +532,22 @@ static ConvDesc fwd_desc(const ConvSpec& cs) {
     return cd;
 }
 
+// First layer of the trailing run of 1x1 convolutions that pointwise.hip can fuse (128 channels in, 128 out except the last,
+// at most 4 layers), or n_conv if there is none.
+static int pw_stack_first(const Ctx& c) {
+    const int n = c.PL.n_conv;
+    if (c.d.dtype != SPAIR_BF16) return n;
+    int i0 = n;
+    for (int i = n - 1; i >= 1; --i) {
+        const ConvSpec& cs = c.PL.conv[i];
+        const bool last = (i == n - 1);
+        if (cs.k != 1 || cs.s != 1 || cs.cin != 128 || (last ? cs.cout > 128 : cs.cout != 128) || n - i > 4) break;
+        if (c.PL.conv[i - 1].cout != 128) break;
+        i0 = i;
+    }
+    return (n - i0 >= 2) ? i0 : n;
+}
+
 static int backbone_fwd(Ctx& c) {
     const SpairDims& d = c.d;
     const int b16 = d.dtype == SPAIR_BF16;
@@ -539,10 +555,21 @@ static int backbone_fwd(Ctx& c) {
     TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, Ip, c.s));
     const ConvSpec& c0 = c.PL.conv[0];
     TRY(misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, b16, c.s));
+    const int pw0 = pw_stack_first(c);
     for (int i = 1; i < c.PL.n_conv; ++i) {
         const ConvSpec& cs = c.PL.conv[i];
         const bool last = (i == c.PL.n_conv - 1);
         const int M = d.B * cs.hout * cs.hout, K = cs.k * cs.k * cs.cin;
+        if (i == pw0) {   // the trailing 1x1 layers run as one fused per-pixel MLP
+            const void* W[4]; const float* bias[4]; void* Y[4]; int ldw[4], cout[4];
+            const int Lp = c.PL.n_conv - pw0;
+            for (int l = 0; l < Lp; ++l) {
+                const ConvSpec& q = c.PL.conv[pw0 + l];
+                W[l] = c.w.conv_wf[pw0 + l]; ldw[l] = round_up(q.cin, 8); cout[l] = q.cout; bias[l] = c.params + q.b; Y[l] = c.w.act[pw0 + l];
+            }
+            TRY(spair_pw_stack_fwd16(c.w.act[pw0 - 1], W, ldw, cout, bias, Y, c.w.feat, c.w.ld_feat, M, Lp, c.s));
+            break;
+        }
         float* out = last ? c.w.feat : c.w.act[i];
         const int ldc = last ? c.w.ld_feat : cs.cout;
         const ConvDesc cd = fwd_desc(cs);
@@ -569,6 +596,17 @@ static int backbone_bwd16(Ctx& c, float* grads) {
     const int last = c.PL.n_conv - 1;
     const int N = d.B * d.G * d.G;
     TRY(spair_to_bf16(c.w.dfeat, c.w.ld_feat, c.w.dfeat16, c.w.ld_feat, N, c.w.ld_feat, c.s));
+    const int pw0 = pw_stack_first(c);
+    if (pw0 <= last) {   // data gradients of the trailing 1x1 layers: one fused kernel, top layer first
+        const void* Wd[4]; const void* gate[4]; void* dX[4]; int ldw[4], cout[4];
+        const int Lp = last - pw0 + 1;
+        for (int l = 0; l < Lp; ++l) {
+            const int i = last - l;
+            const ConvSpec& q = c.PL.conv[i];
+            Wd[l] = c.w.conv_wd[i][0]; ldw[l] = round_up(q.cout, 8); cout[l] = q.cout; gate[l] = c.w.act[i - 1]; dX[l] = c.w.dact[i - 1];
+        }
+        TRY(spair_pw_stack_bwd16(c.w.dfeat16, c.w.ld_feat, c.PL.conv[last].cout, Wd, ldw, cout, gate, dX, N, Lp, c.s));
+    }
     for (int i = last; i >= 1; --i) {
         const ConvSpec& cs = c.PL.conv[i];
         const int M = d.B * cs.hout * cs.hout;
@@ -579,7 +617,7 @@ static int backbone_bwd16(Ctx& c, float* grads) {
         if (cs.k == 1) {
             TRY(tn16(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, true, grads + cs.w, cs.cin, M, grads + cs.b));
             const int Kd = round_up(cs.cout, 8);
-            TRY(nt16(c, dout, ldd, c.w.conv_wd[i][0], Kd, c.w.dact[i - 1], cs.cin, 1, M, cs.cin, Kd, nullptr, in, cs.cin, 0));
+            if (i < pw0) TRY(nt16(c, dout, ldd, c.w.conv_wd[i][0], Kd, c.w.dact[i - 1], cs.cin, 1, M, cs.cin, Kd, nullptr, in, cs.cin, 0));
         } else {
             const int K = cs.k * cs.k * cs.cin;
             TRY(tn16(c, dout, ldd, cs.cout, in, 0, K, true, grads + cs.w, K, M, grads + cs.b, &cd, cs.cin, cs.k * cs.k));

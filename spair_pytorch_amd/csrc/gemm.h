@@ -43,4 +43,9 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s);
 // stem (Cin = 1, 4x4, Cout = 128) weight + bias gradient; dY bf16 [B*Hout*Hout][128], xp padded fp32 input [B][Hin][Hin]
 int spair_stem_wgrad16_impl(const void* dY, const float* xp, float* dW, float* db, float* part, long long part_cap, int B, int Hin,
                             int stride, int Hout, hipStream_t s);
+// pointwise.hip: fused stacks of 1x1 convolutions on bf16 [M][128] activations (<= 4 layers, 128 channels, last/first layer <= 128)
+int spair_pw_stack_fwd16(const void* X, const void* const* W, const int* ldw, const int* cout, const float* const* bias, void* const* Y,
+                         float* Ylast, int ldlast, int M, int L, hipStream_t s);
+int spair_pw_stack_bwd16(const void* dY, int ldd, int kd, const void* const* Wd, const int* ldw, const int* cout, const void* const* gate,
+                         void* const* dX, int M, int L, hipStream_t s);
 int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows, int cols, hipStream_t s);

@@ -251,3 +251,56 @@ def test_stem_wgrad16_vs_torch(B, Hin):
     assert (dW.cpu() - 0.5 - w.grad).abs().max() <= 2e-3 * w.grad.abs().max()
     ref_db = go.sum((0, 2, 3))
     assert (db.cpu() - ref_db).abs().max() <= 2e-3 * ref_db.abs().max() + 1e-3
+
+
+def test_conv1x1_stack_fwd_bwd_vs_torch():
+    """Fused per-pixel MLP (Backbone's trailing 1x1 convs + conv_out): 128 -> 128 -> 128 -> 128 -> 100, bf16 activations."""
+    L = _lib()
+    g = torch.Generator().manual_seed(11)
+    M, Lr, couts = 1000, 4, [128, 128, 128, 100]
+    x = _bf(torch.relu(torch.randn(M, 128, generator=g)))
+    Ws = [_bf(torch.randn(co, 128, generator=g) / 128 ** 0.5) for co in couts]
+    bs = [torch.randn(co, generator=g) * 0.1 for co in couts]
+    # torch reference with bf16 rounding of every stored activation
+    acts, h = [x.float()], x.float()
+    for l in range(Lr):
+        h = h @ Ws[l].float().t() + bs[l]
+        if l < Lr - 1:
+            h = _bf(torch.relu(h)).float()
+            acts.append(h)
+    ref_out = h
+
+    def parr(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
+
+    xd = x.cuda()
+    Wd = [w.cuda() for w in Ws]
+    bd = [b.cuda() for b in bs]
+    Y = [torch.zeros(M, 128, device="cuda", dtype=torch.bfloat16) for _ in range(Lr - 1)] + [None]
+    out = torch.zeros(M, 104, device="cuda")
+    L.check(L.lib().spair_conv1x1_stack_fwd16(L.ptr(xd), parr(Wd), _i(128, 128, 128, 128), _i(*couts), parr(bd), parr(Y), L.ptr(out), 104, M, Lr,
+                                              L.stream()), "1x1 stack fwd")
+    assert (out[:, :100].cpu() - ref_out).abs().max() <= 2e-2 * ref_out.abs().max()
+    for l in range(Lr - 1):
+        assert (Y[l].float().cpu() - acts[l + 1]).abs().max() <= 2e-2 * acts[l + 1].abs().max()
+    # backward: dX_{l-1} = (dX_l W_l) * [act_{l-1} > 0], top layer first
+    dy = torch.zeros(M, 104)
+    dy[:, :100] = torch.randn(M, 100, generator=g)
+    dy16 = _bf(dy)
+    WT = [_bf(Ws[l].t().contiguous()) for l in range(Lr)]          # [128][cout]
+    WTp = []
+    for l in range(Lr):
+        ld = (couts[l] + 7) // 8 * 8
+        t = torch.zeros(128, ld, dtype=torch.bfloat16)
+        t[:, :couts[l]] = WT[l]
+        WTp.append(t.cuda())
+    order = list(range(Lr - 1, -1, -1))
+    gate = [acts[l].to(torch.bfloat16).cuda() for l in order]
+    dX = [torch.zeros(M, 128, device="cuda", dtype=torch.bfloat16) for _ in order]
+    L.check(L.lib().spair_conv1x1_stack_bwd16(L.ptr(dy16.cuda()), 104, 100, parr([WTp[l] for l in order]), _i(*[WTp[l].shape[1] for l in order]),
+                                              _i(*[couts[l] for l in order]), parr(gate), parr(dX), M, Lr, L.stream()), "1x1 stack bwd")
+    gcur = dy16.float()[:, :100]
+    for k, l in enumerate(order):
+        gcur = (gcur @ Ws[l].float()) * (acts[l] > 0)
+        gcur = _bf(gcur).float()
+        assert (dX[k].float().cpu() - gcur).abs().max() <= 3e-2 * gcur.abs().max(), (k, l)
