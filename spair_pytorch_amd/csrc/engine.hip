@@ -607,6 +607,24 @@ static int backbone_bwd16(Ctx& c, float* grads) {
         }
         TRY(spair_pw_stack_bwd16(c.w.dfeat16, c.w.ld_feat, c.PL.conv[last].cout, Wd, ldw, cout, gate, dX, N, Lp, c.s));
     }
+    if (pw0 <= last) {   // ... and their weight / bias gradients as ONE grouped split-K GEMM + one reduce pass
+        GemmTN g;
+        memset(&g, 0, sizeof(g));
+        g.ngroup = last - pw0 + 1;
+        for (int q = 0; q < g.ngroup; ++q) {
+            const int i = pw0 + q;
+            const ConvSpec& cs = c.PL.conv[i];
+            g.Ag[q] = reinterpret_cast<const float*>((i == last) ? c.w.dfeat16 : (const void*)c.w.dact[i]);
+            g.lda_g[q] = (i == last) ? c.w.ld_feat : cs.cout;
+            g.Bg[q] = reinterpret_cast<const float*>(c.w.act[i - 1]); g.ldb_g[q] = cs.cin;
+            g.Cg[q] = grads + cs.w; g.ldc_g[q] = cs.cin; g.colsum_g[q] = grads + cs.b;
+            g.M_g[q] = round_up(cs.cout, 8); g.Mstore_g[q] = cs.cout; g.Nstore_g[q] = cs.cin;
+        }
+        g.A = g.Ag[0]; g.lda = g.lda_g[0]; g.B = g.Bg[0]; g.ldb = g.ldb_g[0]; g.C = g.Cg[0]; g.ldc = g.ldc_g[0];
+        g.M = 128; g.N = 128; g.Mstore = 128; g.Nstore = 128; g.R = N;
+        g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
+        TRY(spair_gemm_tn16_impl(g, false, true, c.s));
+    }
     for (int i = last; i >= 1; --i) {
         const ConvSpec& cs = c.PL.conv[i];
         const int M = d.B * cs.hout * cs.hout;
@@ -615,6 +633,7 @@ static int backbone_bwd16(Ctx& c, float* grads) {
         const void* in = c.w.act[i - 1];
         const ConvDesc cd = fwd_desc(cs);
         if (cs.k == 1) {
+            if (i >= pw0) continue;
             TRY(tn16(c, dout, ldd, cs.cout, in, cs.cin, cs.cin, true, grads + cs.w, cs.cin, M, grads + cs.b));
             const int Kd = round_up(cs.cout, 8);
             if (i < pw0) TRY(nt16(c, dout, ldd, c.w.conv_wd[i][0], Kd, c.w.dact[i - 1], cs.cin, 1, M, cs.cin, Kd, nullptr, in, cs.cin, 0));

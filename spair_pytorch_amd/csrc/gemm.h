@@ -31,6 +31,11 @@ struct GemmTN {
     // optional split-K scratch: each block stores its fp32 tile with plain coalesced stores to part[split][tile][128][128]
     // and a second kernel sums the splits and does C += sum (no atomics).  NULL / too small -> fp32 atomics into C.
     float* part; long long part_cap;    // capacity in floats
+    // gemm16.hip grouped launch: ngroup (2..4) independent problems with M_g, N <= 128 over the same R rows in ONE launch + ONE
+    // reduce pass (the backbone's four 1x1-conv weight gradients were 4 x (48 + 22) us for 2 GFLOP each).  Requires `part`.
+    int ngroup;
+    const float* Ag[4]; const float* Bg[4]; float* Cg[4]; float* colsum_g[4];
+    int lda_g[4], ldb_g[4], ldc_g[4], M_g[4], Mstore_g[4], Nstore_g[4];
 };
 #define SPAIR_TN_PART_FLOATS (1536ll * 128 * 128)    // up to 1536 blocks x one 128x128 tile (100 MB)
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);

@@ -632,8 +632,15 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
     const int tile = idx / per, e = idx - tile * per;
     const int ml = e / bn4, nl = (e - ml * bn4) * 4;
     const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
-    const int m = mt * bm + ml, n = nt * bn + nl;
-    const bool live = tile < tiles && m < g.Mstore && n < g.Nstore;
+    const bool grouped = g.ngroup > 1;
+    const int grp = grouped ? nt : 0;
+    auto pick = [&](auto v0, auto v1, auto v2, auto v3) { return grp == 0 ? v0 : (grp == 1 ? v1 : (grp == 2 ? v2 : v3)); };
+    float* Cp = grouped ? pick(g.Cg[0], g.Cg[1], g.Cg[2], g.Cg[3]) : g.C;
+    const int ldc = grouped ? pick(g.ldc_g[0], g.ldc_g[1], g.ldc_g[2], g.ldc_g[3]) : g.ldc;
+    const int Mst = grouped ? pick(g.Mstore_g[0], g.Mstore_g[1], g.Mstore_g[2], g.Mstore_g[3]) : g.Mstore;
+    const int Nst = grouped ? pick(g.Nstore_g[0], g.Nstore_g[1], g.Nstore_g[2], g.Nstore_g[3]) : g.Nstore;
+    const int m = mt * bm + ml, n = (grouped ? 0 : nt * bn) + nl;
+    const bool live = tile < tiles && m < Mst && n < Nst;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (live) {
         const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
@@ -659,10 +666,10 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int nn = n + q;
-        if (nn >= g.Nstore) break;
+        if (nn >= Nst) break;
         int nc = nn;
         if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
-        g.C[(size_t)m * g.ldc + nc] += v[q];
+        Cp[(size_t)m * ldc + nc] += v[q];
     }
 }
 int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s) {

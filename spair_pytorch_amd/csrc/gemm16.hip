@@ -308,10 +308,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             mt_ = id % ntm; nt_ = (id / ntm) % ntn; sp_ = id / (ntm * ntn);
         }
     }
-    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    // grouped launch (ngroup > 1): the n-tile index selects one of up to 4 independent single-tile problems that share R; their
+    // operands come from fixed slots of the argument struct (a runtime-indexed pointer table would turn into FLAT loads)
+    const int grp = g.ngroup > 1 ? nt_ : 0;
+    auto pick = [&](auto v0, auto v1, auto v2, auto v3) { return grp == 0 ? v0 : (grp == 1 ? v1 : (grp == 2 ? v2 : v3)); };
+    const bool grouped = g.ngroup > 1;
+    const float* gA = grouped ? pick(g.Ag[0], g.Ag[1], g.Ag[2], g.Ag[3]) : g.A;
+    const float* gB = grouped ? pick(g.Bg[0], g.Bg[1], g.Bg[2], g.Bg[3]) : g.B;
+    const int g_lda = grouped ? pick(g.lda_g[0], g.lda_g[1], g.lda_g[2], g.lda_g[3]) : g.lda;
+    const int g_ldb = grouped ? pick(g.ldb_g[0], g.ldb_g[1], g.ldb_g[2], g.ldb_g[3]) : g.ldb;
+    const int g_M = grouped ? pick(g.M_g[0], g.M_g[1], g.M_g[2], g.M_g[3]) : g.M;
+    const int g_Mstore = grouped ? pick(g.Mstore_g[0], g.Mstore_g[1], g.Mstore_g[2], g.Mstore_g[3]) : g.Mstore;
+    float* g_colsum = grouped ? pick(g.colsum_g[0], g.colsum_g[1], g.colsum_g[2], g.colsum_g[3]) : g.colsum_out;
+    const int m0 = mt_ * BM, n0 = grouped ? 0 : nt_ * BN;
     const int r_begin = sp_ * g.rows_per_split;
     const int r_end = min(g.R, r_begin + g.rows_per_split);
-    const u16* A = reinterpret_cast<const u16*>(g.A);
+    const u16* A = reinterpret_cast<const u16*>(gA);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
     float csum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-    const bool do_colsum = g.colsum_out != nullptr && nt_ == 0;
+    const bool do_colsum = g_colsum != nullptr && (grouped || nt_ == 0);
     // B chunks
     constexpr int NB = B16 ? NB16 : NB32;
     uint4 rb16[NB16];
@@ -339,11 +351,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
     bool b_vec = true;
     unsigned a_off[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(r_begin + (tid >> 4) + i * 16) * (unsigned)g.lda + (unsigned)min(m0 + a_mq * 8, g.M - 8);
-    const bool a_mok = (m0 + a_mq * 8) < g.M;
-    const unsigned a_last = (unsigned)(g.R - 1) * (unsigned)g.lda + (unsigned)min(m0 + a_mq * 8, g.M - 8);
+    for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(r_begin + (tid >> 4) + i * 16) * (unsigned)g_lda + (unsigned)min(m0 + a_mq * 8, g_M - 8);
+    const bool a_mok = (m0 + a_mq * 8) < g_M;
+    const unsigned a_last = (unsigned)(g.R - 1) * (unsigned)g_lda + (unsigned)min(m0 + a_mq * 8, g_M - 8);
     const int row_wraps = BCONV ? ceil_div_dev(BK, g.conv.Wout) : 0;
-    const int d_step = BCONV ? BK * g.conv.sx * g.conv.Cin : BK * g.ldb;                                  // x += BK
+    const int d_step = BCONV ? BK * g.conv.sx * g.conv.Cin : BK * g_ldb;                                  // x += BK
     const int d_row = BCONV ? (g.conv.sy * g.conv.Win - g.conv.Wout * g.conv.sx) * g.conv.Cin : 0;      // x -= Wout, y += 1
     const int d_img = BCONV ? (g.conv.Hin - g.conv.Hout * g.conv.sy) * g.conv.Win * g.conv.Cin : 0;     // y -= Hout, b += 1
 #pragma unroll
@@ -367,18 +379,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
                 b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
             }
         } else {
-            b_off[i] = (unsigned)(r_begin + kr) * (unsigned)g.ldb + (unsigned)min(n, g.N - (B16 ? 8 : 4));
+            b_off[i] = (unsigned)(r_begin + kr) * (unsigned)g_ldb + (unsigned)min(n, g.N - (B16 ? 8 : 4));
             b_tapoff[i][0] = b_tapoff[i][1] = b_tapoff[i][2] = b_tapoff[i][3] = 0;
         }
     }
-    const unsigned b_lastrow = BCONV ? 0u : (unsigned)(g.R - 1) * (unsigned)g.ldb;
+    const unsigned b_lastrow = BCONV ? 0u : (unsigned)(g.R - 1) * (unsigned)g_ldb;
     auto load_tiles = [&](int r0) {      // every load is issued unconditionally from a clamped address and zeroed by a select
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = r0 + (tid >> 4) + i * 16;
             const uint4 v = *reinterpret_cast<const uint4*>(A + min(a_off[i], a_last));
             ra[i] = (r < r_end && a_mok) ? v : make_uint4(0u, 0u, 0u, 0u);
-            a_off[i] += (unsigned)(BK * g.lda);
+            a_off[i] += (unsigned)(BK * g_lda);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -388,14 +400,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             // rows past the end of the tensor (last split only) are clamped by construction for conv (crow_init clamps the start and
             // the row test zeroes the value; offsets only ever move forward inside the allocation of the last image) and explicitly here
             unsigned off = b_off[i];
-            if (!BCONV) off = min(off, b_lastrow + (unsigned)(g.ldb - (B16 ? 8 : 4)));
+            if (!BCONV) off = min(off, b_lastrow + (unsigned)(g_ldb - (B16 ? 8 : 4)));
             if (BCONV && !ok) off = 0u;
             if constexpr (B16) {
-                const u16* Bp = reinterpret_cast<const u16*>(g.B);
+                const u16* Bp = reinterpret_cast<const u16*>(gB);
                 const uint4 v = *reinterpret_cast<const uint4*>(Bp + off + (unsigned)b_tapoff[i][0]);
                 rb16[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             } else {
-                const float* Bp = g.B;
+                const float* Bp = gB;
                 float4 v;
                 if (b_vec) v = *reinterpret_cast<const float4*>(Bp + off + (unsigned)b_tapoff[i][0]);     // wave-uniform choice
                 else v = make_float4(Bp[off + (unsigned)b_tapoff[i][0]], Bp[off + (unsigned)b_tapoff[i][1]], Bp[off + (unsigned)b_tapoff[i][2]],
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += scr[q * BM + m];
-            if (m0 + m < g.Mstore) atomicAdd(&g.colsum_out[m0 + m], t);
+            if (m0 + m < g_Mstore) atomicAdd(&g_colsum[m0 + m], t);
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
@@ -652,15 +664,21 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (!b_bf16 && ((g.N & 3) || (!conv && (g.ldb & 3)))) return SPAIR_ERR_ALIGN;
     if ((long long)g.R * g.lda >= (1ll << 31) || (!conv && (long long)g.R * g.ldb >= (1ll << 31))) return SPAIR_ERR_UNSUPPORTED;   // 32-bit offsets
     constexpr int BM = 128, BN = 128;
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    if (g.ngroup > 1) {   // grouped single-tile problems: only through the partial-tile path, plain bf16 rows
+        if (g.ngroup > 4 || conv || !b_bf16 || !g.part || g.N > BN) return SPAIR_ERR_UNSUPPORTED;
+        for (int q = 0; q < g.ngroup; ++q)
+            if (g.M_g[q] > BM || (g.M_g[q] & 7) || (g.lda_g[q] & 7) || (g.ldb_g[q] & 7) || !g.Ag[q] || !g.Bg[q] || !g.Cg[q]) return SPAIR_ERR_SHAPE;
+        g.M = BM;
+    }
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN) * (g.ngroup > 1 ? g.ngroup : 1);
     // one full round of resident blocks: 256 CUs x 3 blocks (150 VGPRs, 35 KB LDS); a 4/3-round grid wastes a third of the time
     int nsplit = max(1, min(ceil_div(g.R, 256), 768 / tiles));
     if (nsplit >= 8) nsplit = nsplit / 8 * 8;
     int rps = round_up(ceil_div(g.R, nsplit), 32);
     if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
-    g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = ceil_div(g.N, BN);
+    g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = g.ngroup > 1 ? g.ngroup : ceil_div(g.N, BN);
     dim3 grid(g.tiles_m * g.tiles_n * nsplit);
-    if (g.part && (long long)grid.x * BM * BN > g.part_cap) g.part = nullptr;     // scratch too small: atomics
+    if (g.part && (long long)grid.x * BM * BN > g.part_cap) { if (g.ngroup > 1) return SPAIR_ERR_UNSUPPORTED; g.part = nullptr; }   // scratch too small: atomics
     if (conv) {
         if (b_bf16) hipLaunchKernelGGL((gemm_tn16_kernel<true, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_tn16_kernel<true, false>), grid, dim3(256), 0, s, g);
