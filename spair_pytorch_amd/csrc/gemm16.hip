@@ -200,45 +200,106 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         __syncthreads();
     }
 
-    // epilogue
-    const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+    // epilogue.  The accumulators go through LDS (the operand buffers are free now) so that everything that touches HBM is a
+    // coalesced 16-byte-per-lane access of whole rows: the relu-mask read (data gradients), the row-remapped store, the sprite
+    // sigmoid.  Straight from the MFMA layout a lane would issue 64 scattered 2-byte mask loads and 64 2/4-byte stores of
+    // 32/64-byte segments (decoder.out: 411 MB of fp32 sprites left at 1 TB/s).
+    constexpr int LDC = BN + 4;                       // fp32 staging tile [BM][LDC]: 67.6 KB of the 73.7 KB
+    float* Cs = reinterpret_cast<float*>(smem);
+    {
+        const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WN + j * 16 + col_l;
+            const float bv = (g.bias && (n0 + nl) < g.N) ? g.bias[n0 + nl] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * WM + i * 16 + rgrp + r;
-            if (m >= g.M) continue;
-            size_t crow;
-            if (g.use_cmap) {
-                const int hw = g.cmap.Hout * g.cmap.Wout;
-                const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
-                crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + cm_ooy)) * g.cmap.Wc + (x * g.cmap.osx + cm_oox);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(wm * WM + i * 16 + rgrp + r) * LDC + nl] = acc[i][j][r] + bv;
+        }
+    }
+    __syncthreads();
+    const bool vec_ok = C16 ? ((g.ldc & 7) == 0) : ((g.ldc & 3) == 0);
+    const int c8 = (tid & 15) * 8;                    // this thread's 8 columns; rows (tid>>4) + 16*i
+    const int nb = n0 + c8;
+#pragma unroll 2
+    for (int i = 0; i < BM / 16; ++i) {
+        const int rl = (tid >> 4) + i * 16;
+        const int m = m0 + rl;
+        if (m >= g.M || nb >= g.N) continue;
+        size_t crow;
+        if (g.use_cmap) {
+            const int hw = g.cmap.Hout * g.cmap.Wout;
+            const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
+            crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + cm_ooy)) * g.cmap.Wc + (x * g.cmap.osx + cm_oox);
+        } else {
+            crow = (size_t)m;
+        }
+        float v[8];
+        {
+            const float4 q0 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8 + 4]);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        }
+        const bool full = (nb + 8) <= g.N;
+        if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.mask) {
+            if (g.mask_bf16 && full && (g.ldmask & 7) == 0) {
+                const uint4 mk = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(g.mask) + crow * g.ldmask + nb);
+                const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                    v[e] = ((h & 0x8000u) == 0 && (h & 0x7fffu) != 0) ? v[e] : 0.f;          // bf16 value > 0
+                }
             } else {
-                crow = (size_t)m;
-            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + col_l;
-                if (n >= g.N) continue;
-                float v = acc[i][j][r];
-                if (g.bias) v += g.bias[n];
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.mask) {
+                for (int e = 0; e < 8; ++e) {
+                    if (nb + e >= g.N) continue;
                     bool on;
                     if (g.mask_bf16) {
-                        const u16 h = reinterpret_cast<const u16*>(g.mask)[crow * g.ldmask + n];
-                        on = (h & 0x8000u) == 0 && (h & 0x7fffu) != 0;      // bf16 value > 0
+                        const u16 h = reinterpret_cast<const u16*>(g.mask)[crow * g.ldmask + nb + e];
+                        on = (h & 0x8000u) == 0 && (h & 0x7fffu) != 0;
                     } else {
-                        on = g.mask[crow * g.ldmask + n] > 0.f;
+                        on = g.mask[crow * g.ldmask + nb + e] > 0.f;
                     }
-                    v = on ? v : 0.f;
+                    v[e] = on ? v[e] : 0.f;
                 }
-                if (g.sprite_ch > 0) {
-                    const float t = ((n % g.sprite_ch) == g.sprite_ch - 1) ? v * g.alpha_scale + g.alpha_bias : v * g.obj_scale;
-                    v = 1.f / (expf(-t) + 1.f);
-                }
-                if (C16) reinterpret_cast<__bf16*>(g.C)[crow * g.ldc + n] = (__bf16)v;
-                else g.C[crow * g.ldc + n] = v;
+            }
+        }
+        if (g.sprite_ch > 0) {
+            int ch = nb % g.sprite_ch;                // one modulo per chunk, then a running channel index
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (ch == g.sprite_ch - 1) ? v[e] * g.alpha_scale + g.alpha_bias : v[e] * g.obj_scale;
+                v[e] = 1.f / (expf(-t) + 1.f);
+                ch = (ch + 1 == g.sprite_ch) ? 0 : ch + 1;
+            }
+        }
+        if (C16) {
+            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + crow * g.ldc + nb;
+            if (full && vec_ok) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (nb + e < g.N) dst[e] = (__bf16)v[e];
+            }
+        } else {
+            float* dst = g.C + crow * g.ldc + nb;
+            if (full && vec_ok) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (nb + e < g.N) dst[e] = v[e];
             }
         }
     }
