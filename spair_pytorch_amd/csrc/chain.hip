@@ -507,7 +507,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
 
 
 // =============================================================================================
-// Backward: the same ownership (one workgroup per sample), wavefronts in reverse order.  Data-gradient
+// Backward: the same ownership (one workgroup per sample), wavefronts in reverse order.  Every layer-output gradient is written
+// to its row buffer as BF16 (same leading dimension in elements; the buffers are sized for fp32, the per-wavefront path keeps using
+// them as fp32): the weight-gradient GEMMs round their operands to bf16 anyway, and one grouped bf16-A launch replaces 14.  Data-gradient
 // chain only -- every layer's pre-activation gradient is written to its HBM row buffer and the weight
 // gradients are long-K GEMMs over all rows afterwards.  The input gradients of the three per-cell nets
 // never go to HBM: their [feat | context] part is summed in a 4-deep LDS ring (a cell's record gradient
@@ -583,7 +585,8 @@ static_assert(NTH == 512, "the mask prefetch maps 512 threads onto 16 rows");
 
 template <int KT, int NT>
 __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned char* mk, int ldh,
-                                           float* __restrict__ dOut, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane) {
+                                           float* __restrict__ dOut_, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane) {
+    __bf16* __restrict__ dOut = reinterpret_cast<__bf16*>(dOut_);       // gradient row buffers hold bf16 in the fused path (see k_chain_bwd)
     wg_gemm_wide<KT, NT>(in, LD_H, Wt, wave, lane, [&](int j, int nt, const f32x4& acc) {
         const int n = nt * 16 + (lane & 15);
         if (n >= nout) return;
@@ -591,7 +594,7 @@ __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __rest
         for (int rr = 0; rr < 4; ++rr) {
             const int row = (lane >> 4) * 4 + rr;
             const float v = mk[row * MK_ROW + n] ? acc[rr] : 0.f;
-            if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = v;
+            if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
             dst[row * LD_H + n] = (__bf16)v;
         }
     });
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float* bd = bundle_sh[row];
                 const float d = pres_backward(grec[row][REC - 1] + bd[BD_GPR], zp_sh[row], bd[BD_ST + ST_PZ], kl, bd[BD_OO], ks, H);
                 dOo_sh[row] = d;
-                P.dOo[r * L.ld_oo] = d;
+                reinterpret_cast<__bf16*>(P.dOo)[r * L.ld_oo] = (__bf16)d;
             }
         }
         lds_barrier();
@@ -818,9 +821,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             const float d = row < nc ? dOo_sh[row] : 0.f;
             const float4 v = make_float4(mkq[5].x > 0.f ? d * w.x : 0.f, mkq[5].y > 0.f ? d * w.y : 0.f, mkq[5].z > 0.f ? d * w.z : 0.f,
                                          mkq[5].w > 0.f ? d * w.w : 0.f);
-            if (row < nc) *reinterpret_cast<float4*>(P.dHo2 + (size_t)row_r[row] * SP_LDH + q4 * 4) = v;
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dHo2) + (size_t)row_r[row] * SP_LDH + q4 * 4) = o;
             *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + q4 * 4]) = o;
         }
         lds_barrier();
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = row < nc ? tailO[row][i] : 0.f;
             Aa[row * LD_H + i] = (__bf16)v;
-            if (row < nc) P.dOz[(size_t)row_r[row] * L.ld_oz + i] = v;
+            if (row < nc) reinterpret_cast<__bf16*>(P.dOz)[(size_t)row_r[row] * L.ld_oz + i] = (__bf16)v;
         }
         if (tid < MT) {
             float d_mu = 0.f, d_ls = 0.f;
@@ -856,8 +859,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float eps = bd[BD_EPSD];
                 const float g_depth = grec[tid][4 + A_] + tailO[tid][NP + 4 + A_] + bd[BD_GDR];
                 depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], bd[BD_OZ1], eps, zp_sh[tid], ks, H, d_mu, d_ls);
-                P.dOz[r * L.ld_oz + NP] = d_mu;
-                P.dOz[r * L.ld_oz + NP + 1] = d_ls;
+                reinterpret_cast<__bf16*>(P.dOz)[r * L.ld_oz + NP] = (__bf16)d_mu;
+                reinterpret_cast<__bf16*>(P.dOz)[r * L.ld_oz + NP + 1] = (__bf16)d_ls;
             }
             Aa[tid * LD_H + NP] = (__bf16)d_mu;
             Aa[tid * LD_H + NP + 1] = (__bf16)d_ls;
@@ -891,8 +894,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float* bd = bundle_sh[row];
                 const float g = grec[row][4 + j] + tailZ[row][NP + 4 + j] + tailO[row][NP + 4 + j] + bd[BD_GA + j];
                 attr_backward(g, bd[BD_OE + j], bd[BD_SD + j], bd[BD_OE + A_ + j], bd[BD_EA + j], zp_sh[row], ks, H, d_mean, d_ls);
-                P.dOe[r * L.ld_oe + j] = d_mean;
-                P.dOe[r * L.ld_oe + A_ + j] = d_ls;
+                reinterpret_cast<__bf16*>(P.dOe)[r * L.ld_oe + j] = (__bf16)d_mean;
+                reinterpret_cast<__bf16*>(P.dOe)[r * L.ld_oe + A_ + j] = (__bf16)d_ls;
             }
             Ab[row * LD_H + j] = (__bf16)d_mean;
             Ab[row * LD_H + A_ + j] = (__bf16)d_ls;
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = row < nc ? tailZ[row][i] : 0.f;
             Aa[row * LD_H + i] = (__bf16)v;
-            if (row < nc) P.dOb[(size_t)row_r[row] * L.ld_ob + i] = v;
+            if (row < nc) reinterpret_cast<__bf16*>(P.dOb)[(size_t)row_r[row] * L.ld_ob + i] = (__bf16)v;
         }
         if (tid < MT) {
             float dlat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 }
                 box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, bd + BD_OBL, zp_sh[tid], ks, H, dlat);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) P.dOb[r * L.ld_ob + NP + k] = dlat[k];
+                for (int k = 0; k < 8; ++k) reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + k] = (__bf16)dlat[k];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) Aa[tid * LD_H + NP + k] = (__bf16)dlat[k];

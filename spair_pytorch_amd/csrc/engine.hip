@@ -5,6 +5,7 @@
 // Nothing here synchronises or allocates: every launch goes to the caller's stream.
 #include <string.h>
 #include <stdio.h>
+#include <algorithm>
 #include <vector>
 
 #include "cells.h"
@@ -614,14 +615,14 @@ static int backbone_bwd16(Ctx& c, float* grads) {
         for (int q = 0; q < g.ngroup; ++q) {
             const int i = pw0 + q;
             const ConvSpec& cs = c.PL.conv[i];
-            g.Ag[q] = reinterpret_cast<const float*>((i == last) ? c.w.dfeat16 : (const void*)c.w.dact[i]);
-            g.lda_g[q] = (i == last) ? c.w.ld_feat : cs.cout;
-            g.Bg[q] = reinterpret_cast<const float*>(c.w.act[i - 1]); g.ldb_g[q] = cs.cin;
-            g.Cg[q] = grads + cs.w; g.ldc_g[q] = cs.cin; g.colsum_g[q] = grads + cs.b;
-            g.M_g[q] = round_up(cs.cout, 8); g.Mstore_g[q] = cs.cout; g.Nstore_g[q] = cs.cin;
+            GemmTN::Tile& t = g.tile[q];
+            t.A = (i == last) ? c.w.dfeat16 : (const void*)c.w.dact[i];
+            t.lda = (i == last) ? c.w.ld_feat : cs.cout;
+            t.B = c.w.act[i - 1]; t.ldb = cs.cin;
+            t.C = grads + cs.w; t.ldc = cs.cin; t.colsum = grads + cs.b;
+            t.M = round_up(cs.cout, 8); t.N = cs.cin; t.Mstore = cs.cout; t.Nstore = cs.cin;
         }
-        g.A = g.Ag[0]; g.lda = g.lda_g[0]; g.B = g.Bg[0]; g.ldb = g.ldb_g[0]; g.C = g.Cg[0]; g.ldc = g.ldc_g[0];
-        g.M = 128; g.N = 128; g.Mstore = 128; g.Nstore = 128; g.R = N;
+        g.R = N;
         g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
         TRY(spair_gemm_tn16_impl(g, false, true, c.s));
     }
@@ -876,6 +877,53 @@ static int wgrad_lin(Ctx& c, int id, const float* dOut, int ldo, const float* In
     return tn(c, dOut, ldo, l.out, In, ldi, l.in, grads + l.w, l.in, R, grads + l.b);
 }
 
+// Weight / bias gradients of the 14 per-cell layers in ONE grouped split-K launch (fused-chain path: the layer-output gradients are
+// bf16 rows, the layer inputs fp32 rows).  36 tiles of <= 128 x 128 at the reference sizes.
+static int cells_wgrad_grouped(Ctx& c, float* grads) {
+    const CellLayout& L = c.L;
+    const CellBufs& P = c.w.cb;
+    GemmTN g;
+    memset(&g, 0, sizeof(g));
+    int nt = 0;
+    bool fits = true;
+    // dY: bf16 [N][ldo] (columns a0 .. a0+M-1 of it), X: fp32 [N][ldi]
+    auto add = [&](int id, const float* dY, int ldo, int a0, const float* X, int ldi) {
+        const LinSpec& l = c.PL.lin[id];
+        const __bf16* A = reinterpret_cast<const __bf16*>(dY);
+        for (int m0 = 0; m0 < l.out; m0 += 128) {
+            const int col = a0 + m0, col_al = col & ~7, skip = col - col_al;          // A tile starts on a 16-byte boundary
+            const int ms = std::min(128, l.out - m0);
+            const int Ml = std::min(round_up(skip + ms, 8), ldo - col_al);
+            for (int n0 = 0; n0 < l.in; n0 += 128) {
+                if (nt >= SPAIR_TN_MAX_TILES || skip + ms > 128) { fits = false; return; }
+                GemmTN::Tile& t = g.tile[nt++];
+                const int ns = std::min(128, l.in - n0);
+                t.A = A + col_al; t.lda = ldo; t.B = X + n0; t.ldb = ldi;
+                t.C = grads + l.w + (size_t)m0 * l.in + n0; t.ldc = l.in; t.colsum = (n0 == 0) ? grads + l.b + m0 : nullptr;
+                t.M = Ml; t.N = std::min(round_up(ns, 4), ldi - n0); t.Mstore = ms; t.Nstore = ns; t.m_skip = skip;
+            }
+        }
+    };
+    add(LIN_BOX0, P.dHb1, SP_LDH, 0, P.Xb, L.ld_xb);
+    add(LIN_BOX1, P.dHb2, SP_LDH, 0, P.Hb1, SP_LDH);
+    add(LIN_BOXH1, P.dOb, L.ld_ob, 0, P.Hb2, SP_LDH);
+    add(LIN_BOXH0, P.dOb, L.ld_ob, L.ob_lat, P.Hb2, SP_LDH);
+    add(LIN_ENC0, P.dHe1, SP_ENC_H1, 0, P.glimpse, L.ld_gl);
+    add(LIN_ENC1, P.dHe2, SP_ENC_H2, 0, P.He1, SP_ENC_H1);
+    add(LIN_ENC2, P.dOe, L.ld_oe, 0, P.He2, SP_ENC_H2);
+    add(LIN_Z0, P.dHz1, SP_LDH, 0, P.Xz, L.ld_x);
+    add(LIN_Z1, P.dHz2, SP_LDH, 0, P.Hz1, SP_LDH);
+    add(LIN_ZH1, P.dOz, L.ld_oz, 0, P.Hz2, SP_LDH);
+    add(LIN_ZH0, P.dOz, L.ld_oz, L.oz_lat, P.Hz2, SP_LDH);
+    add(LIN_OBJ0, P.dHo1, SP_LDH, 0, P.Xo, L.ld_x);
+    add(LIN_OBJ1, P.dHo2, SP_LDH, 0, P.Ho1, SP_LDH);
+    add(LIN_OBJ2, P.dOo, L.ld_oo, 0, P.Ho2, SP_LDH);
+    if (!fits) return SPAIR_ERR_UNSUPPORTED;
+    g.ngroup = nt; g.R = L.N;
+    g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
+    return spair_gemm_tn16_impl(g, false, false, c.s);
+}
+
 extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
                               const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace,
                               const float* grad_loss, float* grads, void* stream) {
@@ -963,7 +1011,12 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     // the per-cell weight gradients (helper stream) and the backbone backward (caller's stream) both hang off the chain only
     if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
     const int ps_wg = prof_begin(PS_CELLS_WGRAD, c.s);
-    // weight gradients of the per-cell nets: one long-K GEMM per layer over all N rows
+    // weight gradients of the per-cell nets: long-K GEMMs over all N rows
+    if (c.use_chain) {
+        if (side) c.tn_scratch = c.w.tn_part2;
+        TRY(cells_wgrad_grouped(c, grads));
+        c.tn_scratch = nullptr;
+    } else {
     TRY(wgrad_lin(c, LIN_BOX0, P.dHb1, SP_LDH, P.Xb, L.ld_xb, grads, N));
     TRY(wgrad_lin(c, LIN_BOX1, P.dHb2, SP_LDH, P.Hb1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_BOXH1, P.dOb, L.ld_ob, P.Hb2, SP_LDH, grads, N));
@@ -978,6 +1031,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(wgrad_lin(c, LIN_OBJ0, P.dHo1, SP_LDH, P.Xo, L.ld_x, grads, N));
     TRY(wgrad_lin(c, LIN_OBJ1, P.dHo2, SP_LDH, P.Ho1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
+    }
     prof_end(ps_wg, c.s);
     if (side) {
         if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;

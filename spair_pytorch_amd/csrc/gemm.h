@@ -18,6 +18,7 @@ struct GemmNT {
     // (blockIdx.z = py*osx + px picks the weight matrix Bz[z] and the row-map offsets); all classes must have the same size.
     int nz; const void* Bz[4];
 };
+#define SPAIR_TN_MAX_TILES 40
 struct GemmTN {
     const float* A; int lda;
     const float* B; int ldb;
@@ -31,11 +32,18 @@ struct GemmTN {
     // optional split-K scratch: each block stores its fp32 tile with plain coalesced stores to part[split][tile][128][128]
     // and a second kernel sums the splits and does C += sum (no atomics).  NULL / too small -> fp32 atomics into C.
     float* part; long long part_cap;    // capacity in floats
-    // gemm16.hip grouped launch: ngroup (2..4) independent problems with M_g, N <= 128 over the same R rows in ONE launch + ONE
-    // reduce pass (the backbone's four 1x1-conv weight gradients were 4 x (48 + 22) us for 2 GFLOP each).  Requires `part`.
+    // gemm16.hip grouped launch: ngroup independent single-tile problems (M, N <= 128 each) over the same R rows in ONE launch +
+    // ONE reduce pass -- per-layer launches of small weight gradients are pure overhead (the per-cell nets' 14 GEMMs = 36 tiles took
+    // 0.74 ms, the backbone's four 1x1 layers 4 x 70 us).  Operand pointers are pre-offset to the tile's first column.  Requires `part`.
     int ngroup;
-    const float* Ag[4]; const float* Bg[4]; float* Cg[4]; float* colsum_g[4];
-    int lda_g[4], ldb_g[4], ldc_g[4], M_g[4], Mstore_g[4], Nstore_g[4];
+    struct Tile {
+        const void* A; const void* B; float* C; float* colsum;     // A bf16 [R][lda]; B bf16 or fp32 [R][ldb]; colsum may be null
+        int lda, ldb, ldc;
+        int M, N;                 // load extents (A: multiple of 8 columns; B: multiple of 8 (bf16) / 4 (fp32)), <= 128
+        int Mstore, Nstore;       // store extents
+        int m_skip;               // the first m_skip rows of the tile belong to another tile (A pointers must stay 16-byte aligned):
+                                  // tile row m is stored at C row m - m_skip for m_skip <= m < m_skip + Mstore
+    } tile[SPAIR_TN_MAX_TILES];
 };
 #define SPAIR_TN_PART_FLOATS (1536ll * 128 * 128)    // up to 1536 blocks x one 128x128 tile (100 MB)
 int spair_gemm_nt_impl(const GemmNT& g, bool conv, int dtype, hipStream_t s);

@@ -633,14 +633,14 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
     const int ml = e / bn4, nl = (e - ml * bn4) * 4;
     const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
     const bool grouped = g.ngroup > 1;
-    const int grp = grouped ? nt : 0;
-    auto pick = [&](auto v0, auto v1, auto v2, auto v3) { return grp == 0 ? v0 : (grp == 1 ? v1 : (grp == 2 ? v2 : v3)); };
-    float* Cp = grouped ? pick(g.Cg[0], g.Cg[1], g.Cg[2], g.Cg[3]) : g.C;
-    const int ldc = grouped ? pick(g.ldc_g[0], g.ldc_g[1], g.ldc_g[2], g.ldc_g[3]) : g.ldc;
-    const int Mst = grouped ? pick(g.Mstore_g[0], g.Mstore_g[1], g.Mstore_g[2], g.Mstore_g[3]) : g.Mstore;
-    const int Nst = grouped ? pick(g.Nstore_g[0], g.Nstore_g[1], g.Nstore_g[2], g.Nstore_g[3]) : g.Nstore;
+    const GemmTN::Tile& gt = g.tile[grouped ? nt : 0];
+    float* Cp = grouped ? gt.C : g.C;
+    const int ldc = grouped ? gt.ldc : g.ldc;
+    const int Mst = grouped ? gt.Mstore : g.Mstore;
+    const int Nst = grouped ? gt.Nstore : g.Nstore;
+    const int mskip = grouped ? gt.m_skip : 0;
     const int m = mt * bm + ml, n = (grouped ? 0 : nt * bn) + nl;
-    const bool live = tile < tiles && m < Mst && n < Nst;
+    const bool live = tile < tiles && m >= mskip && m < mskip + Mst && n < Nst;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (live) {
         const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
         if (nn >= Nst) break;
         int nc = nn;
         if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
-        Cp[(size_t)m * ldc + nc] += v[q];
+        Cp[(size_t)(m - mskip) * ldc + nc] += v[q];
     }
 }
 int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s) {

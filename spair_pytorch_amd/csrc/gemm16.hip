@@ -369,18 +369,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             mt_ = id % ntm; nt_ = (id / ntm) % ntn; sp_ = id / (ntm * ntn);
         }
     }
-    // grouped launch (ngroup > 1): the n-tile index selects one of up to 4 independent single-tile problems that share R; their
-    // operands come from fixed slots of the argument struct (a runtime-indexed pointer table would turn into FLAT loads)
-    const int grp = g.ngroup > 1 ? nt_ : 0;
-    auto pick = [&](auto v0, auto v1, auto v2, auto v3) { return grp == 0 ? v0 : (grp == 1 ? v1 : (grp == 2 ? v2 : v3)); };
+    // grouped launch (ngroup > 1): the n-tile index selects one of the independent single-tile problems of g.tile[] (a table in the
+    // kernel-argument segment: the index is wave-uniform, the entries arrive through scalar loads and stay global pointers)
     const bool grouped = g.ngroup > 1;
-    const float* gA = grouped ? pick(g.Ag[0], g.Ag[1], g.Ag[2], g.Ag[3]) : g.A;
-    const float* gB = grouped ? pick(g.Bg[0], g.Bg[1], g.Bg[2], g.Bg[3]) : g.B;
-    const int g_lda = grouped ? pick(g.lda_g[0], g.lda_g[1], g.lda_g[2], g.lda_g[3]) : g.lda;
-    const int g_ldb = grouped ? pick(g.ldb_g[0], g.ldb_g[1], g.ldb_g[2], g.ldb_g[3]) : g.ldb;
-    const int g_M = grouped ? pick(g.M_g[0], g.M_g[1], g.M_g[2], g.M_g[3]) : g.M;
-    const int g_Mstore = grouped ? pick(g.Mstore_g[0], g.Mstore_g[1], g.Mstore_g[2], g.Mstore_g[3]) : g.Mstore;
-    float* g_colsum = grouped ? pick(g.colsum_g[0], g.colsum_g[1], g.colsum_g[2], g.colsum_g[3]) : g.colsum_out;
+    const GemmTN::Tile& gt = g.tile[grouped ? nt_ : 0];
+    const float* gA = grouped ? reinterpret_cast<const float*>(gt.A) : g.A;
+    const float* gB = grouped ? reinterpret_cast<const float*>(gt.B) : g.B;
+    const int g_lda = grouped ? gt.lda : g.lda;
+    const int g_ldb = grouped ? gt.ldb : g.ldb;
+    const int g_M = grouped ? gt.M : g.M;
+    const int g_N = grouped ? gt.N : g.N;
+    const int g_Mstore = grouped ? gt.Mstore : g.Mstore;
+    const int g_mskip = grouped ? gt.m_skip : 0;
+    float* g_colsum = grouped ? gt.colsum : g.colsum_out;
     const int m0 = mt_ * BM, n0 = grouped ? 0 : nt_ * BN;
     const int r_begin = sp_ * g.rows_per_split;
     const int r_end = min(g.R, r_begin + g.rows_per_split);
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         const int kr = B16 ? f / (BN / 8) : f / (BN / 4);
         const int nq = B16 ? f % (BN / 8) : f % (BN / 4);
         const int n = n0 + nq * (B16 ? 8 : 4);
-        b_nok[i] = n < g.N;
+        b_nok[i] = n < g_N;
         b_x[i] = b_y[i] = 0;
         if (BCONV) {
             b_vec = B16 ? true : (g.conv.Cin & 3) == 0;
@@ -436,11 +437,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ConvTap16 t;
-                ctap_init(g.conv, min(n + e, g.N - 1), t);
+                ctap_init(g.conv, min(n + e, g_N - 1), t);
                 b_tapoff[i][e] = (t.ky * g.conv.dky * g.conv.Win + t.kx * g.conv.dkx) * g.conv.Cin + t.ci;
             }
         } else {
-            b_off[i] = (unsigned)(r_begin + kr) * (unsigned)g_ldb + (unsigned)min(n, g.N - (B16 ? 8 : 4));
+            b_off[i] = (unsigned)(r_begin + kr) * (unsigned)g_ldb + (unsigned)min(n, g_N - (B16 ? 8 : 4));
             b_tapoff[i][0] = b_tapoff[i][1] = b_tapoff[i][2] = b_tapoff[i][3] = 0;
         }
     }
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += scr[q * BM + m];
-            if (m0 + m < g_Mstore) atomicAdd(&g_colsum[m0 + m], t);
+            if (m0 + m >= g_mskip && m0 + m < g_mskip + g_Mstore) atomicAdd(&g_colsum[m0 + m - g_mskip], t);
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
@@ -717,6 +718,7 @@ int spair_stem_wgrad16_impl(const void* dY, const float* xp, float* dW, float* d
 
 // A bf16 [R][lda]; B: bf16 (b_bf16) plain rows / conv gather, or fp32 conv gather / plain rows
 int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
+    if (g.ngroup > 1) { g.M = 128; g.N = 128; g.Mstore = 128; g.Nstore = 128; g.lda = g.tile[0].lda; g.ldb = g.tile[0].ldb; }
     if (g.M <= 0 || g.N <= 0 || g.R <= 0) return SPAIR_ERR_SHAPE;
     if (g.Mstore <= 0) g.Mstore = g.M;
     if (g.Nstore <= 0) g.Nstore = g.N;
@@ -725,11 +727,16 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (!b_bf16 && ((g.N & 3) || (!conv && (g.ldb & 3)))) return SPAIR_ERR_ALIGN;
     if ((long long)g.R * g.lda >= (1ll << 31) || (!conv && (long long)g.R * g.ldb >= (1ll << 31))) return SPAIR_ERR_UNSUPPORTED;   // 32-bit offsets
     constexpr int BM = 128, BN = 128;
-    if (g.ngroup > 1) {   // grouped single-tile problems: only through the partial-tile path, plain bf16 rows
-        if (g.ngroup > 4 || conv || !b_bf16 || !g.part || g.N > BN) return SPAIR_ERR_UNSUPPORTED;
-        for (int q = 0; q < g.ngroup; ++q)
-            if (g.M_g[q] > BM || (g.M_g[q] & 7) || (g.lda_g[q] & 7) || (g.ldb_g[q] & 7) || !g.Ag[q] || !g.Bg[q] || !g.Cg[q]) return SPAIR_ERR_SHAPE;
-        g.M = BM;
+    if (g.ngroup > 1) {   // grouped single-tile problems: only through the partial-tile path, plain rows
+        if (g.ngroup > SPAIR_TN_MAX_TILES || conv || !g.part) return SPAIR_ERR_UNSUPPORTED;
+        for (int q = 0; q < g.ngroup; ++q) {
+            const GemmTN::Tile& t = g.tile[q];
+            if (!t.A || !t.B || !t.C || t.M <= 0 || t.N <= 0 || t.M > BM || t.N > BN || (t.M & 7) || (t.lda & 7)) return SPAIR_ERR_SHAPE;
+            if (b_bf16 ? ((t.N & 7) || (t.ldb & 7)) : ((t.N & 3) || (t.ldb & 3))) return SPAIR_ERR_ALIGN;
+            if ((long long)g.R * t.lda >= (1ll << 31) || (long long)g.R * t.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+            if (t.Mstore <= 0 || t.m_skip < 0 || t.m_skip + t.Mstore > t.M || t.Nstore <= 0 || t.Nstore > t.N) return SPAIR_ERR_SHAPE;
+        }
+        g.M = BM; g.N = BN; g.Mstore = BM; g.Nstore = BN; g.lda = g.tile[0].lda; g.ldb = g.tile[0].ldb;
     }
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN) * (g.ngroup > 1 ? g.ngroup : 1);
     // one full round of resident blocks: 256 CUs x 3 blocks (150 VGPRs, 35 KB LDS); a 4/3-round grid wastes a third of the time
