@@ -206,6 +206,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     // 32/64-byte segments (decoder.out: 411 MB of fp32 sprites left at 1 TB/s).
     constexpr int LDC = BN + 4;                       // fp32 staging tile [BM][LDC]: 67.6 KB of the 73.7 KB
     float* Cs = reinterpret_cast<float*>(smem);
+    const bool vec_ok = C16 ? ((g.ldc & 7) == 0) : ((g.ldc & 3) == 0);
+    const int c8 = (tid & 15) * 8;                    // this thread's 8 columns; rows (tid>>4) + 16*i
+    const int nb = n0 + c8;
+    const bool full = (nb + 8) <= g.N;
+    // destination rows and (data gradients) the relu-gate chunks of all 8 rows first: the gate loads are in flight while the
+    // accumulators are staged -- issued one per row inside the store loop they cost 8 serialised HBM round trips per tile
+    // (23 us of fixed cost on a tile whose 8 K-steps take 8 us)
+    constexpr int NR = BM / 16;
+    size_t crow[NR];
+    uint4 gate[NR];
+    const bool vec_gate = g.mask != nullptr && g.mask_bf16 && (g.ldmask & 7) == 0 && full;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int m = min(m0 + (tid >> 4) + i * 16, g.M - 1);
+        if (g.use_cmap) {
+            const int hw = g.cmap.Hout * g.cmap.Wout;
+            const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
+            crow[i] = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + cm_ooy)) * g.cmap.Wc + (x * g.cmap.osx + cm_oox);
+        } else {
+            crow[i] = (size_t)m;
+        }
+        gate[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (vec_gate) gate[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(g.mask) + crow[i] * g.ldmask + nb);
+    }
     {
         const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
@@ -219,37 +243,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         }
     }
     __syncthreads();
-    const bool vec_ok = C16 ? ((g.ldc & 7) == 0) : ((g.ldc & 3) == 0);
-    const int c8 = (tid & 15) * 8;                    // this thread's 8 columns; rows (tid>>4) + 16*i
-    const int nb = n0 + c8;
-#pragma unroll 2
-    for (int i = 0; i < BM / 16; ++i) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
         const int rl = (tid >> 4) + i * 16;
         const int m = m0 + rl;
         if (m >= g.M || nb >= g.N) continue;
-        size_t crow;
-        if (g.use_cmap) {
-            const int hw = g.cmap.Hout * g.cmap.Wout;
-            const int b = m / hw, rem = m - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
-            crow = ((size_t)b * g.cmap.Hc + (y * g.cmap.osy + cm_ooy)) * g.cmap.Wc + (x * g.cmap.osx + cm_oox);
-        } else {
-            crow = (size_t)m;
-        }
         float v[8];
         {
             const float4 q0 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8]);
             const float4 q1 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8 + 4]);
             v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
         }
-        const bool full = (nb + 8) <= g.N;
         if (g.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (g.mask) {
-            if (g.mask_bf16 && full && (g.ldmask & 7) == 0) {
-                const uint4 mk = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(g.mask) + crow * g.ldmask + nb);
-                const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+            if (vec_gate) {
+                const unsigned mw[4] = {gate[i].x, gate[i].y, gate[i].z, gate[i].w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
@@ -261,10 +272,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                     if (nb + e >= g.N) continue;
                     bool on;
                     if (g.mask_bf16) {
-                        const u16 h = reinterpret_cast<const u16*>(g.mask)[crow * g.ldmask + nb + e];
+                        const u16 h = reinterpret_cast<const u16*>(g.mask)[crow[i] * g.ldmask + nb + e];
                         on = (h & 0x8000u) == 0 && (h & 0x7fffu) != 0;
                     } else {
-                        on = g.mask[crow * g.ldmask + nb + e] > 0.f;
+                        on = g.mask[crow[i] * g.ldmask + nb + e] > 0.f;
                     }
                     v[e] = on ? v[e] : 0.f;
                 }
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
             }
         }
         if (C16) {
-            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + crow * g.ldc + nb;
+            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + crow[i] * g.ldc + nb;
             if (full && vec_ok) {
                 bf16x8 o;
 #pragma unroll
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                     if (nb + e < g.N) dst[e] = (__bf16)v[e];
             }
         } else {
-            float* dst = g.C + crow * g.ldc + nb;
+            float* dst = g.C + crow[i] * g.ldc + nb;
             if (full && vec_ok) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -14,6 +14,7 @@ step, train.py:64-67) runs unchanged.  All arithmetic of the step is in libspair
 * there is no PyTorch/CPU fallback: without the HIP library or a GPU this module raises.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -46,7 +47,8 @@ class SpairStep(ctypes.Structure):
                 ("train", ctypes.c_int), ("flags", ctypes.c_int)]
 
 
-STEP_FLAGS = 0   # bit 0: disable the fused persistent per-cell kernels (tests compare both paths)
+# bit 0: disable the fused persistent per-cell kernels (tests compare both paths); bit 1: stage stamps; bit 2: no helper stream
+STEP_FLAGS = int(os.environ.get("SPAIR_STEP_FLAGS", "0"))
 
 _DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
