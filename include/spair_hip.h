@@ -124,6 +124,14 @@ int spair_conv1x1_stack_fwd16(const void* X, const void* const* W, const int* ld
                               void* stream);
 int spair_conv1x1_stack_bwd16(const void* dY, int ldd, int kd, const void* const* Wd, const int* ldw, const int* cout,
                               const void* const* gate, void* const* dX, int M, int L, void* stream);
+/* ---- evaluation metrics (spair/metric.py:5-99), device-side, no in-place mutation ------------------------------ */
+/* z_where [B,4,G,G] (x, y, w, h image fractions, the reference's top-left convention), z_pres [B,1,G,G], bbox [B,K,4]
+ * (x, y, w, h px, zero padded), count [B] fp32; scratch 2*B floats; out[0] = mAP (metric.py:5-47),
+ * out[1] = object_count_accuracy (metric.py:49-56) */
+int spair_metrics(const float* z_where, const float* z_pres, const float* bbox, const float* count, int B, int G,
+                  int image_side, int K, float* scratch, float* out, void* stream);
+/* batch_jaccard (metric.py:82-99): corner-format boxes [B,A,4] x [B,Bn,4] -> iou [B,A,Bn] */
+int spair_batch_jaccard(const float* box_a, const float* box_b, int B, int A, int Bn, float* iou, void* stream);
 /* fp32 [rows][ld_src] -> bf16 [rows][ld_dst] (round to nearest even), first `cols` columns */
 int spair_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long long rows, int cols, void* stream);
 /* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);

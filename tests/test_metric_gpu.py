@@ -1,0 +1,56 @@
+"""Device metrics (spair_pytorch_amd/metric.py -> spair_metrics / spair_batch_jaccard) against the reference's own numbers
+(tests/golden/metrics.npz, produced by spair/metric.py) and the CPU oracle at BASELINE sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["m_b4_g6", "m_b3_g16", "m_b2_g11"])
+def test_metrics_match_reference(name, golden_dir):
+    from spair_pytorch_amd import metric
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    B, G, I, K = (int(v) for v in z[name + "/dims"])
+    zw, zp = torch.from_numpy(z[name + "/z_where"]).cuda(), torch.from_numpy(z[name + "/z_pres"]).cuda()
+    bb, cnt = torch.from_numpy(z[name + "/bbox"]).cuda(), torch.from_numpy(z[name + "/count"]).cuda()
+    keep = [t.clone() for t in (zw, zp, bb, cnt)]
+    m = metric.mAP(zw, zp, bb, cnt, image_side=I)
+    acc = metric.object_count_accuracy(zp, cnt)
+    assert m.is_cuda and m.dim() == 0
+    for t, k in zip((zw, zp, bb, cnt), keep):
+        assert torch.equal(t, k)
+    assert abs(m.item() - float(z[name + "/mAP"])) <= 2e-6 * max(1.0, abs(float(z[name + "/mAP"])))
+    assert abs(acc.item() - float(z[name + "/count_accuracy"])) <= 1e-5 * max(1.0, abs(float(z[name + "/count_accuracy"])))
+    # batch_jaccard on the corner boxes the reference builds
+    a = (zw * I).permute(0, 2, 3, 1).reshape(B, -1, 4).clone()
+    a[..., 2:] += a[..., :2]
+    g = bb.clone()
+    g[..., 2:] += g[..., :2]
+    iou = metric.batch_jaccard(a, g)
+    assert np.allclose(iou.cpu().numpy(), z[name + "/iou"], rtol=2e-6, atol=1e-7, equal_nan=True)
+
+
+def test_metrics_full_size_vs_oracle():
+    """BASELINE config-2 size (B=256, 16x16 grid, 11 label boxes): device result vs the CPU oracle on the same inputs."""
+    from oracle import metric_oracle as mo
+    from spair_pytorch_amd import metric
+    g = torch.Generator().manual_seed(5)
+    B, G, I, K = 256, 16, 128, 11
+    zw = torch.rand(B, 4, G, G, generator=g) * 0.8
+    zw[:, 2:] = torch.rand(B, 2, G, G, generator=g) * 0.3 + 0.05
+    zp = torch.rand(B, 1, G, G, generator=g)
+    cnt = torch.randint(1, K + 1, (B, 1), generator=g).float()
+    bb = torch.zeros(B, K, 4)
+    for b in range(B):
+        n = int(cnt[b, 0])
+        wh = torch.rand(n, 2, generator=g) * 20 + 8
+        bb[b, :n, 2:] = wh
+        bb[b, :n, :2] = torch.rand(n, 2, generator=g) * (I - wh)
+    ref_m, ref_a = mo.mAP(zw, zp, bb, cnt, I), mo.object_count_accuracy(zp, cnt)
+    m = metric.mAP(zw.cuda(), zp.cuda(), bb.cuda(), cnt.cuda(), image_side=I)
+    a = metric.object_count_accuracy(zp.cuda(), cnt.cuda())
+    assert abs(m.item() - ref_m.item()) <= 5e-6 * max(1.0, abs(ref_m.item()))
+    assert abs(a.item() - ref_a.item()) <= 1e-5 * max(1.0, abs(ref_a.item()))

@@ -105,3 +105,24 @@ def test_freeze_gradient_known_answer():
     out = orc.freeze(0.6, y * 100)
     (out * 0.001).sum().backward()
     assert abs(y.grad.item() - 0.04) < 1e-7
+
+
+# ---- evaluation metrics: oracle vs the reference's own spair/metric.py ------------------------
+@pytest.mark.parametrize("name", ["m_b4_g6", "m_b3_g16", "m_b2_g11"])
+def test_metric_oracle_matches_reference(name, golden_dir):
+    import os
+    from oracle import metric_oracle as mo
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    B, G, I, K = (int(v) for v in z[name + "/dims"])
+    zw, zp = torch.from_numpy(z[name + "/z_where"]), torch.from_numpy(z[name + "/z_pres"])
+    bb, cnt = torch.from_numpy(z[name + "/bbox"]), torch.from_numpy(z[name + "/count"])
+    keep = [t.clone() for t in (zw, zp, bb, cnt)]
+    m = mo.mAP(zw, zp, bb, cnt, I)
+    acc = mo.object_count_accuracy(zp, cnt)
+    a, b = mo.corners(zw, bb, I)
+    iou = mo.batch_jaccard(a, b)
+    for t, k in zip((zw, zp, bb, cnt), keep):
+        assert torch.equal(t, k)                      # unlike the reference, inputs are not mutated
+    assert abs(float(m) - float(z[name + "/mAP"])) <= 1e-6 * max(1.0, abs(float(z[name + "/mAP"])))
+    assert abs(float(acc) - float(z[name + "/count_accuracy"])) <= 1e-5 * max(1.0, abs(float(z[name + "/count_accuracy"])))
+    assert np.allclose(iou.numpy(), z[name + "/iou"], rtol=1e-6, atol=1e-7, equal_nan=True)
