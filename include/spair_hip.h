@@ -132,6 +132,11 @@ int spair_metrics(const float* z_where, const float* z_pres, const float* bbox, 
                   int image_side, int K, float* scratch, float* out, void* stream);
 /* batch_jaccard (metric.py:82-99): corner-format boxes [B,A,4] x [B,Bn,4] -> iou [B,A,Bn] */
 int spair_batch_jaccard(const float* box_a, const float* box_b, int B, int A, int Bn, float* iou, void* stream);
+/* ---- synthetic scattered-digit scenes generated on the device (stands in for spair/dataloader.py:10-36, whose HDF5 file is not
+ * available; same item contract).  image [B,1,I,I] fp32 in [0,1], bbox [B,K,4] fp32 (x, y, w, h px, zero padded), count [B] int64;
+ * samples first..first+B-1 of the Philox stream `seed`; scratch B*K*28 floats. */
+int spair_scenes_generate(uint64_t seed, long long first, int B, int I, int K, int size_min, int size_max, float* image,
+                          float* bbox, long long* count, float* scratch, void* stream);
 /* fp32 [rows][ld_src] -> bf16 [rows][ld_dst] (round to nearest even), first `cols` columns */
 int spair_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, long long rows, int cols, void* stream);
 /* stn(image, z_where, [P,P]) forward (border) and its gradient wrt z_where (modules.py:216-273);

@@ -60,3 +60,38 @@ class SyntheticScatteredDigits(torch.utils.data.Dataset):
 
     def __len__(self):
         return self.image.shape[0]
+
+
+class DeviceScatteredDigits:
+    """Batches of synthetic scenes generated on the GPU (csrc/scenes.hip): same item contract as SimpleScatteredMNISTDataset
+    (dataloader.py:10-36) -- ``(image [B,1,I,I] float in [0,1], bbox [B,K,4] = (x, y, w, h) px zero padded, digit_count [B])`` -- but as
+    device tensors, one launch pair per batch, deterministic in (seed, sample index).  Iterating yields ``len(self)`` batches per epoch;
+    ``batch(i)`` regenerates batch i of the stream directly (any rank, any epoch: rank r of W reads batches r, r+W, ...)."""
+
+    def __init__(self, n_samples, batch_size, image_side=128, max_objects=11, seed=1234, obj_px=(14, 28), device="cuda", rank=0, world=1):
+        self.n, self.B, self.I, self.K, self.seed, self.obj_px = int(n_samples), int(batch_size), int(image_side), int(max_objects), int(seed), obj_px
+        self.device, self.rank, self.world = torch.device(device), int(rank), int(world)
+        self._scratch = None
+
+    def __len__(self):
+        return self.n // (self.B * self.world)
+
+    def batch(self, i, epoch=0):
+        from . import _lib as L
+        import ctypes
+        if self.device.type != "cuda":
+            raise L.SpairHipError("DeviceScatteredDigits generates on the GPU (no CPU fallback)")
+        first = (epoch * len(self) * self.world + i * self.world + self.rank) * self.B
+        img = torch.empty(self.B, 1, self.I, self.I, device=self.device)
+        bbox = torch.empty(self.B, self.K, 4, device=self.device)
+        cnt = torch.empty(self.B, dtype=torch.int64, device=self.device)
+        if self._scratch is None:
+            self._scratch = torch.empty(self.B * self.K * 28, device=self.device)
+        L.check(L.lib().spair_scenes_generate(ctypes.c_uint64(self.seed), ctypes.c_longlong(first), self.B, self.I, self.K, int(self.obj_px[0]),
+                                              int(self.obj_px[1]), L.ptr(img), L.ptr(bbox), L.ptr(cnt), L.ptr(self._scratch), L.stream()),
+                "spair_scenes_generate")
+        return img, bbox, cnt
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.batch(i)
