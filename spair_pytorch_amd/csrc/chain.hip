@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int MT = 16;                    // rows per wavefront tile
-constexpr int F = 100, REC = 56, CTX = 224, A_ = 50, NP = 100, GLN = 784;
+constexpr int F = 100, REC = 56, CTX = 224, A_ = 50, NP = 100, GLN = 784, PG = 28;    // PG: glimpse side (chain_fwd_supported requires P == 28)
 constexpr int KC = 352, LD_XC = KC + 8;   // [feat | ctx] padded to 11 k-steps
 constexpr int KX = 160, LD_XT = KX + 8;   // [pass | box | attr | depth] padded to 5 k-steps
 constexpr int KG = 800, LD_GL = KG + 8;   // glimpse padded to 25 k-steps
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float feat_sh[MT][F];
     __shared__ __attribute__((aligned(16))) float noise_sh[MT][REC];      // [eps_box 4 | eps_attr A | eps_depth | u_pres]
     __shared__ unsigned short cell_hw[32 * 32];
+    __shared__ float pbase_sh[32];                                         // base coordinate of glimpse index j (stn_base), no division per element
     __shared__ __attribute__((aligned(16))) _Float16 img_sh[IMG ? IMG_MAX * IMG_MAX : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Xc[MT * LD_XC];
     __shared__ __attribute__((aligned(16))) __bf16 XtZ[MT * LD_XT];
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     for (int i = tid; i < L.HW * 4; i += NTH) nbr_sh[i] = (short)P.nbr[i];
     for (int i = tid; i < L.HW; i += NTH) cell_hw[i] = (unsigned short)((P.cell_h[i] << 8) | P.cell_w[i]);
     for (int i = tid; i < REC; i += NTH) edge_sh[i] = P.edge[i];
+    if (tid < PG) pbase_sh[tid] = stn_base(tid, PG, a.ac);
 #pragma unroll
     for (int l = 0; l < CW_COUNT; ++l)
         for (int i = tid; i < BIAS_CNT[l]; i += NTH) bias_sh[BIAS_OFF[l] + i] = a.bias[l][i];
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // ---- z_what: glimpse (modules.py:216-273, border padding) + encoder MLP (models.py:383-391)
         for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
-            const int i = e / a.Pp, j0 = e - i * a.Pp;          // P % 4 == 0: the 4 elements share the row i
+            const int i = e / PG, j0 = e - i * PG;              // P % 4 == 0: the 4 elements share the row i
             float iy, my;
-            stn_src_coord(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, i, a.Pp, a.I, a.ac, true, iy, my);
+            stn_src_coord_b(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, pbase_sh[i], a.I, a.ac, true, iy, my);
             const int y0 = (int)floorf(iy);
             const float wy1 = iy - (float)y0, wy0 = 1.f - wy1;
             const bool yin = (y0 + 1) < a.I;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float ix, mx;
-                stn_src_coord(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, j0 + q, a.Pp, a.I, a.ac, true, ix, mx);
+                stn_src_coord_b(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, pbase_sh[j0 + q], a.I, a.ac, true, ix, mx);
                 const int x0 = (int)floorf(ix);
                 const float wx1 = ix - (float)x0, wx0 = 1.f - wx1;
                 const int x1 = ((x0 + 1) < a.I) ? x0 + 1 : x0;
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) int ibundle_sh[MT][8];           // consumers[4] | neighbours[4]
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
+    __shared__ float pbase_sh[32];          // base coordinate of glimpse index j (stn_base)
     __shared__ float prior_sh[12];          // prior mean[6] | std[6]: a lane-indexed read of the kernel-argument struct would be a
                                             // global load + vmcnt(0) wait in the middle of the prefetch window
 
@@ -635,6 +638,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     const int G = L.G, T = 3 * G - 2;
     const float ks = H.kl_scale * (*P.gloss);
     if (tid < SP_H) wobj_sh[tid] = a.w_obj2[tid];
+    if (tid < PG) pbase_sh[tid] = stn_base(tid, PG, a.ac);
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { prior_sh[i] = H.prior_mean[i]; prior_sh[6 + i] = H.prior_std[i]; }
@@ -917,8 +921,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int j, int nt, const f32x4& acc) {
                 const int e = nt * 16 + (lane & 15);
                 if (e >= GLN) return;
-                const int gi = e / a.Pp, gj = e - gi * a.Pp;
-                const float X = stn_base(gj, a.Pp, a.ac), Y = stn_base(gi, a.Pp, a.ac);
+                const int gi = e / PG, gj = e - gi * PG;
+                const float X = pbase_sh[gj], Y = pbase_sh[gi];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int row = (lane >> 4) * 4 + rr;

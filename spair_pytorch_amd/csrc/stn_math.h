@@ -12,9 +12,9 @@ __host__ __device__ __forceinline__ float stn_base(int j, int n, int align_corne
 // `nsrc` pixels.  With `border`, the coordinate is clipped to [0, nsrc-1] and `mult` (d coord / d g)
 // is zeroed outside the clip range exactly like torch's clip_coordinates_set_grad.
 // Returns the base coordinate (needed for d/d scale).
-__host__ __device__ __forceinline__ float stn_src_coord(float scale, float shift, int j, int nout, int nsrc,
-                                                        int align_corners, bool border, float& coord, float& mult) {
-    const float base = stn_base(j, nout, align_corners);
+// Same as stn_src_coord below with the base coordinate supplied by the caller (a table lookup instead of a division per element).
+__host__ __device__ __forceinline__ void stn_src_coord_b(float scale, float shift, float base, int nsrc, int align_corners, bool border,
+                                                         float& coord, float& mult) {
     const float g = scale * base + shift;
     float c;
     if (align_corners) { c = (g + 1.f) * 0.5f * (float)(nsrc - 1); mult = 0.5f * (float)(nsrc - 1); }
@@ -25,5 +25,10 @@ __host__ __device__ __forceinline__ float stn_src_coord(float scale, float shift
         else if (c >= hi) { c = hi; mult = 0.f; }
     }
     coord = c;
+}
+__host__ __device__ __forceinline__ float stn_src_coord(float scale, float shift, int j, int nout, int nsrc,
+                                                        int align_corners, bool border, float& coord, float& mult) {
+    const float base = stn_base(j, nout, align_corners);
+    stn_src_coord_b(scale, shift, base, nsrc, align_corners, border, coord, mult);
     return base;
 }
