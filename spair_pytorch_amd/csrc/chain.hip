@@ -528,8 +528,18 @@ constexpr int LD_R = 328;      // ring row: [feat 100 | ctx 224] fp32
 // weight-fragment double buffer; `epi(nt, acc)` consumes each tile as soon as it is complete (it must ignore nt >= NT).
 // Straight-line between a tile's loads and its MFMAs (see wg_gemm): the trip count is the same for every wave and tiles past
 // the end are clamped, never branched around.
+// first weight tile (fragments 0..3) of the NEXT data-gradient GEMM, issued before the barrier that ends the current stage: the
+// GEMM then starts on registers that are already (being) filled instead of exposing an L2 round trip per stage
+struct WPre { uint4 q[4]; };
+template <int KT, int NT>
+__device__ __forceinline__ void wide_prefetch(const uint4* __restrict__ Wt, int wave, int lane, WPre& pre) {
+    const uint4* b0 = Wt + (size_t)min(wave, NT - 1) * KT * 64 + lane;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) pre.q[kt] = b0[kt * 64];
+}
+
 template <int KT, int NT, class Epi>
-__device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uint4* __restrict__ Wt, int wave, int lane, Epi epi) {
+__device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uint4* __restrict__ Wt, int wave, int lane, Epi epi, const WPre& pre) {
     // epi(j, nt, acc): j = ordinal of the tile within this wave (compile-time constant: the pair loop is fully unrolled so that
     // per-tile data prefetched into registers can be indexed statically)
     constexpr int MY = (NT + NW - 1) / NW, PAIRS = (MY + 1) / 2;
@@ -542,7 +552,10 @@ __device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uin
     {
         const uint4* b0 = tile_ptr(wave);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) bq[0][kt] = b0[kt * 64];
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt < 4) bq[0][kt] = pre.q[kt];
+            else bq[0][kt] = b0[kt * 64];
+        }
     }
 #pragma unroll
     for (int pr = 0; pr < PAIRS; ++pr) {
@@ -587,7 +600,8 @@ static_assert(NTH == 512, "the mask prefetch maps 512 threads onto 16 rows");
 
 template <int KT, int NT>
 __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned char* mk, int ldh,
-                                           float* __restrict__ dOut_, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane) {
+                                           float* __restrict__ dOut_, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane,
+                                           const WPre& pre) {
     __bf16* __restrict__ dOut = reinterpret_cast<__bf16*>(dOut_);       // gradient row buffers hold bf16 in the fused path (see k_chain_bwd)
     wg_gemm_wide<KT, NT>(in, LD_H, Wt, wave, lane, [&](int j, int nt, const f32x4& acc) {
         const int n = nt * 16 + (lane & 15);
@@ -599,7 +613,7 @@ __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __rest
             if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
             dst[row * LD_H + n] = (__bf16)v;
         }
-    });
+    }, pre);
 }
 
 }  // namespace
@@ -750,6 +764,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             mkq[7] = *reinterpret_cast<const float4*>(P.He1 + rr256a * SP_ENC_H1 + (tid & 63) * 4);
             mkq[8] = *reinterpret_cast<const float4*>(P.He1 + rr256b * SP_ENC_H1 + (tid & 63) * 4);
         }
+        WPre wpre;
+        wide_prefetch<4, 7>(a.wt[CW_OBJ1], wave, lane, wpre);     // first tile of the first data-gradient GEMM of this wavefront
         unsigned int gxy_pf[7][4];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -832,7 +848,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mk_sh + MK_HO1, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mk_sh + MK_HO1, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 30>(a.wt[CW_OBJ0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int j, int nt, const f32x4& acc) {
@@ -844,7 +861,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 if (n < F + CTX) slot[row][n] = acc[rr];
                 else tailO[row][n - (F + CTX)] = acc[rr];
             }
-        });
+        }, wpre);
+        wide_prefetch<4, 7>(a.wt[CW_ZH], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
@@ -871,10 +889,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mk_sh + MK_HZ2, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mk_sh + MK_HZ2, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 7>(a.wt[CW_Z1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mk_sh + MK_HZ1, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane);
+        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mk_sh + MK_HZ1, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 30>(a.wt[CW_Z0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int j, int nt, const f32x4& acc) {
@@ -886,7 +906,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 if (n < F + CTX) slot[row][n] += acc[rr];
                 else tailZ[row][n - (F + CTX)] = acc[rr];
             }
-        });
+        }, wpre);
+        wide_prefetch<4, 8>(a.wt[CW_ENC2], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         // ---- attributes -> gradient of the encoder output
@@ -906,10 +927,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mk_sh + MK_HE2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane);
+        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mk_sh + MK_HE2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 16>(a.wt[CW_ENC1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mk_sh + MK_HE1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane);
+        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mk_sh + MK_HE1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane, wpre);
+        wide_prefetch<8, 49>(a.wt[CW_ENC0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273): the glimpse gradient is never stored;
@@ -933,7 +956,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                         gsum[rr][0] += gix; gsum[rr][1] += giy; gsum[rr][2] += gix * X; gsum[rr][3] += giy * Y;
                     }
                 }
-            });
+            }, wpre);
+            wide_prefetch<4, 7>(a.wt[CW_BOXH], wave, lane, wpre);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -981,10 +1005,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mk_sh + MK_HB2, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mk_sh + MK_HB2, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 7>(a.wt[CW_BOX1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mk_sh + MK_HB1, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane);
+        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mk_sh + MK_HB1, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        wide_prefetch<4, 21>(a.wt[CW_BOX0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
         wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int j, int nt, const f32x4& acc) {
@@ -992,7 +1018,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             if (n >= F + CTX) return;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) slot[(lane >> 4) * 4 + rr][n] += acc[rr];
-        });
+        }, wpre);
         lds_barrier();
         CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
