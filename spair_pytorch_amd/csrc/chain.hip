@@ -98,14 +98,23 @@ __device__ __forceinline__ void wg_gemm(const __bf16* inA, int ldA, const __bf16
 
 // epilogue: v = acc + bias (+relu); optional bf16 copy to LDS (next layer's input), fp32 copy to LDS (head outputs) and to the
 // HBM row buffer (what backward / weight-gradient GEMMs read).  Lane holds col = nt*16 + (lane&15), rows (lane>>4)*4 + r.
+// relu layers also leave their sign bits: one wave ballot per accumulator register r (bit = lane, i.e. row group lane>>4, column lane&15
+// of the tile) at mb[nt*4 + r] -- the backward kernel reads 2 KB of bits per wavefront instead of re-reading 56 KB of activations
+constexpr int MB_HB1 = 0, MB_HB2 = 7, MB_HE1 = 14, MB_HE2 = 30, MB_HZ1 = 38, MB_HZ2 = 45, MB_HO1 = 52, MB_HO2 = 59, MB_TILES = 66;
 template <int NT, bool RELU, int NT0 = 0>
 __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restrict__ bias, int nout, __bf16* lds_bf, int ld_bf,
                                          float* lds_f, int ld_f, float* __restrict__ hbm, int ld_hbm, const int* row_r, int nc, int wave,
-                                         int lane) {
+                                         int lane, unsigned long long* __restrict__ mb = nullptr) {
     const int nt = NT0 + wave;
     const int n = nt * 16 + (lane & 15);
-    if (nt >= NT || n >= nout) return;
-    const float bv = bias[n];
+    if (nt >= NT) return;                                        // wave-uniform
+    const float bv = bias[min(n, nout - 1)];
+    if (RELU && mb) {
+        const unsigned long long b0 = __ballot((acc[0] + bv) > 0.f), b1 = __ballot((acc[1] + bv) > 0.f);
+        const unsigned long long b2 = __ballot((acc[2] + bv) > 0.f), b3 = __ballot((acc[3] + bv) > 0.f);
+        if (lane < 4) mb[nt * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));     // one 32-byte LDS write
+    }
+    if (n >= nout) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = (lane >> 4) * 4 + r;
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float noise_sh[MT][REC];      // [eps_box 4 | eps_attr A | eps_depth | u_pres]
     __shared__ unsigned short cell_hw[32 * 32];
     __shared__ float pbase_sh[32];                                         // base coordinate of glimpse index j (stn_base), no division per element
+    __shared__ __attribute__((aligned(16))) unsigned long long mbf_sh[MB_TILES * 4];
     __shared__ __attribute__((aligned(16))) _Float16 img_sh[IMG ? IMG_MAX * IMG_MAX : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Xc[MT * LD_XC];
     __shared__ __attribute__((aligned(16))) __bf16 XtZ[MT * LD_XT];
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         const int c0 = dstart_sh[t];
         const int nc = dstart_sh[t + 1] - c0;
+        unsigned long long* const mbt = mbf_sh;                 // sign-bit ballots of this wavefront, flushed to HBM at its end
         float (*rec_cur)[REC] = recs[t & 3];
         if (tid < MT) {
             const int cp = c0 + min(tid, nc - 1);
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -381,8 +392,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<25, 16, 8>(a.w[CW_ENC0], pipe, wave, lane);
             wg_gemm<25, 0, 16, 8>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
-            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane);
+            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
+            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
-            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane);
+            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, acc, wave, lane);
             pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -503,6 +514,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
+        if (tid < MB_TILES * 4) P.mbits[((size_t)b * T + t) * (MB_TILES * 4) + tid] = mbf_sh[tid];     // one coalesced 2 KB store
         CH_STAMP();
     }
 }
@@ -585,21 +597,17 @@ __device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uin
     }
 }
 
-// One hidden layer of the data-gradient chain: dPre[16, nout] = (dOut . W) * relu'(H).  The relu masks come from the forward
-// activations in HBM: at the start of every wavefront step all 7 masks of the step are fetched with coalesced 16-byte loads
-// (7 per thread -- per-lane 4-byte loads in the MFMA output layout would need 32 and, together with the other prefetches,
-// overflow the 6-bit vmcnt counter, which serialises the wave) and parked in LDS as one byte per element.
-constexpr int MK_H = 112, MK_ROW = 5 * MK_H + 128 + 256;        // per-row mask bytes: Ho1 Hz2 Hz1 Hb2 Hb1 | He2 | He1
-constexpr int MK_HO1 = 0, MK_HZ2 = MK_H, MK_HZ1 = 2 * MK_H, MK_HB2 = 3 * MK_H, MK_HB1 = 4 * MK_H, MK_HE2 = 5 * MK_H, MK_HE1 = 5 * MK_H + 128;
-constexpr int MK_LOADS = 9;
+// One hidden layer of the data-gradient chain: dPre[16, nout] = (dOut . W) * relu'(H).  The relu masks are the sign bits the forward
+// kernel left as wave ballots (mb[tile*4 + r], bit = lane): the MFMA output layout is the same in both kernels, so a lane tests its
+// own bit.  All 66 tiles x 4 words of a wavefront (2 KB) are fetched with one 8-byte load per thread and parked in LDS.
+static_assert(NTH >= MB_TILES * 4, "one sign-bit word per thread");
 // backward bundle row (floats): encoder output [mean A | logstd A] (104) | sd_attr (56) | g_attr from the decoder (56) | eps_attr (56)
 // | nbox 4 | g_nbox 4 | box logstd 4 | stat 12 | eps_box 4 | eps_depth, z_pres, g_pres, obj logit, g_depth, depth mean, depth logstd
 constexpr int BD_OE = 0, BD_SD = 104, BD_GA = 160, BD_EA = 216, BD_NB = 272, BD_GNB = 276, BD_OBL = 280, BD_ST = 284, BD_EB = 296,
-              BD_EPSD = 300, BD_ZP = 301, BD_GPR = 302, BD_OO = 303, BD_GDR = 304, BD_OZ0 = 305, BD_OZ1 = 306, BD_W = 308;                                     // float4 loads per thread and wavefront
-static_assert(NTH == 512, "the mask prefetch maps 512 threads onto 16 rows");
+              BD_EPSD = 300, BD_ZP = 301, BD_GPR = 302, BD_OO = 303, BD_GDR = 304, BD_OZ0 = 305, BD_OZ1 = 306, BD_W = 308;
 
 template <int KT, int NT>
-__device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned char* mk, int ldh,
+__device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned long long* mb, int ldh,
                                            float* __restrict__ dOut_, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane,
                                            const WPre& pre) {
     __bf16* __restrict__ dOut = reinterpret_cast<__bf16*>(dOut_);       // gradient row buffers hold bf16 in the fused path (see k_chain_bwd)
@@ -609,7 +617,7 @@ __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __rest
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = (lane >> 4) * 4 + rr;
-            const float v = mk[row * MK_ROW + n] ? acc[rr] : 0.f;
+            const float v = ((mb[nt * 4 + rr] >> lane) & 1ull) ? acc[rr] : 0.f;
             if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
             dst[row * LD_H + n] = (__bf16)v;
         }
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ float gnb[MT][4], nb_sh[MT][4];
     __shared__ float dOo_sh[MT], zp_sh[MT];
     __shared__ float edge_acc[REC];
-    __shared__ __attribute__((aligned(16))) unsigned char mk_sh[MT * MK_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ int cons_sh[MT][4], nbr_row[MT][4];
     // per-row scalars and vectors of the wavefront, fetched one wavefront AHEAD with coalesced loads and parked here: no global
@@ -745,25 +753,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
-        // One static, branch-free global_load per (layer, thread): a pointer picked from a runtime-indexed table degrades to FLAT
-        // loads behind a branch, and hipcc then waits vmcnt(0)+lgkmcnt(0) after every one of them (7 serialised HBM round trips,
-        // measured 6 us per wavefront).  Rows >= nc re-read row nc-1 (their masks are never used).
-        float4 mkq[MK_LOADS];
-        {
-            const int r100 = min(tid / 25, MT - 1), q100 = tid - (tid / 25) * 25;          // 100-wide layers: 16 x 25 float4
-            const size_t rr100 = (size_t)row_r[min(r100, nc - 1)];
-            mkq[0] = *reinterpret_cast<const float4*>(P.Ho1 + rr100 * SP_LDH + q100 * 4);
-            mkq[1] = *reinterpret_cast<const float4*>(P.Hz2 + rr100 * SP_LDH + q100 * 4);
-            mkq[2] = *reinterpret_cast<const float4*>(P.Hz1 + rr100 * SP_LDH + q100 * 4);
-            mkq[3] = *reinterpret_cast<const float4*>(P.Hb2 + rr100 * SP_LDH + q100 * 4);
-            mkq[4] = *reinterpret_cast<const float4*>(P.Hb1 + rr100 * SP_LDH + q100 * 4);
-            mkq[5] = *reinterpret_cast<const float4*>(P.Ho2 + rr100 * SP_LDH + q100 * 4);
-            const size_t rr128 = (size_t)row_r[min(tid >> 5, nc - 1)];                     // He2: 16 x 32 float4
-            mkq[6] = *reinterpret_cast<const float4*>(P.He2 + rr128 * SP_ENC_H2 + (tid & 31) * 4);
-            const size_t rr256a = (size_t)row_r[min(tid >> 6, nc - 1)], rr256b = (size_t)row_r[min(8 + (tid >> 6), nc - 1)];   // He1: 16 x 64
-            mkq[7] = *reinterpret_cast<const float4*>(P.He1 + rr256a * SP_ENC_H1 + (tid & 63) * 4);
-            mkq[8] = *reinterpret_cast<const float4*>(P.He1 + rr256b * SP_ENC_H1 + (tid & 63) * 4);
-        }
+        // relu sign bits of this wavefront: one word per thread to park (threads 0..263), plus the word that holds this thread's four
+        // Ho2 elements for the rank-1 stage below (row tid/25, columns 4*(tid%25)..+3 -> tile q4/4, register row&3)
+        const unsigned long long* const mbt = P.mbits + ((size_t)b * T + t) * (MB_TILES * 4);
+        const unsigned long long mbq = mbt[min(tid, MB_TILES * 4 - 1)];
+        const int ho_row = min(tid / 25, MT - 1), ho_q4 = tid - (tid / 25) * 25;
+        const unsigned long long mbo = mbt[(MB_HO2 + (ho_q4 >> 2)) * 4 + (ho_row & 3)];
         WPre wpre;
         wide_prefetch<4, 7>(a.wt[CW_OBJ1], wave, lane, wpre);     // first tile of the first data-gradient GEMM of this wavefront
         unsigned int gxy_pf[7][4];
@@ -815,32 +810,15 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        // park the prefetched relu masks in LDS (one byte per element); first consumer is the next stage
-        {
-            auto pack = [](const float4& v) {
-                return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 0x100u : 0u) | (v.z > 0.f ? 0x10000u : 0u) | (v.w > 0.f ? 0x1000000u : 0u);
-            };
-            if (tid < MT * 25) {
-                const int row = tid / 25, q4 = tid - row * 25;
-                unsigned char* m = mk_sh + row * MK_ROW + q4 * 4;
-                *reinterpret_cast<unsigned int*>(m + MK_HO1) = pack(mkq[0]);
-                *reinterpret_cast<unsigned int*>(m + MK_HZ2) = pack(mkq[1]);
-                *reinterpret_cast<unsigned int*>(m + MK_HZ1) = pack(mkq[2]);
-                *reinterpret_cast<unsigned int*>(m + MK_HB2) = pack(mkq[3]);
-                *reinterpret_cast<unsigned int*>(m + MK_HB1) = pack(mkq[4]);
-            }
-            *reinterpret_cast<unsigned int*>(mk_sh + (tid >> 5) * MK_ROW + MK_HE2 + (tid & 31) * 4) = pack(mkq[6]);
-            *reinterpret_cast<unsigned int*>(mk_sh + (tid >> 6) * MK_ROW + MK_HE1 + (tid & 63) * 4) = pack(mkq[7]);
-            *reinterpret_cast<unsigned int*>(mk_sh + (8 + (tid >> 6)) * MK_ROW + MK_HE1 + (tid & 63) * 4) = pack(mkq[8]);
-        }
+        if (tid < MB_TILES * 4) mb_sh[tid] = mbq;            // first consumer is behind the next barrier
         // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu: the thread that prefetched a float4 of Ho2 produces those 4
         // elements (no LDS round trip for this mask)
         if (tid < MT * 25) {
             const int row = tid / 25, q4 = tid - row * 25;
             const float4 w = *reinterpret_cast<const float4*>(&wobj_sh[q4 * 4]);
             const float d = row < nc ? dOo_sh[row] : 0.f;
-            const float4 v = make_float4(mkq[5].x > 0.f ? d * w.x : 0.f, mkq[5].y > 0.f ? d * w.y : 0.f, mkq[5].z > 0.f ? d * w.z : 0.f,
-                                         mkq[5].w > 0.f ? d * w.w : 0.f);
+            const unsigned int hb = (unsigned int)(mbo >> ((row >> 2) * 16 + (q4 & 3) * 4)) & 15u;      // bits of columns 4*q4 .. 4*q4+3
+            const float4 v = make_float4((hb & 1u) ? d * w.x : 0.f, (hb & 2u) ? d * w.y : 0.f, (hb & 4u) ? d * w.z : 0.f, (hb & 8u) ? d * w.w : 0.f);
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
             if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dHo2) + (size_t)row_r[row] * SP_LDH + q4 * 4) = o;
@@ -848,7 +826,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mk_sh + MK_HO1, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mb_sh + MB_HO1 * 4, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 30>(a.wt[CW_OBJ0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -889,11 +867,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mk_sh + MK_HZ2, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mb_sh + MB_HZ2 * 4, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 7>(a.wt[CW_Z1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mk_sh + MK_HZ1, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mb_sh + MB_HZ1 * 4, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 30>(a.wt[CW_Z0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -927,11 +905,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mk_sh + MK_HE2, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mb_sh + MB_HE2 * 4, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 16>(a.wt[CW_ENC1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mk_sh + MK_HE1, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mb_sh + MB_HE1 * 4, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<8, 49>(a.wt[CW_ENC0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -1005,11 +983,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mk_sh + MK_HB2, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mb_sh + MB_HB2 * 4, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 7>(a.wt[CW_BOX1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mk_sh + MK_HB1, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mb_sh + MB_HB1 * 4, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 21>(a.wt[CW_BOX0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();

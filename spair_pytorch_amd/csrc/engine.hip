@@ -217,6 +217,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.Za = c.take<float>(N * L.ld_rec);
     b.Za = w.Za;
     b.gxy = chain_fwd_supported(d) ? c.take<unsigned int>(N * L.ld_gl) : nullptr;
+    b.mbits = chain_fwd_supported(d) ? c.take<unsigned long long>((size_t)d.B * (3 * d.G - 2) * 66 * 4) : nullptr;
     w.Hd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es)); w.Hd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es));
     w.S = c.take<float>(N * w.ld_s);
     w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
