@@ -940,9 +940,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float v = gsum[rr][k];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    float v = gsum[rr][k];          // sum over the 16 lanes of a row group: DPP, no LDS traffic
+                    v = dpp_add_<0xB1>(v); v = dpp_add_<0x4E>(v); v = dpp_add_<0x141>(v); v = dpp_add_<0x140>(v);
                     gsum[rr][k] = v;
                 }
                 const int row = (lane >> 4) * 4 + rr;
