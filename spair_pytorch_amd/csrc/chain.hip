@@ -798,8 +798,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], prior_sh[l], prior_sh[6 + l]);
                 if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], prior_sh[5], prior_sh[6 + 5]);
             }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
+            kl = dpp_add_<0xB1>(kl); kl = dpp_add_<0x4E>(kl); kl = dpp_add_<0x141>(kl); kl = dpp_add_<0x140>(kl);     // 16-lane rows (DPP)
+            kl += __shfl_xor(kl, 16, 64);                                                                             // the two rows of a 32-lane group
             if (row < nc && l == 0) {
                 const size_t r = row_r[row];
                 const float* bd = bundle_sh[row];
