@@ -35,6 +35,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// orders a wave's own LDS writes before its later LDS reads (other lanes' data), no workgroup barrier
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
     union { uint4 u; bf16x8 b; } c;
     c.u = v;
@@ -637,6 +644,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ float dOo_sh[MT], zp_sh[MT];
     __shared__ float edge_acc[REC];
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
+    __shared__ float gtile[NW][16][17];       // wave-private transpose tile of the glimpse-gradient epilogue
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ int cons_sh[MT][4], nbr_row[MT][4];
     // per-row scalars and vectors of the wavefront, fetched one wavefront AHEAD with coalesced loads and parked here: no global
@@ -761,14 +769,16 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         const unsigned long long mbo = mbt[(MB_HO2 + (ho_q4 >> 2)) * 4 + (ho_row & 3)];
         WPre wpre;
         wide_prefetch<4, 7>(a.wt[CW_OBJ1], wave, lane, wpre);     // first tile of the first data-gradient GEMM of this wavefront
-        unsigned int gxy_pf[7][4];
+        // saved glimpse derivatives for this wave's 7 ENC0 tiles, in the row-major mapping of the epilogue's second half (lane -> row
+        // lane>>2, 4 consecutive elements): 7 coalesced 16-byte loads per lane (28 dword gathers in the MFMA output layout stalled the
+        // memory pipeline for ~1.5 us)
+        uint4 gxy_pf[7];
+        {
+            const size_t grow = (size_t)row_r[min(lane >> 2, nc - 1)] * L.ld_gl;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int e = (wave + NW * j) * 16 + (lane & 15);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = (lane >> 4) * 4 + rr;
-                gxy_pf[j][rr] = P.gxy[(size_t)row_r[min(row, nc - 1)] * L.ld_gl + min(e, GLN - 1)];     // branch-free; unused lanes re-read
+            for (int j = 0; j < 7; ++j) {
+                const int e0 = min((wave + NW * j) * 16 + (lane & 3) * 4, GLN - 4);
+                gxy_pf[j] = *reinterpret_cast<const uint4*>(P.gxy + grow + e0);
             }
         }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
@@ -916,39 +926,36 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273): the glimpse gradient is never stored;
         // each element meets the (d val/d gx, d val/d gy) pair the forward kernel saved, lane sums are reduced once per layer
         {
-            float gsum[4][4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) gsum[rr][0] = gsum[rr][1] = gsum[rr][2] = gsum[rr][3] = 0.f;
+            // the accumulator tile goes through a wave-private LDS tile so that each lane meets 4 consecutive elements of ONE row --
+            // exactly one prefetched uint4 of (d val/d gx, d val/d gy) pairs
+            float gs[4] = {0.f, 0.f, 0.f, 0.f};
+            float (*tl)[17] = gtile[wave];
+            const int trow = lane >> 2, tc0 = (lane & 3) * 4;
             wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int j, int nt, const f32x4& acc) {
-                const int e = nt * 16 + (lane & 15);
-                if (e >= GLN) return;
-                const int gi = e / PG, gj = e - gi * PG;
-                const float X = pbase_sh[gj], Y = pbase_sh[gi];
+                if (nt >= 49 || j >= 7) return;                           // wave-uniform: tiles past the glimpse
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = (lane >> 4) * 4 + rr;
-                    if (row < nc && j < 7) {
-                        union { unsigned int u; __bf16 h[2]; } pk;
-                        pk.u = gxy_pf[j < 7 ? j : 0][rr];
-                        const float gix = acc[rr] * (float)pk.h[0], giy = acc[rr] * (float)pk.h[1];
-                        gsum[rr][0] += gix; gsum[rr][1] += giy; gsum[rr][2] += gix * X; gsum[rr][3] += giy * Y;
-                    }
+                for (int rr = 0; rr < 4; ++rr) tl[(lane >> 4) * 4 + rr][lane & 15] = acc[rr];
+                wave_lds_sync();
+                const int e0 = nt * 16 + tc0;
+                const int gi = e0 / PG, gj0 = e0 - gi * PG;             // PG % 4 == 0: the 4 elements share the glimpse row gi
+                const float Y = pbase_sh[gi];
+                const unsigned int pkq[4] = {gxy_pf[j].x, gxy_pf[j].y, gxy_pf[j].z, gxy_pf[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    union { unsigned int u; __bf16 h[2]; } pk;
+                    pk.u = pkq[q];
+                    const float d = trow < nc ? tl[trow][tc0 + q] : 0.f;
+                    const float gix = d * (float)pk.h[0], giy = d * (float)pk.h[1];
+                    gs[0] += gix; gs[1] += giy; gs[2] = fmaf(gix, pbase_sh[gj0 + q], gs[2]); gs[3] = fmaf(giy, Y, gs[3]);
                 }
+                wave_lds_sync();
             }, wpre);
             wide_prefetch<4, 7>(a.wt[CW_BOXH], wave, lane, wpre);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = gsum[rr][k];          // sum over the 16 lanes of a row group: DPP, no LDS traffic
-                    v = dpp_add_<0xB1>(v); v = dpp_add_<0x4E>(v); v = dpp_add_<0x141>(v); v = dpp_add_<0x140>(v);
-                    gsum[rr][k] = v;
-                }
-                const int row = (lane >> 4) * 4 + rr;
-                if ((lane & 15) == 0 && row < nc) {
-                    atomicAdd(&gnb[row][0], 2.f * gsum[rr][0]); atomicAdd(&gnb[row][1], 2.f * gsum[rr][1]);   // tx = 2*xt - 1
-                    atomicAdd(&gnb[row][2], gsum[rr][2]); atomicAdd(&gnb[row][3], gsum[rr][3]);
-                }
+            for (int k = 0; k < 4; ++k) { gs[k] = dpp_add_<0xB1>(gs[k]); gs[k] = dpp_add_<0x4E>(gs[k]); }      // the 4 lanes of a row
+            if ((lane & 3) == 0 && trow < nc) {
+                atomicAdd(&gnb[trow][0], 2.f * gs[0]); atomicAdd(&gnb[trow][1], 2.f * gs[1]);                   // tx = 2*xt - 1
+                atomicAdd(&gnb[trow][2], gs[2]); atomicAdd(&gnb[trow][3], gs[3]);
             }
         }
         lds_barrier();
