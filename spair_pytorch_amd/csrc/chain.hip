@@ -204,26 +204,26 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     // current one: thread -> (row, 4 features) and 2 x (row, noise slot)
     float4 pf_feat = make_float4(0.f, 0.f, 0.f, 0.f);
     float pf_noise[2] = {0.f, 0.f};
-    auto prefetch = [&](int tn, int tidv) {
+    auto prefetch = [&](int tn, int tidv) {       // branch-free (clamped indices): conditional loads would make every later wait on the
+                                                  // weight ring a vmcnt(0), i.e. a wait for THESE loads
         const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
-        if (tidv < MT * (F / 4)) {
-            const int row = tidv / (F / 4), c4 = (tidv - row * (F / 4)) * 4;
+        {
+            const int tf = min(tidv, MT * (F / 4) - 1);
+            const int row = tf / (F / 4), c4 = (tf - row * (F / 4)) * 4;
             const int hw = cell_hw[c0n + min(row, ncn - 1)];
             pf_feat = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + (hw >> 8)) * G + (hw & 255)) * P.ld_feat + c4);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int i = tidv + q * NTH;
-            if (i < MT * REC) {
-                const int row = i / REC, j = i - row * REC;
-                const int hw = cell_hw[c0n + min(row, ncn - 1)];
-                const size_t cell = (size_t)(hw >> 8) * G + (hw & 255);
-                const float* src = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
-                                   : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
-                                   : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
-                                                 : P.u_pres + (size_t)b * G * G;
-                pf_noise[q] = src[cell];
-            }
+            const int i = min(tidv + q * NTH, MT * REC - 1);
+            const int row = i / REC, j = i - row * REC;
+            const int hw = cell_hw[c0n + min(row, ncn - 1)];
+            const size_t cell = (size_t)(hw >> 8) * G + (hw & 255);
+            const float* src = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
+                               : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
+                               : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
+                                             : P.u_pres + (size_t)b * G * G;
+            pf_noise[q] = src[cell];
         }
     };
     auto park = [&](int tidv) {
