@@ -104,13 +104,16 @@ class _StepFn(torch.autograd.Function):
         loss_terms, recon, z_where, z_pres = model._run_forward(x, step, noise, train=True)
         ctx.model, ctx.x, ctx.step, ctx.noise = model, x, step, noise
         ctx.mark_non_differentiable(recon, z_where, z_pres)
+        ctx.set_materialize_grads(False)     # otherwise autograd zero-fills a gradient for each non-differentiable output (17 MB per step)
         model._loss_terms = loss_terms
         return loss_terms[0].clone(), recon, z_where, z_pres
 
     @staticmethod
     def backward(ctx, g_loss, g_recon, g_zw, g_zp):
+        if g_loss is None:
+            return None, None, None, None, None
         ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float())
-        return torch.zeros_like(g_loss), None, None, None, None
+        return None, None, None, None, None      # the parameter gradients went straight into the flat buffer
 
 
 class SPAIR(nn.Module):
