@@ -206,7 +206,7 @@ __device__ __forceinline__ int rb_sweeps(int TU, int TV) {
     return ((TU + cw - 1) >> sh) * ((TV + rows - 1) >> rsh);
 }
 
-__global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+__global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                      const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
                                                      const float4* __restrict__ aux, const float* __restrict__ gloss,
                                                      float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S
                                                      float obj_scale, float alpha_scale, int g_bf16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[RB_WAVES][6];
+    __shared__ float geo[16];
     const int PS = P + 2, NTX = PS * PS;                     // zero-bordered sprite
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float4* Ssh = reinterpret_cast<float4*>(sm);             // (grey, alpha, importance, -)
@@ -224,13 +225,33 @@ __global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S
     // every object of sample b lands on XCD b % 8
     const int b = blockIdx.x, k = blockIdx.y;
     const int r = k * B + b;
-    const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
-    const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
-    const float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
     const float4* auxb = aux + (size_t)b * I * I;
     const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
+    // The object's geometry is the same for every thread, and gfx9 has no scalar float ALU: computed by all four waves it is ~300
+    // VALU instructions per wave and object in a kernel that is VALU-issue bound.  Wave 0 computes it while the others already
+    // fetch the sprite; everybody reads it from LDS behind the staging barrier.
+    if (wave == 0) {
+        const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
+        const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
+        const float ax_ = 1.f / nb.z, bx_ = -tx / nb.z, ay_ = 1.f / nb.w, by_ = -ty / nb.w;
+        float sx0_, sxa_, sy0_, sya_;
+        src_affine(ax_, bx_, I, P, ac, sx0_, sxa_);
+        src_affine(ay_, by_, I, P, ac, sy0_, sya_);
+        const float isx_ = __builtin_amdgcn_rcpf(sxa_), isy_ = __builtin_amdgcn_rcpf(sya_);   // only used for (conservative) index bounds
+        int TU_ = P, TV_ = P;                                     // texel tile whose pixel footprint fits the staging buffer
+        while (rb_span(TU_, isx_, I) * rb_span(TV_, isy_, I) > RB_CAP && rb_sweeps(TU_, TV_) > 1) {
+            if (rb_span(TV_, isy_, I) >= rb_span(TU_, isx_, I) && TV_ > 1) TV_ = (TV_ + 1) >> 1;
+            else if (TU_ > 1) TU_ = (TU_ + 1) >> 1;
+            else TV_ = (TV_ + 1) >> 1;
+        }
+        if (lane == 0) {
+            geo[0] = ax_; geo[1] = bx_; geo[2] = ay_; geo[3] = by_; geo[4] = sx0_; geo[5] = sxa_; geo[6] = sy0_; geo[7] = sya_;
+            geo[8] = isx_; geo[9] = isy_; geo[10] = -mult * ax_; geo[11] = -mult * ay_;      // d(source coord)/d(t) incl. the unnormalisation
+            geo[12] = __int_as_float(TU_); geo[13] = __int_as_float(TV_);
+        }
+    }
     if (P <= 32) {
         // all loads are issued before the first LDS write
         constexpr int RV = RB_T / 32;                         // rows per sweep
@@ -266,18 +287,9 @@ __global__ __launch_bounds__(RB_T) void k_render_bwd(const float* __restrict__ S
     float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f, g_pr = 0.f, g_dp = 0.f;
     // source coordinate of pixel (px,py) ~ (sx0 + px*sxa, sy0 + py*sya), slopes > 0: used for index BOUNDS only (each
     // bound keeps a spare pixel); the coordinates themselves come from src_from_base like the forward's
-    float sx0, sxa, sy0, sya;
-    src_affine(ax, bx, I, P, ac, sx0, sxa);
-    src_affine(ay, by, I, P, ac, sy0, sya);
-    const float isx = __builtin_amdgcn_rcpf(sxa), isy = __builtin_amdgcn_rcpf(sya);     // only used for (conservative) index bounds
-    const float cgx = -mult * ax, cgy = -mult * ay;           // d(source coord)/d(t) incl. the unnormalisation
-    // texel tile whose pixel footprint fits the staging buffer
-    int TU = P, TV = P;
-    while (rb_span(TU, isx, I) * rb_span(TV, isy, I) > RB_CAP && rb_sweeps(TU, TV) > 1) {
-        if (rb_span(TV, isy, I) >= rb_span(TU, isx, I) && TV > 1) TV = (TV + 1) >> 1;
-        else if (TU > 1) TU = (TU + 1) >> 1;
-        else TV = (TV + 1) >> 1;
-    }
+    const float ax = geo[0], bx = geo[1], ay = geo[2], by = geo[3], sx0 = geo[4], sy0 = geo[6];
+    const float isx = geo[8], isy = geo[9], cgx = geo[10], cgy = geo[11];
+    const int TU = __float_as_int(geo[12]), TV = __float_as_int(geo[13]);
     for (int tv0 = 0; tv0 < P; tv0 += TV)
     for (int tu0 = 0; tu0 < P; tu0 += TU) {
         const int tu1 = min(tu0 + TU, P), tv1 = min(tv0 + TV, P);      // texel tile [tu0,tu1) x [tv0,tv1)
