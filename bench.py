@@ -150,9 +150,9 @@ def main():
     d = model._last["engine"]["dims"]
     N = B * d.G * d.G
     P2 = d.P * d.P
-    sprite_b = N * P2 * 2 * 4                    # fp32 (grey, alpha) sprites
+    sprite_b = N * P2 * 2 * (2 if args.dtype == "bf16" else 4)    # (grey, alpha) sprites: bf16 pairs in the bf16 step, fp32 otherwise
     render_fwd_bytes = sprite_b + N * 6 * 4 + B * d.I * d.I * 4          # 429.4 MB at config 2
-    render_bwd_bytes = render_fwd_bytes + sprite_b                         # + the gradient-sprite write
+    render_bwd_bytes = render_fwd_bytes + N * P2 * 2 * (2 if args.dtype == "bf16" else 4)   # + the d-logits write
     peak_f = MFMA_PEAK_TFLOPS["bf16" if args.dtype == "bf16" else "f32"]
     c1 = [c for c in [(d.conv_k[1], d.conv_s[1], d.conv_c[1])]][0]
     h0 = (d.I + d.pad_pre + d.pad_post - d.conv_k[0]) // d.conv_s[0] + 1

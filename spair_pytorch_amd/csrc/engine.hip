@@ -18,8 +18,8 @@ int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld
 int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, int ld, float* dnbox, int r0, int R, int C, int I, int P, int ac, int px16, hipStream_t s);
 int render_sprite_act(float* S, int ld, int N, int per, int CH, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);
 int render_num_blocks(int B, int I);
-int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s);
-int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, hipStream_t s);
+int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s);
+int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s);
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
@@ -848,6 +848,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             memset(&g, 0, sizeof(g));
             g.A = c.w.Hd2; g.lda = SP_DEC_H2; g.B = c.w.lin_wf[LIN_DEC2]; g.ldb = K2; g.C = c.w.S; g.ldc = c.w.ld_s; g.M = N; g.N = per; g.K = K2;
             g.bias = params + PL.lin[LIN_DEC2].b; g.sprite_ch = d->C + 1;
+            g.c_bf16 = b16;      // bf16 step: the sprites leave as bf16 (grey, alpha) pairs -- half the bytes for the renderer, both ways
             g.obj_scale = d->obj_logit_scale; g.alpha_scale = d->alpha_logit_scale; g.alpha_bias = d->alpha_logit_bias;
             if (b16) TRY(spair_gemm_nt16_impl(g, false, c.s));
             else TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
@@ -857,7 +858,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     {
         ProfScope ps(PS_RENDER_FWD, c.s);
         TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
-                       c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s));
+                       c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16, c.s));
     }
     if (side && hipStreamWaitEvent(c.s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
     ProfScope psl(PS_LOSS, c.s);
@@ -943,7 +944,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         ProfScope ps(PS_RENDER_BWD, c.s);
         TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
-                       d->alpha_logit_scale, b16, c.s));
+                       d->alpha_logit_scale, b16, b16, c.s));
     }
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));

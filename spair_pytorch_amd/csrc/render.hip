@@ -19,6 +19,17 @@
 #define RT 16            // output tile side
 #define RCH 256          // objects culled per pass (= threads per block)
 
+// (grey, alpha) of texel idx of a sprite row: fp32 pairs, or bf16 pairs in the bf16 training step (the decoder GEMM writes them so)
+template <bool S16>
+__device__ __forceinline__ float2 ld_texel(const float* __restrict__ S, size_t idx) {
+    if constexpr (S16) {
+        const unsigned u = reinterpret_cast<const unsigned*>(S)[idx];
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    } else {
+        return reinterpret_cast<const float2*>(S)[idx];
+    }
+}
+
 struct Cand {
     float ax, bx, ay, by, pres, depth;
     int row;
@@ -58,6 +69,7 @@ __device__ __forceinline__ void src_affine(float a, float b, int nout, int nsrc,
     c0 = src_of(a, b, 0, nout, nsrc, ac);
 }
 
+template <bool S16>
 __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
                                                     const float* __restrict__ x, float* __restrict__ recon, float4* __restrict__ aux,
@@ -125,14 +137,14 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
                 const float fx = floorf(sx), fy = floorf(sy);
                 const int x0 = (int)fminf(fmaxf(fx, -1.f), (float)(P - 1)), y0 = (int)fminf(fmaxf(fy, -1.f), (float)(P - 1));
                 const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                const float* sp = S + (size_t)q.row * ld_s;
+                const size_t sp = ((size_t)q.row * ld_s) >> 1;          // texel index of the sprite's first (grey, alpha) pair
                 pr_ = q.pres; pd_ = q.pres * q.depth;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
                     const bool ok = cov && yy >= 0 && yy < P && xx >= 0 && xx < P;
                     w[t] = ok ? ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0) : 0.f;
-                    v[t] = *reinterpret_cast<const float2*>(sp + (min(max(yy, 0), P - 1) * P + min(max(xx, 0), P - 1)) * 2);
+                    v[t] = ld_texel<S16>(S, sp + (min(max(yy, 0), P - 1) * P + min(max(xx, 0), P - 1)));
                 }
             };
             fetch(0, tv, tw, prs, pdd);
@@ -206,6 +218,7 @@ __device__ __forceinline__ int rb_sweeps(int TU, int TV) {
     return ((TU + cw - 1) >> sh) * ((TV + rows - 1) >> rsh);
 }
 
+template <bool S16>
 __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                      const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
                                                      const float4* __restrict__ aux, const float* __restrict__ gloss,
@@ -256,13 +269,13 @@ __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
         // all loads are issued before the first LDS write
         constexpr int RV = RB_T / 32;                         // rows per sweep
         constexpr int NI = 32 / RV;
-        const float2* Sr = reinterpret_cast<const float2*>(S + (size_t)r * ld_s);
+        const size_t Sr = ((size_t)r * ld_s) >> 1;
         const int u = tid & 31;
         float2 t[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int v = RV * i + (tid >> 5);
-            t[i] = Sr[min(v, P - 1) * P + min(u, P - 1)];
+            t[i] = ld_texel<S16>(S, Sr + min(v, P - 1) * P + min(u, P - 1));
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -270,9 +283,9 @@ __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
             if (v < P && u < P) Ssh[(v + 1) * PS + u + 1] = make_float4(t[i].x, t[i].y, fmaxf(t[i].y * pd, 0.01f), 0.f);
         }
     } else {
-        const float2* Sr = reinterpret_cast<const float2*>(S + (size_t)r * ld_s);
+        const size_t Sr = ((size_t)r * ld_s) >> 1;
         for (int e = tid; e < P * P; e += RB_T) {
-            const float2 t = Sr[e];
+            const float2 t = ld_texel<S16>(S, Sr + e);
             const int v = e / P, u = e - v * P;
             Ssh[(v + 1) * PS + u + 1] = make_float4(t.x, t.y, fmaxf(t.y * pd, 0.01f), 0.f);
         }
@@ -438,11 +451,16 @@ int render_num_blocks(int B, int I) {
     return B * t * t;
 }
 
+// s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
-               float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s) {
+               float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
-    if (B <= 0 || HW <= 0 || I <= 0) return SPAIR_ERR_SHAPE;
-    hipLaunchKernelGGL(k_render_fwd, dim3(render_num_blocks(B, I)), dim3(256), 0, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,
+    if (B <= 0 || HW <= 0 || I <= 0 || (ld_s & 1)) return SPAIR_ERR_SHAPE;
+    if (s_bf16)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(render_num_blocks(B, I)), dim3(256), 0, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,
+                           reinterpret_cast<float4*>(aux), bce_partial, B, HW, I, P, ac);
+    else
+    hipLaunchKernelGGL(k_render_fwd<false>, dim3(render_num_blocks(B, I)), dim3(256), 0, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,
                        reinterpret_cast<float4*>(aux), bce_partial, B, HW, I, P, ac);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
@@ -450,13 +468,18 @@ int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, c
 
 int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I,
-               int P, int ac, float obj_scale, float alpha_scale, int g_bf16, hipStream_t s) {
+               int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if ((ld_s & 1) || (ld_g & 1)) return SPAIR_ERR_ALIGN;
     if (I > RB_CAP || (long long)I * I > 0x7fffffffLL / 4 || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)(P + 2) * (P + 2) * 4 + 3 * RB_CAP + I) * sizeof(float);
     if (lds > 65536) return SPAIR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_render_bwd, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
+    if (s_bf16)
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
+                           reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
+                           alpha_scale, g_bf16);
+    else
+    hipLaunchKernelGGL(k_render_bwd<false>, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
                        reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
                        alpha_scale, g_bf16);
     SPAIR_CHECK_LAUNCH();
@@ -466,7 +489,7 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
 extern "C" int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                                 const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P,
                                 int align_corners, void* stream) {
-    return render_fwd(sprites, ld_s, nbox, pres, depth, 1, x, recon, aux, bce_partial, B, HW, C, I, P, align_corners,
+    return render_fwd(sprites, ld_s, nbox, pres, depth, 1, x, recon, aux, bce_partial, B, HW, C, I, P, align_corners, 0,
                       (hipStream_t)stream);
 }
 extern "C" int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
@@ -474,5 +497,5 @@ extern "C" int spair_render_bwd(const float* sprites, int ld_s, const float* nbo
                                 float* ddepth, int B, int HW, int C, int I, int P, int align_corners, float obj_scale,
                                 float alpha_scale, void* stream) {
     return render_bwd(sprites, ld_s, nbox, pres, depth, 1, aux, grad_loss, dlogits, dnbox, dpres, ddepth, ld_s, B, HW, C, I, P,
-                      align_corners, obj_scale, alpha_scale, 0, (hipStream_t)stream);
+                      align_corners, obj_scale, alpha_scale, 0, 0, (hipStream_t)stream);
 }
