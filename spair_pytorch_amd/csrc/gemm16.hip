@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float t = (ch == g.sprite_ch - 1) ? v[e] * g.alpha_scale + g.alpha_bias : v[e] * g.obj_scale;
-                v[e] = 1.f / (expf(-t) + 1.f);
+                // bf16 sprites carry 8 mantissa bits: the hardware exp2 / rcp (1 ulp) are exact enough and 10x cheaper than expf + IEEE divide
+                v[e] = C16 ? __builtin_amdgcn_rcpf(__expf(-t) + 1.f) : 1.f / (expf(-t) + 1.f);
                 ch = (ch + 1 == g.sprite_ch) ? 0 : ch + 1;
             }
         }
