@@ -433,6 +433,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.sd_attr[r * L.ld_rec + j] = sd;
             P.rec[r * L.ld_rec + 4 + j] = attr;
             P.Za[r * L.ld_rec + j] = attr;
+            reinterpret_cast<__bf16*>(P.Za16)[r * L.ld_rec + j] = (__bf16)attr;      // decoder input, no conversion pass
             P.Xz[r * L.ld_x + L.x_attr + j] = attr;
             P.Xo[r * L.ld_x + L.x_attr + j] = attr;
         }
@@ -1010,7 +1011,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             const int row = idx / (F + CTX), n = idx - row * (F + CTX);
             const float v = slot[row][n];
             if (n < F) {
-                P.dfeat[((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n] = v;
+                reinterpret_cast<__bf16*>(P.dfeat16)[((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n] = (__bf16)v;   // read by the 1x1 stack
             } else {
                 const int s = (n - F) / REC;
                 if (nbr_row[row][s] < 0) atomicAdd(&edge_acc[(n - F) - s * REC], v);

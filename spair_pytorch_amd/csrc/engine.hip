@@ -223,6 +223,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
     w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
     w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
+    b.Za16 = w.Za16; b.dfeat16 = w.dfeat16;
     w.tn_part = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
@@ -597,7 +598,7 @@ static int backbone_bwd16(Ctx& c, float* grads) {
     const SpairDims& d = c.d;
     const int last = c.PL.n_conv - 1;
     const int N = d.B * d.G * d.G;
-    TRY(spair_to_bf16(c.w.dfeat, c.w.ld_feat, c.w.dfeat16, c.w.ld_feat, N, c.w.ld_feat, c.s));
+    if (!c.use_chain) TRY(spair_to_bf16(c.w.dfeat, c.w.ld_feat, c.w.dfeat16, c.w.ld_feat, N, c.w.ld_feat, c.s));   // the fused chain writes bf16 itself
     const int pw0 = pw_stack_first(c);
     if (pw0 <= last) {   // data gradients of the trailing 1x1 layers: one fused kernel, top layer first
         const void* Wd[4]; const void* gate[4]; void* dX[4]; int ldw[4], cout[4];
@@ -834,7 +835,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         const int b16 = d->dtype == SPAIR_BF16;
         const int K0 = round_up(PL.lin[LIN_DEC0].in, 8), K2 = round_up(PL.lin[LIN_DEC2].in, 8);
         if (b16) {   // hidden activations stored as bf16
-            TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));
+            if (!c.use_chain) TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));     // the fused chain writes bf16 itself
             TRY(nt16(c, c.w.Za16, L.ld_rec, c.w.lin_wf[LIN_DEC0], K0, c.w.Hd1, SP_DEC_H1, 1, N, SP_DEC_H1, K0, params + PL.lin[LIN_DEC0].b, nullptr, 0, 1));
             TRY(nt16(c, c.w.Hd1, SP_DEC_H1, c.w.lin_wf[LIN_DEC1], SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 1, N, SP_DEC_H2, SP_DEC_H1,
                      params + PL.lin[LIN_DEC1].b, nullptr, 0, 1));
