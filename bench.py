@@ -161,8 +161,7 @@ def main():
     dec_out_flop = 2.0 * N * 256 * (P2 * 2)
     # per-cell chain (k_chain_fwd / k_chain_bwd): arithmetic intensity ~50 flop/B, far left of the ridge (312 flop/B),
     # so HBM is the roofline that bounds it.  Algorithmic bytes per row: what the kernel MUST move --
-    # forward: every layer input it has to keep for the weight-gradient GEMMs + latents/records + the glimpse derivative
-    # pairs; backward: relu masks + records + glimpse derivatives in, every layer-output gradient + d feat out.
+    # forward: every layer input it has to keep for the weight-gradient GEMMs + latents/records + the glimpse derivative pairs.
     A, NPc, Fc = d.A, d.NP, d.F
     REC = 4 + A + 2                                                        # record [box4 | attr A | depth | pres]
     box_in = Fc + 4 * REC                                                  # features + 4 neighbour records
@@ -171,7 +170,9 @@ def main():
     hid = 2 * 100 + (256 + 128) + 2 * 100 + 2 * 100                       # relu outputs of the four nets
     fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)        # stores + (features, noise) loads
     outs = (100 + 100 + 8 + NPc) + (256 + 128 + 2 * A) + (100 + 100 + 2 + NPc) + (100 + 100 + 1)
-    bwd_row = 4 * (hid + REC + glim + 32) + 2 * outs + 4 * Fc                              # layer-output gradients leave as bf16
+    # backward: the 308-float per-row bundle + the glimpse derivative pairs + relu sign bits (66 tiles x 4 x 8 B per <= 8 rows) in;
+    # layer-output gradients and d feat out as bf16
+    bwd_row = 4 * (308 + glim) + 66 * 4 * 8 // 8 + 2 * (outs + Fc)
     chain_flop = 2.0 * N * (box_in * 100 + 100 * 100 + 100 * (8 + NPc) + glim * 256 + 256 * 128 + 128 * 2 * A
                             + z_in * 100 + 100 * 100 + 100 * (2 + NPc) + o_in * 100 + 100 * 100 + 100)
     kernels = {}
@@ -193,13 +194,13 @@ def main():
     #  overlap and are not per-kernel durations -- see profiles/ for the rocprofv3 kernel stats)
     # HBM traffic per launch from the committed PMC passes of this same command (two separate rocprofv3 --pmc runs; FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload it was collected on.
-    pmc_path = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
     if os.path.exists(pmc_path) and B == 256 and args.image == 128 and args.dtype == "bf16":
         pmc = json.load(open(pmc_path))
         for name, rec in kernels.items():
             if name in pmc:
                 rec["traffic"] = (pmc[name]["read_MB"] + pmc[name]["write_MB"]) * 1e6
-                rec["traffic_source"] = "profiles/r01_g_pmc_traffic.json"
+                rec["traffic_source"] = "profiles/r01_h_pmc_traffic.json"
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     roof = dict(kernels[dominant], kernel=dominant) if dominant else None
 
