@@ -129,7 +129,29 @@ __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restri
         if (RELU) v = fmaxf(v, 0.f);
         if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
         if (lds_f) lds_f[row * ld_f + n] = v;
-        if (row < nc) hbm[(size_t)row_r[row] * ld_hbm + n] = v;
+        if (hbm && row < nc) hbm[(size_t)row_r[row] * ld_hbm + n] = v;
+    }
+}
+
+// The "store wave": layers with 7 column tiles leave the 8th wave without work.  It copies the PREVIOUS stage's output rows from
+// LDS to their HBM row buffer (coalesced 16-byte stores) while the other seven compute -- their instruction streams then contain no
+// global store at all, so a wait for a weight fragment is only ever a wait for weight fragments.  (Hidden activations reach HBM as
+// the bf16-rounded values the next layer consumed; the weight-gradient GEMMs round their operands to bf16 anyway.)
+template <int NCOL>
+__device__ __forceinline__ void copy_rows_bf16(const __bf16* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
+    constexpr int CH = NCOL / 4;
+    for (int t = lane; t < nc * CH; t += 64) {
+        const int row = t / CH, c = (t - row * CH) * 4;
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c);
+        *reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+template <int NCOL>
+__device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
+    constexpr int CH = NCOL / 4;
+    for (int t = lane; t < nc * CH; t += 64) {
+        const int row = t / CH, c = (t - row * CH) * 4;
+        *reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c) = *reinterpret_cast<const float4*>(src + row * lds_ld + c);
     }
 }
 
@@ -299,27 +321,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, P.Hb1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, P.Hb2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
+        } else {
+            copy_rows_bf16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, acc, wave, lane);
             pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, nullptr, L.ld_ob, row_r, nc, wave, lane);
+        } else {
+            pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
+            copy_rows_bf16<100>(Hb, LD_H, P.Hb2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
         // ---- box latents (models.py:322-381); passthrough -> z-net input
+        if (wave == 7) copy_rows_f32<NP + 8>(Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, lane);
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = Ost[row * LD_O + i];
@@ -412,15 +440,18 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, nullptr, L.ld_oe, row_r, nc, wave, lane);
+        } else {
+            (void)0;
         }
         lds_barrier();
         CH_STAMP();
         // ---- attributes (models.py:83-85)
+        if (wave == 7) copy_rows_f32<2 * A_>(Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, lane);
         for (int idx = tid; idx < nc * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
             const size_t r = row_r[row];
@@ -440,30 +471,37 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         lds_barrier();
         CH_STAMP();
         // ---- z_depth (models.py:88-97)
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, P.Hz1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
+        } else {
+            (void)0;
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, P.Hz2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
+        } else {
+            copy_rows_bf16<100>(Ha, LD_H, P.Hz1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, wave, lane);
+            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, nullptr, L.ld_oz, row_r, nc, wave, lane);
+        } else {
+            copy_rows_bf16<100>(Hb, LD_H, P.Hz2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
+        if (wave == 7) copy_rows_f32<NP + 4>(Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, lane);      // 102 used columns, the row holds 104
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = Ost[row * LD_O + i];
@@ -487,27 +525,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         lds_barrier();
         CH_STAMP();
         // ---- z_pres (models.py:100-102,393-411)
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, P.Ho1, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
+        } else {
+            (void)0;
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, acc, wave, lane);
             pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, P.Ho2, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
+            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
+        } else {
+            copy_rows_bf16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 1>(Hb, LD_H, nullptr, 0, a.w[CW_OBJ2], pipe, acc, wave, lane);
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
             wg_store<1, false>(acc, bias_sh + BIAS_OFF[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
+        } else {
+            copy_rows_bf16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
