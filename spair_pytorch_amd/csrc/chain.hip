@@ -147,6 +147,15 @@ __device__ __forceinline__ void copy_rows_bf16(const __bf16* src, int lds_ld, fl
     }
 }
 template <int NCOL>
+__device__ __forceinline__ void copy_rows_b16(const __bf16* src, int lds_ld, float* __restrict__ dst_, int ldd, const int* row_r, int nc, int lane) {
+    constexpr int CH = NCOL / 4;
+    __bf16* __restrict__ dst = reinterpret_cast<__bf16*>(dst_);
+    for (int t = lane; t < nc * CH; t += 64) {
+        const int row = t / CH, c = (t - row * CH) * 4;
+        *reinterpret_cast<bf16x4*>(dst + (size_t)row_r[row] * ldd + c) = *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c);
+    }
+}
+template <int NCOL>
 __device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
     constexpr int CH = NCOL / 4;
     for (int t = lane; t < nc * CH; t += 64) {
@@ -670,7 +679,7 @@ __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __rest
         for (int rr = 0; rr < 4; ++rr) {
             const int row = (lane >> 4) * 4 + rr;
             const float v = ((mb[nt * 4 + rr] >> lane) & 1ull) ? acc[rr] : 0.f;
-            if (row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
+            if (dOut_ && row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
             dst[row * LD_H + n] = (__bf16)v;
         }
     }, pre);
@@ -881,7 +890,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mb_sh + MB_HO1 * 4, SP_LDH, P.dHo1, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        // 7-tile layers: the 8th wave has no tile; the layer-output gradient (bf16 in LDS) is copied to HBM by that wave one stage later
+        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mb_sh + MB_HO1 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 30>(a.wt[CW_OBJ0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -899,6 +909,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
+        if (wave == 7) copy_rows_b16<SP_H>(Ab, LD_H, P.dHo1, SP_LDH, row_r, nc, lane);      // OBJ1's output, untouched until the ZH stage
         for (int idx = tid; idx < MT * NP; idx += NTH) {
             const int row = idx / NP, i = idx - row * NP;
             const float v = row < nc ? tailO[row][i] : 0.f;
@@ -922,11 +933,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mb_sh + MB_HZ2 * 4, SP_LDH, P.dHz2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mb_sh + MB_HZ2 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 7>(a.wt[CW_Z1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mb_sh + MB_HZ1 * 4, SP_LDH, P.dHz1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        if (wave < 7) hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mb_sh + MB_HZ1 * 4, SP_LDH, nullptr, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        else copy_rows_b16<SP_H>(Ab, LD_H, P.dHz2, SP_LDH, row_r, nc, lane);
         wide_prefetch<4, 30>(a.wt[CW_Z0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -944,6 +956,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // ---- attributes -> gradient of the encoder output
+        if (wave == 7) copy_rows_b16<SP_H>(Aa, LD_H, P.dHz1, SP_LDH, row_r, nc, lane);      // Z1's output, untouched until the ENC2 stage
         for (int idx = tid; idx < MT * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
             float d_mean = 0.f, d_ls = 0.f;
@@ -1034,11 +1047,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mb_sh + MB_HB2 * 4, SP_LDH, P.dHb2, SP_H, Ab, row_r, nc, wave, lane, wpre);
+        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mb_sh + MB_HB2 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
         wide_prefetch<4, 7>(a.wt[CW_BOX1], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mb_sh + MB_HB1 * 4, SP_LDH, P.dHb1, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        if (wave < 7) hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mb_sh + MB_HB1 * 4, SP_LDH, nullptr, SP_H, Aa, row_r, nc, wave, lane, wpre);
+        else copy_rows_b16<SP_H>(Ab, LD_H, P.dHb2, SP_LDH, row_r, nc, lane);
         wide_prefetch<4, 21>(a.wt[CW_BOX0], wave, lane, wpre);
         lds_barrier();
         CB_STAMP();
@@ -1051,6 +1065,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
+        if (wave == 7) copy_rows_b16<SP_H>(Aa, LD_H, P.dHb1, SP_LDH, row_r, nc, lane);      // BOX1's output
         for (int idx = tid; idx < nc * (F + CTX); idx += NTH) {
             const int row = idx / (F + CTX), n = idx - row * (F + CTX);
             const float v = slot[row][n];
