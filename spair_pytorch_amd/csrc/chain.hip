@@ -315,9 +315,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                     }
                 }
                 const size_t r = row_r[row];
-                *reinterpret_cast<float4*>(P.Xb + r * L.ld_xb + c4) = v;
-                *reinterpret_cast<float4*>(P.Xz + r * L.ld_x + c4) = v;
-                *reinterpret_cast<float4*>(P.Xo + r * L.ld_x + c4) = v;
+                *reinterpret_cast<float4*>(P.Xb + r * L.ld_xb + c4) = v;     // the z / obj nets' weight gradients read these columns from Xb too
             }
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
@@ -357,11 +355,13 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         // ---- box latents (models.py:322-381); passthrough -> z-net input
         if (wave == 7) copy_rows_f32<NP + 8>(Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, lane);
-        for (int idx = tid; idx < MT * NP; idx += NTH) {
-            const int row = idx / NP, i = idx - row * NP;
-            const float v = Ost[row * LD_O + i];
-            XtZ[row * LD_XT + i] = (__bf16)v;
-            if (row < nc) P.Xz[(size_t)row_r[row] * L.ld_x + L.x_pass + i] = v;
+        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
+            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(&Ost[row * LD_O + i]);
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(&XtZ[row * LD_XT + i]) = o;
+            if (row < nc) *reinterpret_cast<float4*>(P.Xz + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = v;
         }
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
@@ -511,11 +511,13 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         lds_barrier();
         CH_STAMP();
         if (wave == 7) copy_rows_f32<NP + 4>(Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, lane);      // 102 used columns, the row holds 104
-        for (int idx = tid; idx < MT * NP; idx += NTH) {
-            const int row = idx / NP, i = idx - row * NP;
-            const float v = Ost[row * LD_O + i];
-            XtO[row * LD_XT + i] = (__bf16)v;
-            if (row < nc) P.Xo[(size_t)row_r[row] * L.ld_x + L.x_pass + i] = v;
+        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {
+            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(&Ost[row * LD_O + i]);
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(&XtO[row * LD_XT + i]) = o;
+            if (row < nc) *reinterpret_cast<float4*>(P.Xo + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = v;
         }
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];

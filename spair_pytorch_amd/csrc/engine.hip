@@ -890,23 +890,28 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     int nt = 0;
     bool fits = true;
     // dY: bf16 [N][ldo] (columns a0 .. a0+M-1 of it), X: fp32 [N][ldi]
-    auto add = [&](int id, const float* dY, int ldo, int a0, const float* X, int ldi) {
+    // input columns [n_lo, n_hi) of layer `id` come from X (row stride ldi), whose column 0 is the layer's input column xcol0
+    auto add_cols = [&](int id, const float* dY, int ldo, int a0, const float* X, int ldi, int xcol0, int n_lo, int n_hi, bool with_bias) {
         const LinSpec& l = c.PL.lin[id];
         const __bf16* A = reinterpret_cast<const __bf16*>(dY);
         for (int m0 = 0; m0 < l.out; m0 += 128) {
             const int col = a0 + m0, col_al = col & ~7, skip = col - col_al;          // A tile starts on a 16-byte boundary
             const int ms = std::min(128, l.out - m0);
             const int Ml = std::min(round_up(skip + ms, 8), ldo - col_al);
-            for (int n0 = 0; n0 < l.in; n0 += 128) {
-                if (nt >= SPAIR_TN_MAX_TILES || skip + ms > 128) { fits = false; return; }
+            for (int n0 = n_lo; n0 < n_hi; n0 += 128) {
+                if (nt >= SPAIR_TN_MAX_TILES || skip + ms > 128 || ((n0 - xcol0) & 3)) { fits = false; return; }
                 GemmTN::Tile& t = g.tile[nt++];
-                const int ns = std::min(128, l.in - n0);
-                t.A = A + col_al; t.lda = ldo; t.B = X + n0; t.ldb = ldi;
-                t.C = grads + l.w + (size_t)m0 * l.in + n0; t.ldc = l.in; t.colsum = (n0 == 0) ? grads + l.b + m0 : nullptr;
-                t.M = Ml; t.N = std::min(round_up(ns, 4), ldi - n0); t.Mstore = ms; t.Nstore = ns; t.m_skip = skip;
+                const int ns = std::min(128, n_hi - n0);
+                t.A = A + col_al; t.lda = ldo; t.B = X + (n0 - xcol0); t.ldb = ldi;
+                t.C = grads + l.w + (size_t)m0 * l.in + n0; t.ldc = l.in; t.colsum = (with_bias && n0 == n_lo) ? grads + l.b + m0 : nullptr;
+                t.M = Ml; t.N = std::min(round_up(ns, 4), ldi - (n0 - xcol0)); t.Mstore = ms; t.Nstore = ns; t.m_skip = skip;
             }
         }
     };
+    auto add = [&](int id, const float* dY, int ldo, int a0, const float* X, int ldi) {
+        add_cols(id, dY, ldo, a0, X, ldi, 0, 0, c.PL.lin[id].in, true);
+    };
+    const int nfc = L.F + L.CTX;      // the [features | context] columns every first layer shares: the fused chain stores them once (Xb)
     add(LIN_BOX0, P.dHb1, SP_LDH, 0, P.Xb, L.ld_xb);
     add(LIN_BOX1, P.dHb2, SP_LDH, 0, P.Hb1, SP_LDH);
     add(LIN_BOXH1, P.dOb, L.ld_ob, 0, P.Hb2, SP_LDH);
@@ -914,11 +919,13 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     add(LIN_ENC0, P.dHe1, SP_ENC_H1, 0, P.glimpse, L.ld_gl);
     add(LIN_ENC1, P.dHe2, SP_ENC_H2, 0, P.He1, SP_ENC_H1);
     add(LIN_ENC2, P.dOe, L.ld_oe, 0, P.He2, SP_ENC_H2);
-    add(LIN_Z0, P.dHz1, SP_LDH, 0, P.Xz, L.ld_x);
+    add_cols(LIN_Z0, P.dHz1, SP_LDH, 0, P.Xb, L.ld_xb, 0, 0, nfc, true);
+    add_cols(LIN_Z0, P.dHz1, SP_LDH, 0, P.Xz, L.ld_x, 0, nfc, c.PL.lin[LIN_Z0].in, false);
     add(LIN_Z1, P.dHz2, SP_LDH, 0, P.Hz1, SP_LDH);
     add(LIN_ZH1, P.dOz, L.ld_oz, 0, P.Hz2, SP_LDH);
     add(LIN_ZH0, P.dOz, L.ld_oz, L.oz_lat, P.Hz2, SP_LDH);
-    add(LIN_OBJ0, P.dHo1, SP_LDH, 0, P.Xo, L.ld_x);
+    add_cols(LIN_OBJ0, P.dHo1, SP_LDH, 0, P.Xb, L.ld_xb, 0, 0, nfc, true);
+    add_cols(LIN_OBJ0, P.dHo1, SP_LDH, 0, P.Xo, L.ld_x, 0, nfc, c.PL.lin[LIN_OBJ0].in, false);
     add(LIN_OBJ1, P.dHo2, SP_LDH, 0, P.Ho1, SP_LDH);
     add(LIN_OBJ2, P.dOo, L.ld_oo, 0, P.Ho2, SP_LDH);
     if (!fits) return SPAIR_ERR_UNSUPPORTED;
