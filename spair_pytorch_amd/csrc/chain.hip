@@ -912,11 +912,13 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
         if (wave == 7) copy_rows_b16<SP_H>(Ab, LD_H, P.dHo1, SP_LDH, row_r, nc, lane);      // OBJ1's output, untouched until the ZH stage
-        for (int idx = tid; idx < MT * NP; idx += NTH) {
-            const int row = idx / NP, i = idx - row * NP;
-            const float v = row < nc ? tailO[row][i] : 0.f;
-            Aa[row * LD_H + i] = (__bf16)v;
-            if (row < nc) reinterpret_cast<__bf16*>(P.dOz)[(size_t)row_r[row] * L.ld_oz + i] = (__bf16)v;
+        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
+            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
+            const float4 v = row < nc ? *reinterpret_cast<const float4*>(&tailO[row][i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + i]) = o;
+            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dOz) + (size_t)row_r[row] * L.ld_oz + i) = o;
         }
         if (tid < MT) {
             float d_mu = 0.f, d_ls = 0.f;
@@ -1021,11 +1023,13 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // ---- box (models.py:322-381 backward); passthrough gradient -> box-net head
-        for (int idx = tid; idx < MT * NP; idx += NTH) {
-            const int row = idx / NP, i = idx - row * NP;
-            const float v = row < nc ? tailZ[row][i] : 0.f;
-            Aa[row * LD_H + i] = (__bf16)v;
-            if (row < nc) reinterpret_cast<__bf16*>(P.dOb)[(size_t)row_r[row] * L.ld_ob + i] = (__bf16)v;
+        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
+            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
+            const float4 v = row < nc ? *reinterpret_cast<const float4*>(&tailZ[row][i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + i]) = o;
+            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dOb) + (size_t)row_r[row] * L.ld_ob + i) = o;
         }
         if (tid < MT) {
             float dlat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
