@@ -111,7 +111,7 @@ constexpr int MB_HB1 = 0, MB_HB2 = 7, MB_HE1 = 14, MB_HE2 = 30, MB_HZ1 = 38, MB_
 template <int NT, bool RELU, int NT0 = 0>
 __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restrict__ bias, int nout, __bf16* lds_bf, int ld_bf,
                                          float* lds_f, int ld_f, float* __restrict__ hbm, int ld_hbm, const int* row_r, int nc, int wave,
-                                         int lane, unsigned long long* __restrict__ mb = nullptr) {
+                                         int lane, unsigned long long* __restrict__ mb = nullptr, bool hbm_b16 = false) {
     const int nt = NT0 + wave;
     const int n = nt * 16 + (lane & 15);
     if (nt >= NT) return;                                        // wave-uniform
@@ -129,7 +129,10 @@ __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restri
         if (RELU) v = fmaxf(v, 0.f);
         if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
         if (lds_f) lds_f[row * ld_f + n] = v;
-        if (hbm && row < nc) hbm[(size_t)row_r[row] * ld_hbm + n] = v;
+        if (hbm && row < nc) {
+            if (hbm_b16) reinterpret_cast<__bf16*>(hbm)[(size_t)row_r[row] * ld_hbm + n] = (__bf16)v;
+            else hbm[(size_t)row_r[row] * ld_hbm + n] = v;
+        }
     }
 }
 
@@ -137,6 +140,12 @@ __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restri
 // LDS to their HBM row buffer (coalesced 16-byte stores) while the other seven compute -- their instruction streams then contain no
 // global store at all, so a wait for a weight fragment is only ever a wait for weight fragments.  (Hidden activations reach HBM as
 // the bf16-rounded values the next layer consumed; the weight-gradient GEMMs round their operands to bf16 anyway.)
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 o;
+    o[0] = (__bf16)a; o[1] = (__bf16)b; o[2] = (__bf16)c; o[3] = (__bf16)d;
+    return o;
+}
+
 template <int NCOL>
 __device__ __forceinline__ void copy_rows_bf16(const __bf16* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
     constexpr int CH = NCOL / 4;
@@ -315,7 +324,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                     }
                 }
                 const size_t r = row_r[row];
-                *reinterpret_cast<float4*>(P.Xb + r * L.ld_xb + c4) = v;     // the z / obj nets' weight gradients read these columns from Xb too
+                // (every operand of the weight-gradient GEMMs is stored as bf16 by this kernel: same leading dimensions in elements,
+                //  the buffers are sized for the per-wavefront path's fp32; the z / obj nets read these columns from Xb too)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xb) + r * L.ld_xb + c4) = pack4(v.x, v.y, v.z, v.w);
             }
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
             wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
         } else {
-            copy_rows_bf16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, nullptr, L.ld_ob, row_r, nc, wave, lane);
         } else {
             pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
-            copy_rows_bf16<100>(Hb, LD_H, P.Hb2, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Hb, LD_H, P.Hb2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
             *reinterpret_cast<bf16x4*>(&XtZ[row * LD_XT + i]) = o;
-            if (row < nc) *reinterpret_cast<float4*>(P.Xz + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = v;
+            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xz) + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = o;
         }
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 XtZ[tid * LD_XT + NP + k] = (__bf16)o.box[k];
                 XtO[tid * LD_XT + NP + k] = (__bf16)o.box[k];
                 P.rec[r * L.ld_rec + k] = o.box[k];
-                P.Xz[r * L.ld_x + L.x_box + k] = o.box[k];
-                P.Xo[r * L.ld_x + L.x_box + k] = o.box[k];
+                reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + k] = (__bf16)o.box[k];
+                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + k] = (__bf16)o.box[k];
                 P.nbox[r * 4 + k] = o.nbox[k];
                 P.z_where[(((size_t)b * 4 + k) * G + h) * G + w] = o.nbox[k];
             }
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             bf16x4 o;
             o[0] = (__bf16)out[0]; o[1] = (__bf16)out[1]; o[2] = (__bf16)out[2]; o[3] = (__bf16)out[3];
             *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
-            *reinterpret_cast<float4*>(P.glimpse + (size_t)row_r[row] * L.ld_gl + e) = make_float4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)row_r[row] * L.ld_gl + e) = o;
             *reinterpret_cast<uint4*>(P.gxy + (size_t)row_r[row] * L.ld_gl + e) = make_uint4(gxy[0], gxy[1], gxy[2], gxy[3]);
         }
         lds_barrier();
@@ -436,8 +447,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<25, 16, 8>(a.w[CW_ENC0], pipe, wave, lane);
             wg_gemm<25, 0, 16, 8>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
-            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
+            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4, true);
+            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4, true);
         }
         lds_barrier();
         CH_STAMP();
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
-            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4);
+            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4, true);
         }
         lds_barrier();
         CH_STAMP();
@@ -474,8 +485,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.rec[r * L.ld_rec + 4 + j] = attr;
             P.Za[r * L.ld_rec + j] = attr;
             reinterpret_cast<__bf16*>(P.Za16)[r * L.ld_rec + j] = (__bf16)attr;      // decoder input, no conversion pass
-            P.Xz[r * L.ld_x + L.x_attr + j] = attr;
-            P.Xo[r * L.ld_x + L.x_attr + j] = attr;
+            reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_attr + j] = (__bf16)attr;
+            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_attr + j] = (__bf16)attr;
         }
         lds_barrier();
         CH_STAMP();
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
             wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
         } else {
-            copy_rows_bf16<100>(Ha, LD_H, P.Hz1, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Ha, LD_H, P.Hz1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
             wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, nullptr, L.ld_oz, row_r, nc, wave, lane);
         } else {
-            copy_rows_bf16<100>(Hb, LD_H, P.Hz2, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Hb, LD_H, P.Hz2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             bf16x4 o;
             o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
             *reinterpret_cast<bf16x4*>(&XtO[row * LD_XT + i]) = o;
-            if (row < nc) *reinterpret_cast<float4*>(P.Xo + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = v;
+            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xo) + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = o;
         }
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             rec_cur[tid][4 + A_] = depth;
             XtO[tid * LD_XT + NP + 4 + A_] = (__bf16)depth;
             P.rec[r * L.ld_rec + 4 + A_] = depth;
-            P.Xo[r * L.ld_x + L.x_depth] = depth;
+            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_depth] = (__bf16)depth;
         }
         lds_barrier();
         CH_STAMP();
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
             wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
         } else {
-            copy_rows_bf16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
             wg_store<1, false>(acc, bias_sh + BIAS_OFF[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
         } else {
-            copy_rows_bf16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();

@@ -880,8 +880,8 @@ static int wgrad_lin(Ctx& c, int id, const float* dOut, int ldo, const float* In
     return tn(c, dOut, ldo, l.out, In, ldi, l.in, grads + l.w, l.in, R, grads + l.b);
 }
 
-// Weight / bias gradients of the 14 per-cell layers in ONE grouped split-K launch (fused-chain path: the layer-output gradients are
-// bf16 rows, the layer inputs fp32 rows).  36 tiles of <= 128 x 128 at the reference sizes.
+// Weight / bias gradients of the 14 per-cell layers in ONE grouped split-K launch (fused-chain path: layer-output gradients and layer
+// inputs are both bf16 rows).  38 tiles of <= 128 x 128 at the reference sizes.
 static int cells_wgrad_grouped(Ctx& c, float* grads) {
     const CellLayout& L = c.L;
     const CellBufs& P = c.w.cb;
@@ -890,21 +890,27 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     int nt = 0;
     bool fits = true;
     // dY: bf16 [N][ldo] (columns a0 .. a0+M-1 of it), X: fp32 [N][ldi]
-    // input columns [n_lo, n_hi) of layer `id` come from X (row stride ldi), whose column 0 is the layer's input column xcol0
-    auto add_cols = [&](int id, const float* dY, int ldo, int a0, const float* X, int ldi, int xcol0, int n_lo, int n_hi, bool with_bias) {
+    // input columns [n_lo, n_hi) of layer `id` come from X (bf16 rows, row stride ldi elements), whose column 0 is the layer's input
+    // column xcol0.  A tile's operand pointer is rounded down to 8 elements (16 bytes); the columns in front belong to another tile.
+    auto add_cols = [&](int id, const float* dY, int ldo, int a0, const float* X_, int ldi, int xcol0, int n_lo, int n_hi, bool with_bias) {
         const LinSpec& l = c.PL.lin[id];
         const __bf16* A = reinterpret_cast<const __bf16*>(dY);
+        const __bf16* X = reinterpret_cast<const __bf16*>(X_);
         for (int m0 = 0; m0 < l.out; m0 += 128) {
             const int col = a0 + m0, col_al = col & ~7, skip = col - col_al;          // A tile starts on a 16-byte boundary
             const int ms = std::min(128, l.out - m0);
             const int Ml = std::min(round_up(skip + ms, 8), ldo - col_al);
-            for (int n0 = n_lo; n0 < n_hi; n0 += 128) {
-                if (nt >= SPAIR_TN_MAX_TILES || skip + ms > 128 || ((n0 - xcol0) & 3)) { fits = false; return; }
+            int n0 = n_lo;
+            while (n0 < n_hi) {
+                const int xc = n0 - xcol0, xc_al = xc & ~7, nskip = xc - xc_al;
+                const int ns = std::min(128 - nskip, n_hi - n0);
+                if (nt >= SPAIR_TN_MAX_TILES || skip + ms > 128) { fits = false; return; }
                 GemmTN::Tile& t = g.tile[nt++];
-                const int ns = std::min(128, n_hi - n0);
-                t.A = A + col_al; t.lda = ldo; t.B = X + (n0 - xcol0); t.ldb = ldi;
+                t.A = A + col_al; t.lda = ldo; t.B = X + xc_al; t.ldb = ldi;
                 t.C = grads + l.w + (size_t)m0 * l.in + n0; t.ldc = l.in; t.colsum = (with_bias && n0 == n_lo) ? grads + l.b + m0 : nullptr;
-                t.M = Ml; t.N = std::min(round_up(ns, 4), ldi - (n0 - xcol0)); t.Mstore = ms; t.Nstore = ns; t.m_skip = skip;
+                t.M = Ml; t.N = std::min(round_up(nskip + ns, 8), ldi - xc_al); t.Mstore = ms; t.Nstore = ns; t.m_skip = skip; t.n_skip = nskip;
+                if (t.N < nskip + ns) { fits = false; return; }
+                n0 += ns;
             }
         }
     };
@@ -931,7 +937,7 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     if (!fits) return SPAIR_ERR_UNSUPPORTED;
     g.ngroup = nt; g.R = L.N;
     g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
-    return spair_gemm_tn16_impl(g, false, false, c.s);
+    return spair_gemm_tn16_impl(g, false, true, c.s);      // A and B both bf16 rows
 }
 
 extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,

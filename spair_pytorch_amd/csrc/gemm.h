@@ -41,8 +41,8 @@ struct GemmTN {
         int lda, ldb, ldc;
         int M, N;                 // load extents (A: multiple of 8 columns; B: multiple of 8 (bf16) / 4 (fp32)), <= 128
         int Mstore, Nstore;       // store extents
-        int m_skip;               // the first m_skip rows of the tile belong to another tile (A pointers must stay 16-byte aligned):
-                                  // tile row m is stored at C row m - m_skip for m_skip <= m < m_skip + Mstore
+        int m_skip, n_skip;       // the first m_skip rows / n_skip columns of the tile belong to another tile (operand pointers must stay
+                                  // 16-byte aligned): tile row m is stored at C row m - m_skip for m_skip <= m < m_skip + Mstore, same for columns
     } tile[SPAIR_TN_MAX_TILES];
 };
 #define SPAIR_TN_PART_FLOATS (1536ll * 128 * 128)    // up to 1536 blocks x one 128x128 tile (100 MB)

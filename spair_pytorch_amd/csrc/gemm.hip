@@ -638,9 +638,9 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
     const int ldc = grouped ? gt.ldc : g.ldc;
     const int Mst = grouped ? gt.Mstore : g.Mstore;
     const int Nst = grouped ? gt.Nstore : g.Nstore;
-    const int mskip = grouped ? gt.m_skip : 0;
+    const int mskip = grouped ? gt.m_skip : 0, nskip = grouped ? gt.n_skip : 0;
     const int m = mt * bm + ml, n = (grouped ? 0 : nt * bn) + nl;
-    const bool live = tile < tiles && m >= mskip && m < mskip + Mst && n < Nst;
+    const bool live = tile < tiles && m >= mskip && m < mskip + Mst && n < nskip + Nst;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (live) {
         const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
@@ -666,8 +666,9 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int nn = n + q;
-        if (nn >= Nst) break;
-        int nc = nn;
+        if (nn >= nskip + Nst) break;
+        if (nn < nskip) continue;
+        int nc = nn - nskip;
         if (g.cw_cin > 0) { const int tap = nn / g.cw_cin, ci = nn - tap * g.cw_cin; nc = ci * g.cw_taps + tap; }
         Cp[(size_t)(m - mskip) * ldc + nc] += v[q];
     }

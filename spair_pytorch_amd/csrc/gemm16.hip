@@ -746,7 +746,7 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
             if (!t.A || !t.B || !t.C || t.M <= 0 || t.N <= 0 || t.M > BM || t.N > BN || (t.M & 7) || (t.lda & 7)) return SPAIR_ERR_SHAPE;
             if (b_bf16 ? ((t.N & 7) || (t.ldb & 7)) : ((t.N & 3) || (t.ldb & 3))) return SPAIR_ERR_ALIGN;
             if ((long long)g.R * t.lda >= (1ll << 31) || (long long)g.R * t.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
-            if (t.Mstore <= 0 || t.m_skip < 0 || t.m_skip + t.Mstore > t.M || t.Nstore <= 0 || t.Nstore > t.N) return SPAIR_ERR_SHAPE;
+            if (t.Mstore <= 0 || t.m_skip < 0 || t.m_skip + t.Mstore > t.M || t.Nstore <= 0 || t.n_skip < 0 || t.n_skip + t.Nstore > t.N) return SPAIR_ERR_SHAPE;
         }
         g.M = BM; g.N = BN; g.Mstore = BM; g.Nstore = BN; g.lda = g.tile[0].lda; g.ldb = g.tile[0].ldb;
     }
