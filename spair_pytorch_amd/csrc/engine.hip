@@ -551,13 +551,18 @@ static int pw_stack_first(const Ctx& c) {
     return (n - i0 >= 2) ? i0 : n;
 }
 
-static int backbone_fwd(Ctx& c) {
+// input padding + the stem conv: they read the fp32 parameters directly, so they do not wait for the weight preparation
+static int backbone_stem_fwd(Ctx& c) {
     const SpairDims& d = c.d;
     const int b16 = d.dtype == SPAIR_BF16;
     const int Ip = d.I + d.pad_pre + d.pad_post;
     TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, Ip, c.s));
     const ConvSpec& c0 = c.PL.conv[0];
-    TRY(misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, b16, c.s));
+    return misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, b16, c.s);
+}
+static int backbone_fwd(Ctx& c) {
+    const SpairDims& d = c.d;
+    const int b16 = d.dtype == SPAIR_BF16;
     const int pw0 = pw_stack_first(c);
     for (int i = 1; i < c.PL.n_conv; ++i) {
         const ConvSpec& cs = c.PL.conv[i];
@@ -809,16 +814,25 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     const CellLayout& L = c.L;
     CellBufs& P = c.w.cb;
     P.z_where = z_where; P.z_pres = z_pres;
-    {
-        ProfScope ps(PS_PREP, c.s);
-        TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
-        TRY(prep_weights(c, st->train != 0));
-    }
-    { ProfScope ps(PS_BACKBONE_FWD, c.s); TRY(backbone_fwd(c)); }
-    { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
-    // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));
+    {   // tables + per-step weight copies (helper stream) beside the input padding and the stem conv (caller's stream)
+        hipStream_t const main_s = c.s;
+        if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
+        {
+            ProfScope ps(PS_PREP, c.s);
+            TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
+            TRY(prep_weights(c, st->train != 0));
+        }
+        if (side) { if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH; c.s = main_s; }
+    }
+    const int ps_bb = prof_begin(PS_BACKBONE_FWD, c.s);
+    TRY(backbone_stem_fwd(c));
+    if (side && hipStreamWaitEvent(c.s, side->ev[3], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    TRY(backbone_fwd(c));
+    prof_end(ps_bb, c.s);
+    { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
+    // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer
     {
         hipStream_t ks = side ? side->s : c.s;
         if (side) TRY(stream_link(c.s, ks, side->ev[0]));
