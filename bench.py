@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--image", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=4, help="record the per-kernel HIP event pairs on every n-th timed step")
+    ap.add_argument("--prof-mask", type=lambda v: int(v, 0), default=-1, help="bit mask of the engine's event-pair slots to record (-1 = all)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,12 +118,16 @@ def main():
     for _ in range(args.warmup):
         step()
     lib = L.lib()
+    L.check(lib.spair_prof_select(ctypes.c_ulonglong(args.prof_mask & 0xFFFFFFFFFFFFFFFF)), "prof_select")
     L.check(lib.spair_prof_enable(1), "prof_enable")
+    lib.spair_prof_enable(0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # the kernels' event pairs are sampled on every n-th step of the timed region (each pair costs ~3 us of queue time)
+        lib.spair_prof_enable(2 if i % args.prof_every == 0 else 0)
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -145,7 +151,8 @@ def main():
         return
 
     K = args.steps
-    per_step_ms = {SLOT_NAMES[i]: ms[i] / K for i in range(nslots) if cnt[i] > 0}
+    Ks = len(range(0, K, args.prof_every))                                              # steps on which the event pairs were recorded
+    per_step_ms = {SLOT_NAMES[i]: ms[i] / Ks for i in range(nslots) if cnt[i] > 0}
     avg = {SLOT_NAMES[i]: ms[i] / cnt[i] for i in range(nslots) if cnt[i] > 0}       # per launch / region
     d = model._last["engine"]["dims"]
     N = B * d.G * d.G

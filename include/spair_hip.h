@@ -81,7 +81,8 @@ int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* e
  * 6 KL+loss, 7 render bwd (1 kernel), 8 decoder bwd, 9 per-cell chain bwd, 10 per-cell weight grads,
  * 11 backbone bwd, 12 conv_1 fwd (1 kernel), 13 decoder.out fwd GEMM (1 kernel), 14 STN glimpse fwd (per wavefront),
  * 15 adam, 16 decoder.out wgrad, 17 decoder.out dgrad.  spair_prof_read synchronises: call it outside timed regions. */
-int spair_prof_enable(int enable);
+int spair_prof_enable(int enable);                      /* 0 stop, 1 start afresh, 2 resume (keeps earlier records) */
+int spair_prof_select(unsigned long long slot_mask);   /* record only the regions whose bit is set (default: all) */
 int spair_prof_read(float* ms, int* counts, int nslots);
 
 /* ---- unit-level entry points (each kernel can be parity-checked alone) --------------------- */

@@ -41,6 +41,7 @@ int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, 
 struct ProfState {
     int enabled;
     int n_events;                 // created
+    unsigned long long mask = ~0ull;   // slots recorded (spair_prof_select)
     int used;                     // event pairs used
     hipEvent_t ev[2 * SP_PROF_POOL];
     int slot[SP_PROF_POOL];
@@ -48,7 +49,7 @@ struct ProfState {
 static ProfState g_prof;
 
 static inline int prof_begin(int slot, hipStream_t s) {
-    if (slot < 0 || !g_prof.enabled || g_prof.used >= SP_PROF_POOL) return -1;
+    if (slot < 0 || !g_prof.enabled || !((g_prof.mask >> slot) & 1ull) || g_prof.used >= SP_PROF_POOL) return -1;
     const int i = g_prof.used++;
     g_prof.slot[i] = slot;
     hipEventRecord(g_prof.ev[2 * i], s);
@@ -70,9 +71,11 @@ extern "C" int spair_prof_enable(int enable) {
         g_prof.n_events = 2 * SP_PROF_POOL;
     }
     g_prof.enabled = enable ? 1 : 0;
-    g_prof.used = 0;
+    if (enable == 1) g_prof.used = 0;      // 0 (stop) and 2 (resume) keep what was recorded: sampling every n-th step of a timed region
     return SPAIR_OK;
 }
+// Restricts the recorded regions to the slots whose bit is set (default: all).
+extern "C" int spair_prof_select(unsigned long long mask) { g_prof.mask = mask; return SPAIR_OK; }
 // Synchronises on the recorded events (call only outside the timed region); ms[slot] += elapsed, counts[slot] += 1.
 extern "C" int spair_prof_read(float* ms, int* counts, int nslots) {
     for (int i = 0; i < g_prof.used; ++i) {
