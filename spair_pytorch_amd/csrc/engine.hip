@@ -558,10 +558,12 @@ static int pw_stack_first(const Ctx& c) {
 static int backbone_stem_fwd(Ctx& c) {
     const SpairDims& d = c.d;
     const int b16 = d.dtype == SPAIR_BF16;
-    const int Ip = d.I + d.pad_pre + d.pad_post;
-    TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, Ip, c.s));
     const ConvSpec& c0 = c.PL.conv[0];
-    return misc_conv0_fwd(c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, c0.hin, d.C, c0.k, c0.s, c0.hout, c0.cout, b16, c.s);
+    // the fast stem reads the unpadded image itself (spair_forward makes the padded copy on the helper stream, for the weight gradient)
+    if (!misc_conv0_reads_unpadded(d.B, c0.hin, d.C, c0.k, c0.cout))
+        TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, d.I + d.pad_pre + d.pad_post, c.s));
+    return misc_conv0_fwd(c.x, c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, d.I, d.pad_pre, c0.hin, d.C, c0.k, c0.s, c0.hout,
+                          c0.cout, b16, c.s);
 }
 static int backbone_fwd(Ctx& c) {
     const SpairDims& d = c.d;
@@ -827,7 +829,12 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
             TRY(prep_weights(c, st->train != 0));
         }
-        if (side) { if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH; c.s = main_s; }
+        if (side && hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        // the padded copy is only read by the stem's weight gradient: it stays behind the event conv_1 waits on (the helper stream's
+        // later joins order it before the backward)
+        if (misc_conv0_reads_unpadded(d->B, c.PL.conv[0].hin, d->C, c.PL.conv[0].k, c.PL.conv[0].cout))
+            TRY(misc_pad_input(x, c.w.xpad, d->B, d->C, d->I, d->pad_pre, d->I + d->pad_pre + d->pad_post, c.s));
+        c.s = main_s;
     }
     const int ps_bb = prof_begin(PS_BACKBONE_FWD, c.s);
     TRY(backbone_stem_fwd(c));

@@ -202,21 +202,28 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ xp,
         }
     }
 }
-// Single-channel 4x4 specialisation (the reference's grey-scale stem): workgroup = one output row of one sample, the
-// 4 input rows staged in LDS, the 16x4 weights of a thread's channel quad held in registers, thread = (pixel group,
+constexpr int C0_ROWS = 5;
+// Single-channel 4x4 specialisation (the reference's grey-scale stem): workgroup = C0_ROWS output rows of one sample, their
+// input rows staged in LDS, the 16x4 weights of a thread's channel quad held in registers, thread = (pixel group,
 // channel quad) so a pixel's 128 channels leave as one contiguous 256 B (bf16) / 512 B (fp32) store.  HBM-write bound.
-__global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict__ xp, const float* __restrict__ w,
+// The input is read straight from the unpadded image (zero outside [pre, pre + I)): the padded copy the weight gradient
+// reads later is made beside this kernel, not before it.
+__global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out, int Hin, int s,
-                                                        int Hout, int Cout, int out_bf16) {
-    extern __shared__ float xs[];    // [4][Hin]
-    const int oy = blockIdx.x, b = blockIdx.y;
+                                                        int Hout, int Cout, int out_bf16, int I, int pre) {
+    extern __shared__ float xs[];    // [s * (C0_ROWS - 1) + 4][Hin]: the input rows of this workgroup's C0_ROWS output rows
+    const int oy0 = blockIdx.x * C0_ROWS, b = blockIdx.y;
+    const int nrow = min(C0_ROWS, Hout - oy0), nin = s * (nrow - 1) + 4;
     const int q = Cout >> 2, groups = 256 / q;
     const int cq = threadIdx.x % q, pg = threadIdx.x / q;
-    for (int i = threadIdx.x; i < 4 * Hin; i += 256) {
-        const int ky = i / Hin, x = i - ky * Hin;
-        xs[i] = xp[((size_t)b * Hin + oy * s + ky) * Hin + x];
+    for (int i = threadIdx.x; i < nin * Hin; i += 256) {
+        const int ky = i / Hin, xx = i - ky * Hin;
+        const int sy = oy0 * s + ky - pre, sx = xx - pre;
+        const bool in = (unsigned)sy < (unsigned)I && (unsigned)sx < (unsigned)I;
+        xs[i] = in ? x[((size_t)b * I + sy) * I + sx] : 0.f;
     }
-    float4 wr[16];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 wlo[16], whi[16];             // per tap: channels (0,1) and (2,3) of the quad -- the 64 FMAs of a pixel issue as 32 packed ones
     {
         const float4* w4 = reinterpret_cast<const float4*>(w + (size_t)cq * 4 * 16);     // 4 channels x 16 taps, contiguous
         float4 t[16];
@@ -224,43 +231,54 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict_
         for (int i = 0; i < 16; ++i) t[i] = w4[i];
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {      // t[c*4 + tq] holds taps 4tq..4tq+3 of channel c
-            wr[tq * 4 + 0] = make_float4(t[tq].x, t[4 + tq].x, t[8 + tq].x, t[12 + tq].x);
-            wr[tq * 4 + 1] = make_float4(t[tq].y, t[4 + tq].y, t[8 + tq].y, t[12 + tq].y);
-            wr[tq * 4 + 2] = make_float4(t[tq].z, t[4 + tq].z, t[8 + tq].z, t[12 + tq].z);
-            wr[tq * 4 + 3] = make_float4(t[tq].w, t[4 + tq].w, t[8 + tq].w, t[12 + tq].w);
+            wlo[tq * 4 + 0] = f2{t[tq].x, t[4 + tq].x}; whi[tq * 4 + 0] = f2{t[8 + tq].x, t[12 + tq].x};
+            wlo[tq * 4 + 1] = f2{t[tq].y, t[4 + tq].y}; whi[tq * 4 + 1] = f2{t[8 + tq].y, t[12 + tq].y};
+            wlo[tq * 4 + 2] = f2{t[tq].z, t[4 + tq].z}; whi[tq * 4 + 2] = f2{t[8 + tq].z, t[12 + tq].z};
+            wlo[tq * 4 + 3] = f2{t[tq].w, t[4 + tq].w}; whi[tq * 4 + 3] = f2{t[8 + tq].w, t[12 + tq].w};
         }
     }
     const float4 bv = *reinterpret_cast<const float4*>(bias + cq * 4);
     __syncthreads();
     if (pg >= groups) return;
-    const size_t mrow = ((size_t)b * Hout + oy) * Hout;
-    for (int ox = pg; ox < Hout; ox += groups) {
-        float4 acc = bv;
+    const size_t mrow = ((size_t)b * Hout + oy0) * Hout;
+    const int npix = nrow * Hout;
+#pragma unroll 2
+    for (int p = pg; p < npix; p += groups) {
+        const int r = p / Hout, ox = p - r * Hout;
+        const float* xr = xs + r * s * Hin + ox * s;
+        f2 a0 = f2{bv.x, bv.y}, a1 = f2{bv.z, bv.w};
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                const float xv = xs[ky * Hin + ox * s + kx];
-                const float4 wv = wr[ky * 4 + kx];
-                acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y); acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+                const float xv = xr[ky * Hin + kx];
+                const f2 x2 = f2{xv, xv};
+                a0 = __builtin_elementwise_fma(x2, wlo[ky * 4 + kx], a0);
+                a1 = __builtin_elementwise_fma(x2, whi[ky * 4 + kx], a1);
             }
-        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        float4 acc;
+        acc.x = fmaxf(a0.x, 0.f); acc.y = fmaxf(a0.y, 0.f); acc.z = fmaxf(a1.x, 0.f); acc.w = fmaxf(a1.y, 0.f);
         if (out_bf16) {
             bf16x4 o;
             o[0] = (__bf16)acc.x; o[1] = (__bf16)acc.y; o[2] = (__bf16)acc.z; o[3] = (__bf16)acc.w;
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (mrow + ox) * Cout + cq * 4) = o;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (mrow + p) * Cout + cq * 4) = o;
         } else {
-            *reinterpret_cast<float4*>(out + (mrow + ox) * Cout + cq * 4) = acc;
+            *reinterpret_cast<float4*>(out + (mrow + p) * Cout + cq * 4) = acc;
         }
     }
 }
 
-int misc_conv0_fwd(const float* xp, const float* w, const float* bias, float* out, int B, int Hin, int C, int k, int s, int Hout,
-                   int Cout, int out_bf16, hipStream_t st) {
+bool misc_conv0_reads_unpadded(int B, int Hin, int C, int k, int Cout) {
+    return Cout % 4 == 0 && C == 1 && k == 4 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0 && B <= 65535 &&
+           (size_t)(4 * (C0_ROWS - 1) + 4) * Hin * sizeof(float) <= 48 * 1024;     // stride <= 4
+}
+int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float* bias, float* out, int B, int I, int pre, int Hin, int C, int k,
+                   int s, int Hout, int Cout, int out_bf16, hipStream_t st) {
     if (Cout % 4) return SPAIR_ERR_ALIGN;
-    if (C == 1 && k == 4 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0 && B <= 65535 && (size_t)4 * Hin * sizeof(float) <= 48 * 1024) {
-        hipLaunchKernelGGL(k_conv0_fwd_c1k4, dim3(Hout, B), dim3(256), (size_t)4 * Hin * sizeof(float), st, xp, w, bias, out, Hin, s,
-                           Hout, Cout, out_bf16);
+    if (misc_conv0_reads_unpadded(B, Hin, C, k, Cout)) {
+        if (s < 1 || s > 4) return SPAIR_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_conv0_fwd_c1k4, dim3((Hout + C0_ROWS - 1) / C0_ROWS, B), dim3(256),
+                           (size_t)(s * (C0_ROWS - 1) + 4) * Hin * sizeof(float), st, x, w, bias, out, Hin, s, Hout, Cout, out_bf16, I, pre);
         SPAIR_CHECK_LAUNCH();
         return SPAIR_OK;
     }
