@@ -44,7 +44,8 @@ typedef struct SpairStep {
     float kl_scale;            /* 1/(B*world_size): batch-mean of the KL terms (models.py:553) */
     int train;                 /* 1: keep what backward needs */
     int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps;
-                                * bit 2: no helper stream (every kernel on the caller's stream) */
+                                * bit 2: no helper stream (every kernel on the caller's stream);
+                                * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient) */
 } SpairStep;
 
 /* ---- parameter / workspace layout -------------------------------------------------------- */

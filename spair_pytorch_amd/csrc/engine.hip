@@ -607,6 +607,7 @@ static int backbone_fwd(Ctx& c) {
 static int backbone_bwd16(Ctx& c, float* grads) {
     const SpairDims& d = c.d;
     const int last = c.PL.n_conv - 1;
+    bool stem_fused = false;
     const int N = d.B * d.G * d.G;
     if (!c.use_chain) TRY(spair_to_bf16(c.w.dfeat, c.w.ld_feat, c.w.dfeat16, c.w.ld_feat, N, c.w.ld_feat, c.s));   // the fused chain writes bf16 itself
     const int pw0 = pw_stack_first(c);
@@ -670,6 +671,14 @@ static int backbone_bwd16(Ctx& c, float* grads) {
                 g.nz = cs.s * cs.s;
                 for (int q = 0; q < g.nz; ++q) g.Bz[q] = c.w.conv_wd[i][q];
                 g.B = g.Bz[0];
+                if (i == 1) {     // conv_1: take the stem's weight gradient from the tile in LDS; d act0 never reaches HBM
+                    const ConvSpec& c0 = c.PL.conv[0];
+                    g.stem_xp = c.w.xpad; g.stem_hin = c0.hin; g.stem_s = c0.s; g.stem_dw = grads + c0.w; g.stem_db = grads + c0.b;
+                    g.stem_part = c.w.tn_part; g.stem_part_cap = SPAIR_TN_PART_FLOATS;
+                    stem_fused = c0.cin == 1 && c0.k == 4 && c0.cout == 128 && c0.hout == cs.hin && !(c.st.flags & 8) &&
+                                 spair_nt16_stem_fusable(g, g.stem_part_cap);
+                    if (!stem_fused) g.stem_part = nullptr;
+                }
                 TRY(spair_gemm_nt16_impl(g, true, c.s));
             } else
             for (int py = 0; py < cs.s; ++py)
@@ -686,7 +695,7 @@ static int backbone_bwd16(Ctx& c, float* grads) {
                 }
         }
     }
-    {   // first layer: A = d act0 (bf16), B gathered element-wise from the padded fp32 input
+    if (!stem_fused) {   // first layer: A = d act0 (bf16), B gathered element-wise from the padded fp32 input
         const ConvSpec& c0 = c.PL.conv[0];
         const ConvDesc cd = fwd_desc(c0);
         const int K = c0.k * c0.k * c0.cin;

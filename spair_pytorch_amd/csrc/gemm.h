@@ -17,7 +17,12 @@ struct GemmNT {
     // gemm16.hip: nz > 1 batches the nz = osy*osx output-parity classes of a strided conv data-gradient in ONE launch
     // (blockIdx.z = py*osx + px picks the weight matrix Bz[z] and the row-map offsets); all classes must have the same size.
     int nz; const void* Bz[4];
+    // gemm16.hip, conv_1's data gradient only: stem_part != NULL fuses the stem's weight gradient into the epilogue (the gated
+    // tile x the 4x4 patches of the padded single-channel input stem_xp [B][stem_hin][stem_hin], stride stem_s) and skips the C
+    // store; per-workgroup partials go to stem_part (capacity in floats), their sum is added to stem_dw [128][16] / stem_db [128].
+    const float* stem_xp; float* stem_part; long long stem_part_cap; float* stem_dw; float* stem_db; int stem_hin, stem_s;
 };
+bool spair_nt16_stem_fusable(const GemmNT& g, long long part_cap);
 #define SPAIR_TN_MAX_TILES 40
 struct GemmTN {
     const float* A; int lda;

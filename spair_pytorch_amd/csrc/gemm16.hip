@@ -66,7 +66,24 @@ __device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const Co
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float bf16_bits_to_float(u16 v) { return __uint_as_float(((unsigned int)v) << 16); }
 
-template <bool ACONV, bool C16>
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const __bf16* a0 = tile + (8 * g + q) * ld + c0 + 4 * p;
+    const __bf16* a1 = a0 + 4 * ld;
+    const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a0));
+    const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a1));
+    union { struct { v4s16_t lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+// STEM (conv_1's data gradient only): the stem's weight gradient is taken from the gated tile while it is still in LDS --
+// dW0[ch][tap] = sum_rows G[row][ch] * patch(row)[tap] is one more 128x32x128 MFMA product per tile (column 16 of the patch
+// matrix is 1: the bias gradient) -- and d act0 is never written to HBM (321 MB out + 321 MB back in at config 2).  Each
+// workgroup leaves a [128][17] fp32 partial; spair_gemm_nt16_impl sums them (two small passes, no atomics).
+#define STEM_PART_FLOATS (128 * 17)
+template <bool ACONV, bool C16, bool STEM>
 __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
     constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
@@ -230,6 +247,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         gate[i] = make_uint4(0u, 0u, 0u, 0u);
         if (vec_gate) gate[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(g.mask) + crow[i] * g.ldmask + nb);
     }
+    // STEM: this thread's half patch (row tid>>1, input rows ky = 2*half, 2*half+1; 4 taps each), in flight during the staging
+    float2 sp[4];
+    bool sp_ok = false;
+    if (STEM) {
+        const int prow = tid >> 1, half = tid & 1;
+        const int m = m0 + prow;
+        sp_ok = m < g.M;
+        const int mc = min(m, g.M - 1);
+        const int hw = g.cmap.Hout * g.cmap.Wout;
+        const int b = mc / hw, rem = mc - b * hw, y = rem / g.cmap.Wout, x = rem - y * g.cmap.Wout;
+        const int yy = y * g.cmap.osy + cm_ooy, xx = x * g.cmap.osx + cm_oox;
+        const float* src = g.stem_xp + ((size_t)b * g.stem_hin + yy * g.stem_s + 2 * half) * g.stem_hin + xx * g.stem_s;
+        sp[0] = *reinterpret_cast<const float2*>(src);
+        sp[1] = *reinterpret_cast<const float2*>(src + 2);
+        sp[2] = *reinterpret_cast<const float2*>(src + g.stem_hin);
+        sp[3] = *reinterpret_cast<const float2*>(src + g.stem_hin + 2);
+    }
+    uint4 gq[STEM ? NR : 1];
     {
         const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     for (int i = 0; i < NR; ++i) {
         const int rl = (tid >> 4) + i * 16;
         const int m = m0 + rl;
+        if (STEM) gq[i] = make_uint4(0u, 0u, 0u, 0u);
         if (m >= g.M || nb >= g.N) continue;
         float v[8];
         {
@@ -291,7 +327,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                 ch = (ch + 1 == g.sprite_ch) ? 0 : ch + 1;
             }
         }
-        if (C16) {
+        if (STEM) {          // kept for the fused weight-gradient product below; nothing goes to HBM
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((nb + e) < g.N ? v[e] : 0.f);
+            gq[i] = *reinterpret_cast<uint4*>(&o);
+        } else if (C16) {
             __bf16* dst = reinterpret_cast<__bf16*>(g.C) + crow[i] * g.ldc + nb;
             if (full && vec_ok) {
                 bf16x8 o;
@@ -315,6 +356,88 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
             }
         }
     }
+    if (STEM) {
+        constexpr int LDG = BN + 8, LDP = 32 + 8;
+        __bf16* Gs = smem;                                   // [BM rows][LDG]: the gated tile, bf16 (what d act0 would have held)
+        __bf16* Ps = smem + BM * LDG;                        // [BM rows][LDP]: 16 taps | 1 | 0 ...
+        float* Ws = reinterpret_cast<float*>(smem + BM * LDG + BM * LDP);    // [128 ch][17]
+        __syncthreads();                                     // every thread has read its part of Cs
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<uint4*>(&Gs[((tid >> 4) + i * 16) * LDG + c8]) = gq[i];
+        {
+            const int prow = tid >> 1, half = tid & 1;
+            bf16x8 o, one;
+            const float pv[8] = {sp[0].x, sp[0].y, sp[1].x, sp[1].y, sp[2].x, sp[2].y, sp[3].x, sp[3].y};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = (__bf16)(sp_ok ? pv[e] : 0.f); one[e] = (__bf16)0.f; }
+            one[0] = (__bf16)((sp_ok && half == 0) ? 1.f : 0.f);
+            *reinterpret_cast<bf16x8*>(&Ps[prow * LDP + half * 8]) = o;
+            *reinterpret_cast<bf16x8*>(&Ps[prow * LDP + 16 + half * 8]) = one;
+        }
+        __syncthreads();
+        f32x4 sacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < BM / 32; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = lds_tr_frag16(Gs + ks * 32 * LDG, LDG, wave * 32 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = lds_tr_frag16(Ps + ks * 32 * LDP, LDP, j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], sacc[i][j], 0, 0, 0);
+        }
+        {
+            const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = wave * 32 + i * 16 + rgrp + r;
+                    Ws[ch * 17 + col_l] = sacc[i][0][r];
+                    if (col_l == 0) Ws[ch * 17 + 16] = sacc[i][1][r];
+                }
+        }
+        __syncthreads();
+        float4* pt = reinterpret_cast<float4*>(g.stem_part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * STEM_PART_FLOATS);
+        for (int q = tid; q < STEM_PART_FLOATS / 4; q += 256) pt[q] = reinterpret_cast<const float4*>(Ws)[q];
+    }
+}
+
+// sums of the fused stem partials: part[nblk][128*17] -> part2[S][128*17] -> dW0 / db0
+__global__ __launch_bounds__(256) void k_stem_fused_reduce1(const float* __restrict__ part, int nblk, int per, float* __restrict__ part2) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= STEM_PART_FLOATS) return;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        t0 += part[(size_t)b * STEM_PART_FLOATS + col];
+        t1 += part[(size_t)(b + 1) * STEM_PART_FLOATS + col];
+        t2 += part[(size_t)(b + 2) * STEM_PART_FLOATS + col];
+        t3 += part[(size_t)(b + 3) * STEM_PART_FLOATS + col];
+    }
+    for (; b < b1; ++b) t0 += part[(size_t)b * STEM_PART_FLOATS + col];
+    part2[(size_t)blockIdx.y * STEM_PART_FLOATS + col] = (t0 + t1) + (t2 + t3);
+}
+__global__ __launch_bounds__(256) void k_stem_fused_reduce2(const float* __restrict__ part2, int S, float* __restrict__ dW, float* __restrict__ db) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= STEM_PART_FLOATS) return;
+    float t = 0.f;
+    for (int q = 0; q < S; ++q) t += part2[(size_t)q * STEM_PART_FLOATS + col];
+    const int ch = col / 17, n = col - ch * 17;
+    if (n < 16) dW[ch * 16 + n] += t;
+    else if (db) db[ch] += t;
+}
+bool spair_nt16_stem_fusable(const GemmNT& g, long long part_cap) {
+    const long long tiles = (long long)ceil_div(g.M, 128) * (g.nz > 1 ? g.nz : 1);
+    return g.N == 128 && g.use_cmap && g.c_bf16 && (g.stem_hin % 2) == 0 && (g.stem_s % 2) == 0 &&
+           (tiles + 64) * STEM_PART_FLOATS <= part_cap;
 }
 
 int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
@@ -327,18 +450,30 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), g.nz > 1 ? g.nz : 1);
-#define NT16_LAUNCH(AC, C16)                                                                                     \
+#define NT16_LAUNCH(AC, C16, ST)                                                                                 \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16>),                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16>), grid, dim3(256), lds, s, g);                              \
+        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST>), grid, dim3(256), lds, s, g);                          \
     } while (0)
-    if (conv) { if (g.c_bf16) NT16_LAUNCH(true, true); else NT16_LAUNCH(true, false); }
-    else { if (g.c_bf16) NT16_LAUNCH(false, true); else NT16_LAUNCH(false, false); }
+    if (g.stem_part) {   // conv_1's data gradient with the stem's weight gradient taken in the epilogue
+        if (!conv || !g.stem_xp || !g.stem_dw || !spair_nt16_stem_fusable(g, g.stem_part_cap)) return SPAIR_ERR_UNSUPPORTED;
+        NT16_LAUNCH(true, true, true);
+        SPAIR_CHECK_LAUNCH();
+        const int nblk = (int)(grid.x * grid.z), S = 64, per = ceil_div(nblk, S);
+        float* part2 = g.stem_part + (size_t)nblk * STEM_PART_FLOATS;
+        hipLaunchKernelGGL(k_stem_fused_reduce1, dim3(ceil_div(STEM_PART_FLOATS, 256), S), dim3(256), 0, s, g.stem_part, nblk, per, part2);
+        SPAIR_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_stem_fused_reduce2, dim3(ceil_div(STEM_PART_FLOATS, 256)), dim3(256), 0, s, part2, S, g.stem_dw, g.stem_db);
+        SPAIR_CHECK_LAUNCH();
+        return SPAIR_OK;
+    }
+    if (conv) { if (g.c_bf16) NT16_LAUNCH(true, true, false); else NT16_LAUNCH(true, false, false); }
+    else { if (g.c_bf16) NT16_LAUNCH(false, true, false); else NT16_LAUNCH(false, false, false); }
 #undef NT16_LAUNCH
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
@@ -347,18 +482,6 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // TN (weight gradients) with bf16-stored A (and B)
 // ---------------------------------------------------------------------------------------------
-typedef short v4s16_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int c0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const __bf16* a0 = tile + (8 * g + q) * ld + c0 + 4 * p;
-    const __bf16* a1 = a0 + 4 * ld;
-    const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a0));
-    const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16_t*)(a1));
-    union { struct { v4s16_t lo, hi; } s; bf16x8 v; } u;
-    u.s.lo = lo; u.s.hi = hi;
-    return u.v;
-}
-
 // B16: B is bf16 (plain rows or conv gather with Cin % 8 == 0); otherwise B is an fp32 conv gather (any Cin, scalar loads)
 template <bool BCONV, bool B16>
 __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {

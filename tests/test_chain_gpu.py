@@ -27,6 +27,7 @@ def run(case, z, flags):
                    z_attr=m.export_map(0).cpu(), z_depth=m.export_map(1).cpu())
         loss.backward()
         out["grads"] = m.flat_gradients().cpu().clone()
+        out["slices"] = dict(m._slices)
         return out
     finally:
         models.STEP_FLAGS = 0
@@ -45,3 +46,21 @@ def test_fused_chain_equals_per_wavefront_path(name):
     assert (ga - gb).norm().item() <= 2e-2 * gb.norm().item()
     # and the fused path meets the north-star tolerance against the reference's own numbers
     assert abs(a["terms"][0].item() - float(z["loss"])) <= 1e-3 * abs(float(z["loss"]))
+
+
+@pytest.mark.parametrize("name", ["c1_b8_step1001", "c2_b2_step1001", "c4_b1_step1001"])
+def test_stem_weight_gradient_fused_into_conv1_dgrad(name):
+    """SpairStep.flags bit 3 runs the stem's weight gradient as its own kernel over the stored d act0; the default takes it from
+    conv_1's data-gradient tile in LDS (gemm16.hip, STEM).  Same bf16 operands, different summation order."""
+    z, case = load_case(name)
+    a = run(case, z, flags=0)
+    b = run(case, z, flags=8)
+    seen = 0
+    for k, sl in a["slices"].items():
+        if k.startswith("backbone.net.conv_0."):
+            o, n = int(sl[0]), int(sl[1])
+            ga, gb = a["grads"][o:o + n].double(), b["grads"][o:o + n].double()
+            assert gb.norm().item() > 0
+            assert (ga - gb).norm().item() <= 2e-3 * gb.norm().item(), k
+            seen += 1
+    assert seen == 2
