@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256) void k_stem_fused_reduce1(const float* __restr
     const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        t0 += part[(size_t)b * STEM_PART_FLOATS + col];
-        t1 += part[(size_t)(b + 1) * STEM_PART_FLOATS + col];
-        t2 += part[(size_t)(b + 2) * STEM_PART_FLOATS + col];
-        t3 += part[(size_t)(b + 3) * STEM_PART_FLOATS + col];
+    for (; b + 8 <= b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(b + e) * STEM_PART_FLOATS + col];
+        t0 += v[0] + v[4]; t1 += v[1] + v[5]; t2 += v[2] + v[6]; t3 += v[3] + v[7];
     }
     for (; b < b1; ++b) t0 += part[(size_t)b * STEM_PART_FLOATS + col];
     part2[(size_t)blockIdx.y * STEM_PART_FLOATS + col] = (t0 + t1) + (t2 + t3);
@@ -429,7 +429,13 @@ __global__ __launch_bounds__(256) void k_stem_fused_reduce2(const float* __restr
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= STEM_PART_FLOATS) return;
     float t = 0.f;
-    for (int q = 0; q < S; ++q) t += part2[(size_t)q * STEM_PART_FLOATS + col];
+    for (int q0 = 0; q0 < S; q0 += 8) {      // 8 independent loads in flight (S is a multiple of 8)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = part2[(size_t)(q0 + e) * STEM_PART_FLOATS + col];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += v[e];
+    }
     const int ch = col / 17, n = col - ch * 17;
     if (n < 16) dW[ch * 16 + n] += t;
     else if (db) db[ch] += t;

@@ -94,20 +94,43 @@ __global__ __launch_bounds__(256) void k_gauss_kl(CellLayout L, CellBufs P, Cell
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ bce_partial, int n_bce, const float* __restrict__ kl_partial,
                                                        int n_kl, const float* __restrict__ klp, int B, float kl_scale, float beta,
                                                        float* __restrict__ loss_out) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n_bce; i += blockDim.x) s += bce_partial[i];
-    const float bce = block_reduce_sum_256(s, red);
-    float kls[7];
+    // all eight sums in one pass: every load of a thread is issued before the first add, one LDS reduction for the lot
+    // (eight block reductions in sequence, each behind its own dependent loads, took 23 us between the renderer's two passes)
+    __shared__ float red[4][8];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i0 = threadIdx.x; i0 < n_bce; i0 += 8 * 256) {
+        float v[8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        float t = 0.f;
-        for (int i = threadIdx.x; i < n_kl; i += blockDim.x) t += kl_partial[i * 6 + k];
-        kls[k] = block_reduce_sum_256(t, red) * kl_scale;
+        for (int e = 0; e < 8; ++e) { const int i = i0 + e * 256; v[e] = i < n_bce ? bce_partial[i] : 0.f; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[0] += v[e];
     }
-    float t = 0.f;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) t += klp[i];
-    kls[6] = block_reduce_sum_256(t, red) * kl_scale;
+    for (int i0 = threadIdx.x; i0 < n_kl; i0 += 4 * 256) {
+        float v[4][6];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e * 256;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[e][k] = i < n_kl ? kl_partial[i * 6 + k] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[1 + k] += v[e][k];
+    }
+    for (int i = threadIdx.x; i < B; i += 256) acc[7] += klp[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = wave_reduce_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    float bce = 0.f, kls[7];
+    if (threadIdx.x == 0) {
+        bce = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        for (int k = 0; k < 7; ++k) kls[k] = ((red[0][1 + k] + red[1][1 + k]) + (red[2][1 + k] + red[3][1 + k])) * kl_scale;
+    }
     if (threadIdx.x == 0) {
         float kl_total = 0.f;
         for (int k = 0; k < 7; ++k) { loss_out[2 + k] = kls[k]; kl_total += kls[k]; }
