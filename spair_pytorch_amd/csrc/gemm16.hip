@@ -94,9 +94,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // parity-batched data gradients: the nz classes of one M tile read the same d-out rows (and the 2x2 taps overlap), so they run
+    // back to back on ONE XCD (workgroup ids go round-robin over the 8 XCDs, each with its own L2): id -> (xcd, j), class = j % nz,
+    // M tile = (j / nz) * 8 + xcd.  Class-major order (blockIdx.z) streamed d-out once per class: 773 MB read for a 76 MB tensor.
+    int mt = blockIdx.x, zq = 0;
+    if (g.nz > 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        zq = j % g.nz;
+        mt = (j / g.nz) * 8 + xcd;
+        if (mt * BM >= g.M) return;                  // grid padded to a whole number of (8 XCD x nz) groups
+    }
+    const int m0 = mt * BM, n0 = blockIdx.y * BN;
     const u16* A = reinterpret_cast<const u16*>(g.A);
-    const int zq = g.nz > 1 ? (int)blockIdx.z : 0;
     const u16* B = reinterpret_cast<const u16*>(g.nz > 1 ? g.Bz[zq] : g.B);
     const int cm_ooy = g.nz > 1 ? zq / g.cmap.osx : g.cmap.ooy, cm_oox = g.nz > 1 ? zq - (zq / g.cmap.osx) * g.cmap.osx : g.cmap.oox;
 
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                 }
         }
         __syncthreads();
-        float4* pt = reinterpret_cast<float4*>(g.stem_part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * STEM_PART_FLOATS);
+        float4* pt = reinterpret_cast<float4*>(g.stem_part + ((size_t)zq * ceil_div_dev(g.M, BM) + mt) * STEM_PART_FLOATS);
         for (int q = tid; q < STEM_PART_FLOATS / 4; q += 256) pt[q] = reinterpret_cast<const float4*>(Ws)[q];
     }
 }
@@ -455,7 +464,8 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     if ((long long)g.N * g.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
-    dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), g.nz > 1 ? g.nz : 1);
+    dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
+    if (g.nz > 1) grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.nz);      // (8 XCDs) x (nz classes) x ceil(tiles / 8)
 #define NT16_LAUNCH(AC, C16, ST)                                                                                 \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
@@ -470,7 +480,7 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
         if (!conv || !g.stem_xp || !g.stem_dw || !spair_nt16_stem_fusable(g, g.stem_part_cap)) return SPAIR_ERR_UNSUPPORTED;
         NT16_LAUNCH(true, true, true);
         SPAIR_CHECK_LAUNCH();
-        const int nblk = (int)(grid.x * grid.z), S = 64, per = ceil_div(nblk, S);
+        const int nblk = ceil_div(g.M, 128) * (g.nz > 1 ? g.nz : 1), S = 64, per = ceil_div(nblk, S);
         float* part2 = g.stem_part + (size_t)nblk * STEM_PART_FLOATS;
         hipLaunchKernelGGL(k_stem_fused_reduce1, dim3(ceil_div(STEM_PART_FLOATS, 256), S), dim3(256), 0, s, g.stem_part, nblk, per, part2);
         SPAIR_CHECK_LAUNCH();
