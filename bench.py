@@ -175,7 +175,13 @@ def main():
     z_in, glim = box_in + NPc + 4 + A, P2
     o_in = z_in + 1
     hid = 2 * 100 + (256 + 128) + 2 * 100 + 2 * 100                       # relu outputs of the four nets
-    fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)        # stores + (features, noise) loads
+    if args.dtype == "bf16":
+        # the fused chain stores every GEMM operand as bf16, once: [features|context|box|attr|depth] (o_in columns, shared by the
+        # box/z/obj first layers), the glimpse, the relu outputs; the glimpse derivative pairs as bf16x2; fp32: the 308-float
+        # per-row bundle the elementwise backward reads and the record; relu sign bits; + (features, noise) loads
+        fwd_row = 2 * (o_in + glim + hid + A) + 4 * glim + 4 * (308 + REC) + 66 * 4 * 8 // 8 + 4 * (Fc + REC + 2)
+    else:
+        fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)    # fp32 stores + (features, noise) loads
     outs = (100 + 100 + 8 + NPc) + (256 + 128 + 2 * A) + (100 + 100 + 2 + NPc) + (100 + 100 + 1)
     # backward: the 308-float per-row bundle + the glimpse derivative pairs + relu sign bits (66 tiles x 4 x 8 B per <= 8 rows) in;
     # layer-output gradients and d feat out as bf16
