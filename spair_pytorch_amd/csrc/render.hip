@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
                                                     const float* __restrict__ x, float* __restrict__ recon, float4* __restrict__ aux,
                                                     float* __restrict__ bce_partial, int B, int HW, int I, int P, int ac) {
     __shared__ Cand cand[RCH];
-    __shared__ int ncand_sh;
-    __shared__ int wave_cnt[4];
+    __shared__ unsigned short wlist[4][RCH];     // per wave (= a 16 x 4 pixel strip of the tile): the candidates that reach its rows
+    __shared__ int wave_cnt[4][5];               // [culling wave][tile, strip 0..3]
     __shared__ float red[4];
     const int tiles_x = (I + RT - 1) / RT, tiles = tiles_x * tiles_x;
     int b, tile;
@@ -112,15 +112,38 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
             hit = src_of(c.ax, c.bx, tx1, I, P, ac) > -1.f && src_of(c.ax, c.bx, tx0, I, P, ac) < (float)P &&
                   src_of(c.ay, c.by, ty1, I, P, ac) > -1.f && src_of(c.ay, c.by, ty0, I, P, ac) < (float)P;
         }
+        // a second, finer cull per wave strip: at 16 x 16 a tile meets ~25 of 256 objects, a pixel ~9; the 4-row strips drop a
+        // third of the (pixel, candidate) pairs.  Skipped pairs have zero weights, so the sums are unchanged to the bit.
+        bool hs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sy0 = ty0 + 4 * q, sy1 = min(sy0 + 3, I - 1);
+            hs[q] = hit && sy0 < I && src_of(c.ay, c.by, sy1, I, P, ac) > -1.f && src_of(c.ay, c.by, sy0, I, P, ac) < (float)P;
+        }
         const unsigned long long bal = __ballot(hit);
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        unsigned long long bs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bs[q] = __ballot(hs[q]);
+        if (lane == 0) {
+            wave_cnt[wave][0] = __popcll(bal);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wave_cnt[wave][1 + q] = __popcll(bs[q]);
+        }
         __syncthreads();
         int base = 0;
-        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
-        if (hit) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
-        if (threadIdx.x == 0) ncand_sh = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w][0];
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int ci_me = base + __popcll(bal & below);
+        if (hit) cand[ci_me] = c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int bq = 0;
+            for (int w = 0; w < wave; ++w) bq += wave_cnt[w][1 + q];
+            if (hs[q]) wlist[q][bq + __popcll(bs[q] & below)] = (unsigned short)ci_me;
+        }
         __syncthreads();
-        const int nc = ncand_sh;
+        const int nc = wave_cnt[0][1 + wave] + wave_cnt[1][1 + wave] + wave_cnt[2][1 + wave] + wave_cnt[3][1 + wave];
+        const unsigned short* const wl = wlist[wave];
         // ---- accumulate the surviving objects at this thread's pixel.  Branch-free and software-pipelined: the four taps of
         // candidate ci+1 are in flight while candidate ci is composited (taps outside the sprite / pixels the object does not
         // cover read a clamped texel with weight 0).  With a `continue` per tap every load sat behind its own wait and the
@@ -147,9 +170,9 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
                     v[t] = ld_texel<S16>(S, sp + (min(max(yy, 0), P - 1) * P + min(max(xx, 0), P - 1)));
                 }
             };
-            fetch(0, tv, tw, prs, pdd);
+            fetch(wl[0], tv, tw, prs, pdd);
             for (int ci = 0; ci < nc; ++ci) {
-                fetch(min(ci + 1, nc - 1), tn, twn, prs_n, pdd_n);
+                fetch(wl[min(ci + 1, nc - 1)], tn, twn, prs_n, pdd_n);
                 float g = 0.f, a = 0.f, m = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
