@@ -713,7 +713,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
     __shared__ float gtile[NW][16][17];       // wave-private transpose tile of the glimpse-gradient epilogue
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
-    __shared__ int cons_sh[MT][4], nbr_row[MT][4];
+    __shared__ __attribute__((aligned(16))) int cons_sh[MT][4];
+    __shared__ int nbr_row[MT][4];
     // per-row scalars and vectors of the wavefront, fetched one wavefront AHEAD with coalesced loads and parked here: no global
     // load is left inside a stage (each one cost a full HBM round trip on the critical path: 1.5-3 us in the pres / depth / attr /
     // box stages).  Row layout (floats): see BD_* below.
@@ -849,17 +850,26 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
-        for (int idx = tid; idx < nc * REC; idx += NTH) {
-            const int row = idx / REC, j = idx - row * REC;
-            float g = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int q = cons_sh[row][s];
-                if (q < 0) continue;
-                const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);
-                g += ring[(t + dt) & 3][q - dstart_sh[t + dt]][F + s * REC + j];
+        // (branch-free: the four consumer slots are read side by side -- with a `continue` per slot the loop was twelve dependent LDS
+        // round trips, 1.2 us per wavefront)
+        {
+            const int d1 = dstart_sh[min(t + 1, T)], d2 = dstart_sh[min(t + 2, T)], d3 = dstart_sh[min(t + 3, T)];
+            const float (*r1)[LD_R] = ring[(t + 1) & 3];
+            const float (*r2)[LD_R] = ring[(t + 2) & 3];
+            const float (*r3)[LD_R] = ring[(t + 3) & 3];
+            for (int idx = tid; idx < nc * REC; idx += NTH) {
+                const int row = idx / REC, j = idx - row * REC;
+                const int4 q = *reinterpret_cast<const int4*>(cons_sh[row]);
+                const float v0 = r3[min(max(q.x - d3, 0), MT - 1)][F + j];
+                const float v1 = r2[min(max(q.y - d2, 0), MT - 1)][F + REC + j];
+                const float v2 = r1[min(max(q.z - d1, 0), MT - 1)][F + 2 * REC + j];
+                const float v3 = r1[min(max(q.w - d1, 0), MT - 1)][F + 3 * REC + j];
+                float g = q.x >= 0 ? v0 : 0.f;
+                g += q.y >= 0 ? v1 : 0.f;
+                g += q.z >= 0 ? v2 : 0.f;
+                g += q.w >= 0 ? v3 : 0.f;
+                grec[row][j] = g;
             }
-            grec[row][j] = g;
         }
         lds_barrier();
         CB_STAMP();
