@@ -7,6 +7,7 @@
 //   gemm_tn16 : C[M,N] += sum_r A[r,M] . B[r,N] (weight gradients), A bf16, B bf16 (plain / conv gather) or fp32 gather
 //               (first layer, Cin = image channels); operands staged row-major, fragments through ds_read_b64_tr_b16;
 //               split over r with fp32 atomics; optional fused column sums of A (bias gradient); XCD-aware tile order.
+#include <cstdlib>
 #include "common.h"
 #include "gemm.h"
 
@@ -83,11 +84,13 @@ __device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int 
 // matrix is 1: the bias gradient) -- and d act0 is never written to HBM (321 MB out + 321 MB back in at config 2).  Each
 // workgroup leaves a [128][17] fp32 partial; spair_gemm_nt16_impl sums them (two small passes, no atomics).
 #define STEM_PART_FLOATS (128 * 17)
-template <bool ACONV, bool C16, bool STEM>
-__global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
-    constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 8;
+template <bool ACONV, bool C16, bool STEM, int BK>
+__global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT g) {
+    static_assert(BK == 64 || (BK == 32 && !STEM), "K tile");
+    constexpr int BM = 128, BN = 128, LD = BK + 8;
     constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
-    constexpr int NA = BM * (BK / 8) / 256, NB = BN * (BK / 8) / 256;   // 16-byte chunks per thread: 4 + 4
+    constexpr int KQ = BK / 8, RPI = 256 / KQ;                          // 16-byte chunks per tile row; rows staged per pass of the block
+    constexpr int NA = BM * KQ / 256, NB = BN * KQ / 256;               // 16-byte chunks per thread: 4 + 4 (BK 64), 2 + 2 (BK 32)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
     __bf16* As0 = smem;                       // [2][BM*LD]
     __bf16* Bs0 = smem + 2 * BM * LD;         // [2][BN*LD]
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     // Address arithmetic is the bottleneck of a conv gather if done naively (a 64-bit multiply chain per 16-byte chunk made both
     // conv kernels VALU-issue bound): every row's element offset is computed ONCE (32-bit), the tap's offset once per K tile, and a
     // chunk's address is one add.  Tensors must stay below 2^31 elements (checked by the launcher).
-    const int kq = tid & 7;
+    const int kq = tid % KQ;
     ConvTap16 a_ct;
     unsigned a_base[NA];                 // element offset of (b, y*sy+oy, x*sx+ox, 0) (conv) or of row m (plain)
     int a_y[NA], a_x[NA];                // conv: y*sy+oy, x*sx+ox for the bounds test of data-gradient gathers
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     const bool need_bounds = ACONV && (g.conv.dky < 0 || g.conv.oy != 0 || g.conv.ox != 0 || g.conv.dkx < 0);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 3) + i * 32;
+        const int row = tid / KQ + i * RPI;
         a_ok[i] = (m0 + row) < g.M;
         const int mr = min(m0 + row, g.M - 1);
         a_y[i] = a_x[i] = 0;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (tid >> 3) + i * 32;
+        const int row = tid / KQ + i * RPI;
         b_ok[i] = (n0 + row) < g.N;
         b_base[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldb;
     }
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         __bf16* As = As0 + buf * BM * LD;
         __bf16* Bs = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[((tid >> 3) + i * 32) * LD + kq * 8]) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[(tid / KQ + i * RPI) * LD + kq * 8]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + i * 32) * LD + kq * 8]) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[(tid / KQ + i * RPI) * LD + kq * 8]) = rb[i];
     };
 
     f32x4 acc[TM][TN];
@@ -230,7 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
     // coalesced 16-byte-per-lane access of whole rows: the relu-mask read (data gradients), the row-remapped store, the sprite
     // sigmoid.  Straight from the MFMA layout a lane would issue 64 scattered 2-byte mask loads and 64 2/4-byte stores of
     // 32/64-byte segments (decoder.out: 411 MB of fp32 sprites left at 1 TB/s).
-    constexpr int LDC = BN + 4;                       // fp32 staging tile [BM][LDC]: 67.6 KB of the 73.7 KB
+    constexpr int LDC = BN + 4;                       // fp32 staging tile [BM][LDC]: 67.6 KB of the 73.7 KB (BK 64)
+    constexpr int NH = BK == 32 ? 2 : 1;              // BK 32 (40 KB of LDS, 3 workgroups per CU): the tile is staged in two 64-row passes
+    constexpr int RH = BM / NH;
     float* Cs = reinterpret_cast<float*>(smem);
     const bool vec_ok = C16 ? ((g.ldc & 7) == 0) : ((g.ldc & 3) == 0);
     const int c8 = (tid & 15) * 8;                    // this thread's 8 columns; rows (tid>>4) + 16*i
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
         sp[3] = *reinterpret_cast<const float2*>(src + g.stem_hin + 2);
     }
     uint4 gq[STEM ? NR : 1];
-    {
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+    if (hh > 0) __syncthreads();                      // the previous pass has been read
+    if (NH == 1 || wm == hh) {
         const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -283,20 +291,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Cs[(wm * WM + i * 16 + rgrp + r) * LDC + nl] = acc[i][j][r] + bv;
+                for (int r = 0; r < 4; ++r) Cs[(wm * WM + i * 16 + rgrp + r - hh * RH) * LDC + nl] = acc[i][j][r] + bv;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int ii = 0; ii < NR / NH; ++ii) {
+        const int i = hh * (NR / NH) + ii;
         const int rl = (tid >> 4) + i * 16;
         const int m = m0 + rl;
         if (STEM) gq[i] = make_uint4(0u, 0u, 0u, 0u);
         if (m >= g.M || nb >= g.N) continue;
         float v[8];
         {
-            const float4 q0 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8]);
-            const float4 q1 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c8 + 4]);
+            const float4 q0 = *reinterpret_cast<const float4*>(&Cs[(rl - hh * RH) * LDC + c8]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&Cs[(rl - hh * RH) * LDC + c8 + 4]);
             v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
         }
         if (g.relu) {
@@ -378,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(GemmNT g) {
                     if (nb + e < g.N) dst[e] = v[e];
             }
         }
+    }
     }
     if (STEM) {
         constexpr int LDG = BN + 8, LDP = 32 + 8;
@@ -476,20 +486,27 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     if (g.accumulate) return SPAIR_ERR_UNSUPPORTED;
     if (!conv && (long long)g.M * g.lda >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;   // 32-bit element offsets
     if ((long long)g.N * g.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
-    constexpr size_t lds = (size_t)2 * (128 + 128) * (64 + 8) * 2;
+    // K tile: 64 (73.7 KB of LDS, 2 workgroups per CU) or 32 (41 KB, 3 per CU, the epilogue staged in two passes).  Measured: the
+    // long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out data gradient 0.099 vs 0.128 ms), the short-K
+    // ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148 ms).  SPAIR_NT16_BK=32|64 forces one.
+    static const int bk_env = [] { const char* e = getenv("SPAIR_NT16_BK"); return e ? atoi(e) : 0; }();
+    const int bk = g.stem_part ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
+    const size_t lds = (size_t)2 * (128 + 128) * (bk + 8) * 2;
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
     if (g.nz > 1) grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.nz);      // (8 XCDs) x (nz classes) x ceil(tiles / 8)
-#define NT16_LAUNCH(AC, C16, ST)                                                                                 \
+#define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST>),                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST>), grid, dim3(256), lds, s, g);                          \
+        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV>), grid, dim3(256), lds, s, g);                     \
     } while (0)
+#define NT16_LAUNCH(AC, C16, ST)                                                                                 \
+    do { if (!(ST) && bk == 32) NT16_LAUNCH_BK(AC, C16, false, 32); else NT16_LAUNCH_BK(AC, C16, ST, 64); } while (0)
     if (g.stem_part) {   // conv_1's data gradient with the stem's weight gradient taken in the epilogue
         if (!conv || !g.stem_xp || !g.stem_dw || !spair_nt16_stem_fusable(g, g.stem_part_cap)) return SPAIR_ERR_UNSUPPORTED;
         NT16_LAUNCH(true, true, true);
@@ -505,6 +522,7 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     if (conv) { if (g.c_bf16) NT16_LAUNCH(true, true, false); else NT16_LAUNCH(true, false, false); }
     else { if (g.c_bf16) NT16_LAUNCH(false, true, false); else NT16_LAUNCH(false, false, false); }
 #undef NT16_LAUNCH
+#undef NT16_LAUNCH_BK
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
