@@ -7,6 +7,7 @@
 //   gemm_tn16 : C[M,N] += sum_r A[r,M] . B[r,N] (weight gradients), A bf16, B bf16 (plain / conv gather) or fp32 gather
 //               (first layer, Cin = image channels); operands staged row-major, fragments through ds_read_b64_tr_b16;
 //               split over r with fp32 atomics; optional fused column sums of A (bias gradient); XCD-aware tile order.
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 #include "gemm.h"
@@ -86,7 +87,7 @@ __device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int 
 #define STEM_PART_FLOATS (128 * 17)
 template <bool ACONV, bool C16, bool STEM, int BK>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT g) {
-    static_assert(BK == 64 || (BK == 32 && !STEM), "K tile");
+    static_assert(BK == 64 || BK == 32, "K tile");
     constexpr int BM = 128, BN = 128, LD = BK + 8;
     constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
     constexpr int KQ = BK / 8, RPI = 256 / KQ;                          // 16-byte chunks per tile row; rows staged per pass of the block
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         constexpr int LDG = BN + 8, LDP = 32 + 8;
         __bf16* Gs = smem;                                   // [BM rows][LDG]: the gated tile, bf16 (what d act0 would have held)
         __bf16* Ps = smem + BM * LDG;                        // [BM rows][LDP]: 16 taps | 1 | 0 ...
-        float* Ws = reinterpret_cast<float*>(smem + BM * LDG + BM * LDP);    // [128 ch][17]
+        float* Ws = reinterpret_cast<float*>(smem);          // [128 ch][17]: over the gated tile once the MFMAs have read it (45 KB in all)
         __syncthreads();                                     // every thread has read its part of Cs
 #pragma unroll
         for (int i = 0; i < NR; ++i) *reinterpret_cast<uint4*>(&Gs[((tid >> 4) + i * 16) * LDG + c8]) = gq[i];
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #pragma unroll
                 for (int j = 0; j < 2; ++j) sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], sacc[i][j], 0, 0, 0);
         }
+        __syncthreads();                                     // Gs is free
         {
             const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
@@ -490,8 +492,9 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     // long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out data gradient 0.099 vs 0.128 ms), the short-K
     // ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148 ms).  SPAIR_NT16_BK=32|64 forces one.
     static const int bk_env = [] { const char* e = getenv("SPAIR_NT16_BK"); return e ? atoi(e) : 0; }();
-    const int bk = g.stem_part ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
-    const size_t lds = (size_t)2 * (128 + 128) * (bk + 8) * 2;
+    const int bk = (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
+    size_t lds = (size_t)2 * (128 + 128) * (bk + 8) * 2;
+    if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
     if (g.nz > 1) grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.nz);      // (8 XCDs) x (nz classes) x ceil(tiles / 8)
@@ -506,7 +509,7 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV>), grid, dim3(256), lds, s, g);                     \
     } while (0)
 #define NT16_LAUNCH(AC, C16, ST)                                                                                 \
-    do { if (!(ST) && bk == 32) NT16_LAUNCH_BK(AC, C16, false, 32); else NT16_LAUNCH_BK(AC, C16, ST, 64); } while (0)
+    do { if (bk == 32) NT16_LAUNCH_BK(AC, C16, ST, 32); else NT16_LAUNCH_BK(AC, C16, ST, 64); } while (0)
     if (g.stem_part) {   // conv_1's data gradient with the stem's weight gradient taken in the epilogue
         if (!conv || !g.stem_xp || !g.stem_dw || !spair_nt16_stem_fusable(g, g.stem_part_cap)) return SPAIR_ERR_UNSUPPORTED;
         NT16_LAUNCH(true, true, true);
