@@ -7,48 +7,66 @@
 
 #define KL_MAXBINS 1025   // HW+1 for G <= 32
 
+// orders a wave's own LDS writes before its later reads of other lanes' values (no workgroup barrier: one wave per sample)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane), so a step is
+// register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
+// G = 32, where this kernel, not the decoder beside it, set the forward's length).
+template <int NBR>
 __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
-    __shared__ float cd_sh[4][KL_MAXBINS + 7];
     __shared__ float z_sh[4][KL_MAXBINS - 1];
     __shared__ float pz_sh[4][KL_MAXBINS - 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= L.B) return;
-    float* cd = cd_sh[wave];
     float* zs = z_sh[wave];
     float* pzs = pz_sh[wave];
     const int HW = L.HW, NB = HW + 1;
     // all of this sample's z_pres in row-major cell order: no global access inside the sequential loop
     for (int i = lane; i < HW; i += 64) zs[i] = P.rec[((size_t)P.cidx[i] * L.B + b) * L.ld_rec + L.REC - 1];
     // geometric count distribution (1-p) p^k, normalised (models.py:190-193)
+    float c[NBR], ef[NBR];
     float part = 0.f;
-    for (int e = lane; e < NB; e += 64) {
-        const float v = (1.f - prior_prob) * powf(prior_prob, (float)e);
-        cd[e] = v;
-        part += v;
+#pragma unroll
+    for (int k = 0; k < NBR; ++k) {
+        const int e = k * 64 + lane;
+        ef[k] = (float)e;
+        c[k] = e < NB ? (1.f - prior_prob) * powf(prior_prob, (float)e) : 0.f;     // bins past HW stay 0
+        part += c[k];
     }
     const float norm0 = wave_reduce_sum(part);
-    for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / norm0;
+#pragma unroll
+    for (int k = 0; k < NBR; ++k) c[k] = c[k] / norm0;
+    wave_lds_fence();
     float count = 0.f;
+    float znext = zs[0];
     for (int i = 0; i < HW; ++i) {
-        const float z = zs[i];
-        const float rem = (float)(HW - i);
-        const float s = rintf(z);   // torch.round: half to even
+        const float z = znext;
+        znext = zs[min(i + 1, HW - 1)];
+        const float rem = (float)(HW - i), inv_rem = 1.f / rem;      // one IEEE division per step; x * (1/r) is within 1 ulp of x / r
+        const bool on = rintf(z) != 0.f;   // torch.round: half to even
         float pz = 0.f, np = 0.f;
-        for (int e = lane; e < NB; e += 64) {
-            const float q = fminf(fmaxf((float)e - count, 0.f), rem) / rem;
-            const float c = cd[e];
-            pz += c * q;
-            const float v = (s * q + (1.f - s) * (1.f - q)) * c;
-            cd[e] = v;
+#pragma unroll
+        for (int k = 0; k < NBR; ++k) {
+            const float q = fminf(fmaxf(ef[k] - count, 0.f), rem) * inv_rem;
+            pz += c[k] * q;
+            const float v = (on ? q : 1.f - q) * c[k];
+            c[k] = v;
             np += v;
         }
         pz = wave_reduce_sum(pz);
         np = fmaxf(wave_reduce_sum(np), 1e-6f);
-        for (int e = lane; e < NB; e += 64) cd[e] = cd[e] / np;
+        const float inv_np = 1.f / np;
+#pragma unroll
+        for (int k = 0; k < NBR; ++k) c[k] = c[k] * inv_np;
         if (lane == 0) pzs[i] = pz;
-        count += s;
+        count += on ? 1.f : 0.f;
     }
+    wave_lds_fence();
     // Bernoulli KL per cell (models.py:223-226) and the p_z map the backward pass needs
     float klsum = 0.f;
     for (int i = lane; i < HW; i += 64) {
@@ -141,7 +159,10 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
 
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s) {
     if (L.HW + 1 > KL_MAXBINS) return SPAIR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_count_kl, dim3(ceil_div(L.B, 4)), dim3(256), 0, s, L, P, prior_prob, klp);
+    const dim3 grid(ceil_div(L.B, 4));
+    if (L.HW + 1 <= 5 * 64) hipLaunchKernelGGL(k_count_kl<5>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
+    else if (L.HW + 1 <= 9 * 64) hipLaunchKernelGGL(k_count_kl<9>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
+    else hipLaunchKernelGGL(k_count_kl<17>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
