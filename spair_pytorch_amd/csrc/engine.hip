@@ -329,7 +329,7 @@ struct Ctx {
 // SpairStep.flags bit 2 disables it (everything on the caller's stream).
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t ev[4];
+    hipEvent_t ev[6];
     int dev = -1;
 };
 static SideStream g_side;
@@ -338,7 +338,7 @@ static int side_stream(SideStream*& out) {
     if (hipGetDevice(&dev) != hipSuccess) return SPAIR_ERR_LAUNCH;
     if (g_side.s == nullptr || g_side.dev != dev) {
         if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) return SPAIR_ERR_LAUNCH;
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 6; ++i)
             if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return SPAIR_ERR_LAUNCH;
         g_side.dev = dev;
     }
@@ -433,7 +433,8 @@ static const void* bptr(const void* base, size_t elem_off, int dtype) {
 }
 
 // ---- weight preparation ----------------------------------------------------------------------------
-static int prep_weights(Ctx& c, bool need_dgrad) {
+// part 0: the backbone's conv weights (what conv_1 waits for); part 1: everything else (first needed by the per-cell chain)
+static int prep_weights(Ctx& c, bool need_dgrad, int part) {
     std::vector<PrepEntry> es;
     const int bf = c.d.dtype == SPAIR_BF16;
     auto push = [&](const float* src, void* dst, int rows, int cols, int ld, int mode, int bf16, int cin = 0, int cout = 0, int k = 0,
@@ -444,7 +445,7 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
         e.cin = cin; e.cout = cout; e.k = k; e.py = py; e.px = px; e.T = T; e.s = s;
         es.push_back(e);
     };
-    for (int i = 1; i < c.PL.n_conv; ++i) {
+    for (int i = 1; part == 0 && i < c.PL.n_conv; ++i) {
         const ConvSpec& cs = c.PL.conv[i];
         const float* w = c.params + cs.w;
         const int K = cs.k * cs.k * cs.cin;
@@ -461,7 +462,7 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
             }
         }
     }
-    for (int id = 0; id < LIN_COUNT; ++id) {
+    for (int id = 0; part == 1 && id < LIN_COUNT; ++id) {
         if (id == LIN_BOXH0 || id == LIN_ZH0) continue;
         const LinSpec& l = c.PL.lin[id];
         const int ldf = round_up(l.in, 8);
@@ -478,7 +479,7 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
             if (need_dgrad) push(c.params + h.w, const_cast<void*>(bptr(c.w.lin_wt[id], (size_t)l.out, c.d.dtype)), h.in, h.out, ldt, 1, bf);
         }
     }
-    if (c.use_chain) {
+    if (part == 1 && c.use_chain) {
         auto pack = [&](int cw, int lin_id, int KT, int ksplit, int kpad0, int n_off) {
             const LinSpec& l = c.PL.lin[lin_id];
             PrepEntry e;
@@ -517,10 +518,12 @@ static int prep_weights(Ctx& c, bool need_dgrad) {
             packt(CW_OBJ0, LIN_OBJ0, 4, 0); packt(CW_OBJ1, LIN_OBJ1, 4, 0);
         }
     }
-    push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
-    push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
-    push(c.params + c.PL.lin[LIN_ZH1].b, c.w.bias_zh, 1, c.L.NP, c.L.NP + 8, 0, 0);
-    push(c.params + c.PL.lin[LIN_ZH0].b, c.w.bias_zh + c.L.NP, 1, 2, 8, 0, 0);
+    if (part == 1) {
+        push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
+        push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
+        push(c.params + c.PL.lin[LIN_ZH1].b, c.w.bias_zh, 1, c.L.NP, c.L.NP + 8, 0, 0);
+        push(c.params + c.PL.lin[LIN_ZH0].b, c.w.bias_zh + c.L.NP, 1, 2, 8, 0, 0);
+    }
     for (size_t i = 0; i < es.size(); i += SP_MAX_PREP) {
         PrepTable T;
         T.n = (int)std::min((size_t)SP_MAX_PREP, es.size() - i);
@@ -835,10 +838,12 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
         {
             ProfScope ps(PS_PREP, c.s);
+            TRY(prep_weights(c, st->train != 0, 0));       // conv weights first: conv_1 waits for these only
+            if (side && hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
             TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
-            TRY(prep_weights(c, st->train != 0));
+            TRY(prep_weights(c, st->train != 0, 1));
         }
-        if (side && hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        if (side && hipEventRecord(side->ev[4], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
         // the padded copy is only read by the stem's weight gradient: it stays behind the event conv_1 waits on (the helper stream's
         // later joins order it before the backward)
         if (misc_conv0_reads_unpadded(d->B, c.PL.conv[0].hin, d->C, c.PL.conv[0].k, c.PL.conv[0].cout))
@@ -850,6 +855,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     if (side && hipStreamWaitEvent(c.s, side->ev[3], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
     TRY(backbone_fwd(c));
     prof_end(ps_bb, c.s);
+    if (side && hipStreamWaitEvent(c.s, side->ev[4], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // tables, per-cell and decoder weights
     { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
     // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer
     {
