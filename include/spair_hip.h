@@ -46,6 +46,9 @@ typedef struct SpairStep {
     int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps;
                                 * bit 2: no helper stream (every kernel on the caller's stream);
                                 * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient) */
+    int draw_noise;            /* spair_forward only: 1 = fill eps_box/eps_attr/eps_depth/u_pres from noise_seed first (what spair_noise_fill
+                                * does, but on the helper stream beside the backbone); the buffers must be writable */
+    unsigned long long noise_seed;
 } SpairStep;
 
 /* ---- parameter / workspace layout -------------------------------------------------------- */

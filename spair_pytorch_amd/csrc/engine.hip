@@ -841,6 +841,9 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             TRY(prep_weights(c, st->train != 0, 0));       // conv weights first: conv_1 waits for these only
             if (side && hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
             TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
+            if (st->draw_noise)
+                TRY(spair_noise_fill(d, st->noise_seed, const_cast<float*>(eps_box), const_cast<float*>(eps_attr), const_cast<float*>(eps_depth),
+                                     const_cast<float*>(u_pres), c.s));
             TRY(prep_weights(c, st->train != 0, 1));
         }
         if (side && hipEventRecord(side->ev[4], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;

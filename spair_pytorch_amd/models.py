@@ -44,7 +44,7 @@ class SpairDims(ctypes.Structure):
 class SpairStep(ctypes.Structure):
     """include/spair_hip.h :: SpairStep"""
     _fields_ = [("wheel", ctypes.c_float), ("count_prior_prob", ctypes.c_float), ("kl_scale", ctypes.c_float),
-                ("train", ctypes.c_int), ("flags", ctypes.c_int)]
+                ("train", ctypes.c_int), ("flags", ctypes.c_int), ("draw_noise", ctypes.c_int), ("noise_seed", ctypes.c_uint64)]
 
 
 # bit 0: disable the fused persistent per-cell kernels (tests compare both paths); bit 1: stage stamps; bit 2: no helper stream
@@ -285,10 +285,8 @@ class SPAIR(nn.Module):
         """The 7 per-cell draws (models.py:333-336,84,95,402-403) as whole maps, one launch; the seed
         comes from torch's CPU generator so torch.manual_seed controls it."""
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        n = e['noise']
-        L.check(L.lib().spair_noise_fill(ctypes.byref(e['dims']), ctypes.c_uint64(seed), L.ptr(n['eps_box']), L.ptr(n['eps_attr']),
-                                         L.ptr(n['eps_depth']), L.ptr(n['u_pres']), L.stream()), "spair_noise_fill")
-        return n
+        # the maps are filled by spair_forward itself (SpairStep.draw_noise), on its helper stream beside the backbone
+        return dict(e['noise'], _seed=seed)
 
     def _run_forward(self, x, step, noise, train):
         e = self._engine(x.shape[0])
@@ -300,6 +298,8 @@ class SPAIR(nn.Module):
         z_where = torch.empty(B, 4, G, G, device=dev, dtype=torch.float32)
         z_pres = torch.empty(B, 1, G, G, device=dev, dtype=torch.float32)
         st = step_scalars(step, B, self.world_size, train)
+        if noise.get('_seed') is not None:
+            st.draw_noise, st.noise_seed = 1, int(noise['_seed'])
         self._last = dict(engine=e, st=st)
         L.check(L.lib().spair_forward(ctypes.byref(d), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
                                       L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),

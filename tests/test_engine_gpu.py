@@ -138,3 +138,28 @@ def test_noise_statistics():
     ea2 = torch.empty_like(ea)
     L.check(L.lib().spair_noise_fill(ctypes.byref(d), ctypes.c_uint64(1234), L.ptr(eb), L.ptr(ea2), L.ptr(ed), L.ptr(up), L.stream()), "noise")
     assert torch.equal(ea, ea2)   # counter-based: same seed, same stream
+
+
+def test_internal_noise_follows_torch_seed():
+    """Without injected noise the 7 per-cell draws come from SpairStep.draw_noise (filled inside spair_forward on its helper stream)
+    with a seed taken from torch's CPU generator: same torch seed -> same step to the bit, another seed -> another sample; and the
+    maps the backward reads are the ones the forward drew (the gradient of a repeated step is identical)."""
+    z, case = load_case("c1_b8_step1001")
+    m = build_model(case, "bf16")
+    x = torch.from_numpy(z["x"]).cuda()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        m.zero_grad()
+        loss = m(x, 1001)[0]
+        loss.backward()
+        return loss.item(), m.flat_gradients().clone()
+
+    la, ga = run(5)
+    lb, gb = run(5)
+    lc, gc = run(6)
+    assert la == lb
+    assert (ga - gb).abs().max().item() <= 1e-5 * ga.abs().max().item()      # fp32 atomics on the edge/bias gradients
+    assert lc != la
+    eps = m._last["engine"]["noise"]["eps_attr"]
+    assert abs(eps.mean().item()) < 0.05 and abs(eps.std().item() - 1.0) < 0.05
