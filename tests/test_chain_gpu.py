@@ -64,3 +64,15 @@ def test_stem_weight_gradient_fused_into_conv1_dgrad(name):
             assert (ga - gb).norm().item() <= 2e-3 * gb.norm().item(), k
             seen += 1
     assert seen == 2
+
+
+def test_helper_stream_off_gives_the_same_step():
+    """SpairStep.flags bit 2: every kernel on the caller's stream (no fork/join by events) -- same kernels, same results."""
+    z, case = load_case("c2_b2_step1001")
+    a = run(case, z, flags=0)
+    b = run(case, z, flags=4)
+    for k in ("z_where", "z_pres", "z_attr", "z_depth", "recon"):
+        assert (a[k] - b[k]).abs().max().item() == 0.0, k
+    assert a["terms"][0].item() == b["terms"][0].item()
+    ga, gb = a["grads"].double(), b["grads"].double()
+    assert (ga - gb).norm().item() <= 1e-5 * gb.norm().item()      # fp32 atomics on bias / edge gradients
