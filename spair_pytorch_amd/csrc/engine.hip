@@ -407,14 +407,29 @@ static int tn(Ctx& c, const float* A, int lda, int M, const float* B, int ldb, i
     return spair_gemm_tn_impl(g, false, c.d.dtype, c.s);
 }
 // bf16-stored operand GEMMs (gemm16.hip)
+// strided k x k convs of the bf16 step keep their forward weights in tap-parity K order (gemm.h, GemmNT::ktab)
+static bool conv_kperm(const Ctx& c, const ConvSpec& cs) {
+    return c.d.dtype == SPAIR_BF16 && cs.k > 1 && cs.s > 1 && cs.k % cs.s == 0 && cs.cin % 64 == 0 && cs.k * cs.k * cs.cin / 64 <= 64;
+}
+static void fill_ktab(GemmNT& g, const ConvSpec& cs) {
+    const int T = cs.k / cs.s, TT = T * T, nh = cs.cin / 64;
+    g.n_ktab = cs.k * cs.k * nh;
+    for (int blk = 0; blk < g.n_ktab; ++blk) {
+        const int tq = blk % TT, rr = blk / TT, h = rr % nh, cls = rr / nh;
+        const int ky = cls / cs.s + cs.s * (tq / T), kx = cls % cs.s + cs.s * (tq % T);
+        g.ktab[blk] = ((unsigned)ky << 24) | ((unsigned)kx << 16) | (unsigned)(h * 64);
+    }
+}
 static int nt16(Ctx& c, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
-                const void* mask, int ldmask, int relu, const ConvDesc* conv = nullptr, const RowMap* cmap = nullptr) {
+                const void* mask, int ldmask, int relu, const ConvDesc* conv = nullptr, const RowMap* cmap = nullptr,
+                const ConvSpec* fwd_cs = nullptr) {
     GemmNT g;
     memset(&g, 0, sizeof(g));
     g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.B = B; g.ldb = ldb; g.C = reinterpret_cast<float*>(C); g.ldc = ldc; g.c_bf16 = c_bf16;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.mask = reinterpret_cast<const float*>(mask); g.ldmask = ldmask; g.mask_bf16 = 1; g.relu = relu;
     if (conv) g.conv = *conv;
     if (cmap) { g.cmap = *cmap; g.use_cmap = 1; }
+    if (fwd_cs && conv_kperm(c, *fwd_cs)) fill_ktab(g, *fwd_cs);       // forward conv: B (conv_wf) is stored in tap-parity K order
     return spair_gemm_nt16_impl(g, conv != nullptr, c.s);
 }
 static int tn16(Ctx& c, const void* A, int lda, int M, const void* B, int ldb, int N, bool b_bf16, float* C, int ldc, int R, float* colsum,
@@ -453,7 +468,8 @@ static int prep_weights(Ctx& c, bool need_dgrad, int part) {
             push(w, c.w.conv_wf[i], cs.cout, cs.cin, round_up(K, 8), 0, bf);
             if (need_dgrad) push(w, c.w.conv_wd[i][0], cs.cin, cs.cout, round_up(cs.cout, 8), 1, bf);
         } else {
-            push(w, c.w.conv_wf[i], cs.cout, K, round_up(K, 8), 2, bf, cs.cin, cs.cout, cs.k);
+            const bool perm = conv_kperm(c, cs);
+            push(w, c.w.conv_wf[i], cs.cout, K, round_up(K, 8), 2, bf, cs.cin, cs.cout, cs.k, 0, 0, perm ? cs.k / cs.s : 0, perm ? cs.s : 0);
             if (need_dgrad) {
                 const int T = cs.k / cs.s;
                 for (int py = 0; py < cs.s; ++py)
@@ -592,7 +608,7 @@ static int backbone_fwd(Ctx& c) {
         if (b16) {   // activations stored as bf16; the feature map handed to the per-cell chain stays fp32
             ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
             TRY(nt16(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, last ? 0 : 1, M, cs.cout, round_up(K, 8),
-                     c.params + cs.b, nullptr, 0, last ? 0 : 1, cs.k == 1 ? nullptr : &cd));
+                     c.params + cs.b, nullptr, 0, last ? 0 : 1, cs.k == 1 ? nullptr : &cd, nullptr, cs.k == 1 ? nullptr : &cs));
         } else if (cs.k == 1) {
             TRY(nt(c, c.w.act[i - 1], cs.cin, c.w.conv_wf[i], round_up(K, 8), out, ldc, M, cs.cout, round_up(K, 8), c.params + cs.b, nullptr, 0, last ? 0 : 1));
         } else {

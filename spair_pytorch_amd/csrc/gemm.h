@@ -17,6 +17,12 @@ struct GemmNT {
     // gemm16.hip: nz > 1 batches the nz = osy*osx output-parity classes of a strided conv data-gradient in ONE launch
     // (blockIdx.z = py*osx + px picks the weight matrix Bz[z] and the row-map offsets); all classes must have the same size.
     int nz; const void* Bz[4];
+    // gemm16.hip conv gathers, optional: K runs over 64-column blocks in tap-parity order -- ktab[kt] = ky << 24 | kx << 16 | first channel
+    // of K block kt (n_ktab = K / 64 <= 64 entries, Cin % 64 == 0, B stored in the same order).  The taps of one stride-parity class read
+    // the same input lattice shifted by one output pixel, so running them back to back turns the 4x re-use of a strided conv's input
+    // into L2 hits (conv_1 forward fetched 860 MB for a 321 MB input in (ky, kx, ci) order).
+    int n_ktab; unsigned ktab[64];
+    int xcd_tiles_n;                      // filled by the gemm16.hip launcher: > 1 = linear grid, the N tiles of an M block adjacent on one XCD
     // gemm16.hip, conv_1's data gradient only: stem_part != NULL fuses the stem's weight gradient into the epilogue (the gated
     // tile x the 4x4 patches of the padded single-channel input stem_xp [B][stem_hin][stem_hin], stride stem_s) and skips the C
     // store; per-workgroup partials go to stem_part (capacity in floats), their sum is added to stem_dw [128][16] / stem_db [128].

@@ -108,7 +108,16 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         mt = (j / g.nz) * 8 + xcd;
         if (mt * BM >= g.M) return;                  // grid padded to a whole number of (8 XCD x nz) groups
     }
-    const int m0 = mt * BM, n0 = blockIdx.y * BN;
+    // several N tiles: the tiles of one M block read the same A rows, so they too run back to back on one XCD (column-tile-major
+    // order re-streamed A once per N tile: the decoder.out data gradient read its 205 MB of d-logits twice and was HBM bound)
+    int ntile = blockIdx.y;
+    if (g.xcd_tiles_n > 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        ntile = j % g.xcd_tiles_n;
+        mt = (j / g.xcd_tiles_n) * 8 + xcd;
+        if (mt * BM >= g.M) return;
+    }
+    const int m0 = mt * BM, n0 = ntile * BN;
     const u16* A = reinterpret_cast<const u16*>(g.A);
     const u16* B = reinterpret_cast<const u16*>(g.nz > 1 ? g.Bz[zq] : g.B);
     const int cm_ooy = g.nz > 1 ? zq / g.cmap.osx : g.cmap.ooy, cm_oox = g.nz > 1 ? zq - (zq / g.cmap.osx) * g.cmap.osx : g.cmap.oox;
@@ -157,8 +166,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         const bool kok = k < g.K;
         const unsigned kc = (unsigned)min(k, Klast);
         if (ACONV) {
-            const int dy = a_ct.ky * g.conv.dky, dx = a_ct.kx * g.conv.dkx;
-            const unsigned tapoff = (unsigned)((dy * g.conv.Win + dx) * g.conv.Cin + min(a_ct.ci, g.conv.Cin - 8));
+            int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
+            if (BK == 64 && g.n_ktab > 0) {     // wave-uniform: tap-parity K order, one (tap, 64-channel block) per K tile
+                const unsigned e = g.ktab[min(k0 >> 6, g.n_ktab - 1)];
+                t_ky = (int)(e >> 24); t_kx = (int)((e >> 16) & 255u); t_ci = (int)(e & 0xffffu) + kq * 8;
+            }
+            const int dy = t_ky * g.conv.dky, dx = t_kx * g.conv.dkx;
+            const unsigned tapoff = (unsigned)((dy * g.conv.Win + dx) * g.conv.Cin + min(t_ci, g.conv.Cin - 8));
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 bool ok = a_ok[i] && kok;
@@ -481,7 +495,8 @@ bool spair_nt16_stem_fusable(const GemmNT& g, long long part_cap) {
            (tiles + 64) * STEM_PART_FLOATS <= part_cap;
 }
 
-int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
+int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
+    GemmNT g = g_in;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return SPAIR_ERR_SHAPE;
     if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldb & 7)) return SPAIR_ERR_ALIGN;
     if (conv && (g.conv.Cin & 7)) return SPAIR_ERR_ALIGN;
@@ -492,12 +507,19 @@ int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s) {
     // long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out data gradient 0.099 vs 0.128 ms), the short-K
     // ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148 ms).  SPAIR_NT16_BK=32|64 forces one.
     static const int bk_env = [] { const char* e = getenv("SPAIR_NT16_BK"); return e ? atoi(e) : 0; }();
-    const int bk = (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
+    if (g.n_ktab > 0 && (!conv || g.n_ktab > 64 || g.n_ktab * 64 != g.K || (g.conv.Cin & 63))) return SPAIR_ERR_SHAPE;
+    const int bk = g.n_ktab > 0 ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
     size_t lds = (size_t)2 * (128 + 128) * (bk + 8) * 2;
     if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
     if (g.nz > 1) grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.nz);      // (8 XCDs) x (nz classes) x ceil(tiles / 8)
+    g.xcd_tiles_n = 0;
+    if (g.nz <= 1 && grid.y > 1) {
+        g.xcd_tiles_n = (int)grid.y;
+        grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.xcd_tiles_n);
+        grid.y = 1;
+    }
 #define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \

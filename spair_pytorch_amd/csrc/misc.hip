@@ -128,7 +128,15 @@ __global__ __launch_bounds__(256) void k_prep(PrepTable T) {
         if (e.mode == 0) v = e.src[(size_t)r * e.cols + c];
         else if (e.mode == 1) v = e.src[(size_t)c * e.rows + r];
         else if (e.mode == 2) {
-            const int tap = c / e.cin, ci = c - tap * e.cin, ky = tap / e.k, kx = tap - ky * e.k;
+            int ky, kx, ci;
+            if (e.s > 0) {   // tap-parity K order of gemm16.hip (GemmNT::ktab): 64-column blocks = (parity class, channel block, tap of the class)
+                const int blk = c >> 6, TT = e.T * e.T, nh = e.cin >> 6;
+                const int tq = blk % TT, rr = blk / TT, h = rr % nh, cls = rr / nh;
+                ky = cls / e.s + e.s * (tq / e.T); kx = cls % e.s + e.s * (tq % e.T); ci = h * 64 + (c & 63);
+            } else {
+                const int tap = c / e.cin;
+                ci = c - tap * e.cin; ky = tap / e.k; kx = tap - ky * e.k;
+            }
             v = e.src[(((size_t)r * e.cin + ci) * e.k + ky) * e.k + kx];
         } else {
             const int t = c / e.cout, co = c - t * e.cout, ty = t / e.T, tx = t - ty * e.T;
