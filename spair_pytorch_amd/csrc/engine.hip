@@ -337,7 +337,12 @@ static int side_stream(SideStream*& out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return SPAIR_ERR_LAUNCH;
     if (g_side.s == nullptr || g_side.dev != dev) {
-        if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        // lowest priority: what runs here (weight gradients, KL terms, preparation) has slack, the caller's stream carries the
+        // dependent chain -- when both have workgroups to place, the chain's go first
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = 0;
+        if (getenv("SPAIR_SIDE_PRIO")) prio_least = atoi(getenv("SPAIR_SIDE_PRIO"));
+        if (hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_least) != hipSuccess) return SPAIR_ERR_LAUNCH;
         for (int i = 0; i < 6; ++i)
             if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return SPAIR_ERR_LAUNCH;
         g_side.dev = dev;
