@@ -60,6 +60,26 @@ def cpu_baseline(image_side, strides, batch, steps=2):
                 sample="oracle fwd+bwd+Adam, 128x128, 16x16 grid, batch %d, %d timed steps after 1 warm-up (%.2f s/step)" % (batch, steps, dt))
 
 
+def hbm_copy_rates(dev, mb=1024):
+    """Stream rates of this box (the measured copy peak beside the vendor figure): a 1 GiB device copy counted as
+    read + written bytes, and a fill (writes only)."""
+    n = mb * (1 << 20) // 4
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    a.fill_(1.0)
+
+    def rate(fn, nbytes, reps=10):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    return dict(copy_GBs=rate(lambda: b.copy_(a), 2 * n * 4), fill_GBs=rate(lambda: b.fill_(2.0), n * 4), unit="GB/s", bytes=n * 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +245,7 @@ def main():
                            global_batch=world * B, image=args.image, grid=d.G, parallelism="dp%d" % world),
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
+    out["hbm_measured"] = hbm_copy_rates(dev)      # what this box sustains, beside the vendor 8 TB/s the roofline divides by
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.image, strides, batch=8)
     print(json.dumps(out), flush=True)
