@@ -66,6 +66,21 @@ __device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const Co
 }
 
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+// 16-byte load through a buffer descriptor: an offset past num_records returns zeros, so a masked lane needs no select on the result
+// and -- what matters -- no branch around the load (hipcc turns `ok ? *p : 0` into a conditional load, and a conditional VM op makes
+// every later wait a vmcnt(0)).  The descriptor spans the whole 32-bit offset range; masked lanes pass BUF_OOB.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define BUF_OOB 0xfffffff0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)0xffffff00u, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float bf16_bits_to_float(u16 v) { return __uint_as_float(((unsigned int)v) << 16); }
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));
@@ -158,12 +173,16 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         b_base[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldb;
     }
 
+    const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(A), rsB = buf_rsrc(B);
     uint4 ra[NA], rb[NB];
     const int tap_wraps = ACONV ? ceil_div_dev(BK, g.conv.Cin) : 0;
     const int Klast = g.K - 8;
-    auto load_tiles = [&](int k0) {
+    // (no branch around a load: a conditional VM op makes the pending count unknown and every wait becomes vmcnt(0); tiles past K are
+    //  fetched from clamped addresses and zeroed by selects)
+    auto load_tiles = [&](int k0, uint4 (&ra)[NA], uint4 (&rb)[NB]) {
         const int k = k0 + kq * 8;
         const bool kok = k < g.K;
+        const bool live = k0 < g.K;                      // wave-uniform
         const unsigned kc = (unsigned)min(k, Klast);
         if (ACONV) {
             int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
@@ -183,24 +202,17 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                     ok = ok && in;
                     off = in ? off : 0u;
                 }
-                const uint4 v = *reinterpret_cast<const uint4*>(A + off);
-                ra[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+                ra[i] = buf_load16(rsA, (ok && live) ? off * 2u : BUF_OOB);
             }
-            ctap_advance(g.conv, a_ct, BK, tap_wraps);
+            if (live) ctap_advance(g.conv, a_ct, BK, tap_wraps);
         } else {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const uint4 v = *reinterpret_cast<const uint4*>(A + (a_base[i] + kc));
-                ra[i] = (a_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = buf_load16(rsA, (a_ok[i] && kok) ? (a_base[i] + kc) * 2u : BUF_OOB);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const uint4 v = *reinterpret_cast<const uint4*>(B + (b_base[i] + kc));
-            rb[i] = (b_ok[i] && kok) ? v : make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
         __bf16* As = As0 + buf * BM * LD;
         __bf16* Bs = Bs0 + buf * BN * LD;
 #pragma unroll
@@ -216,15 +228,9 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (g.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) load_tiles((kt + 1) * BK);
-        __builtin_amdgcn_sched_barrier(0);      // loads issued here; nothing that consumes them may move above the MFMAs
-        const __bf16* As = As0 + (kt & 1) * BM * LD;
-        const __bf16* Bs = Bs0 + (kt & 1) * BN * LD;
+    auto mfma_tile = [&](int buf) {
+        const __bf16* As = As0 + buf * BM * LD;
+        const __bf16* Bs = Bs0 + buf * BN * LD;
         const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = (lane >> 4) * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
@@ -239,9 +245,22 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) store_tiles((kt + 1) & 1);   // the other buffer: last read one iteration ago, behind the previous barrier
-        __syncthreads();
+    };
+    load_tiles(0, ra, rb);
+    store_tiles(0, ra, rb);
+    __syncthreads();
+    // (a second register set with the tile after next in flight -- wait vmcnt(8) instead of vmcnt(0) before the LDS writes -- was
+    //  measured: nothing for a lone workgroup, spills at 3 workgroups per CU.  The K step is bound by its LDS read -> MFMA -> LDS write
+    //  sequence, not by the global-load latency.)
+    {
+        for (int kt = 0; kt < nk; ++kt) {
+            load_tiles((kt + 1) * BK, ra, rb);
+            __builtin_amdgcn_sched_barrier(0);      // loads issued here; nothing that consumes them may move above the MFMAs
+            mfma_tile(kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles((kt + 1) & 1, ra, rb);      // the other buffer: last read one iteration ago, behind the previous barrier
+            __syncthreads();
+        }
     }
 
     // epilogue.  The accumulators go through LDS (the operand buffers are free now) so that everything that touches HBM is a
