@@ -673,12 +673,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
         }
     }
     const unsigned b_lastrow = BCONV ? 0u : (unsigned)(g.R - 1) * (unsigned)g_ldb;
+    const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(A), rsB = buf_rsrc(gB);
     auto load_tiles = [&](int r0) {      // every load is issued unconditionally from a clamped address and zeroed by a select
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
+        for (int i = 0; i < NA; ++i) {       // buffer loads: a masked lane goes out of range (zeros), nothing is conditional (see buf_load16)
             const int r = r0 + (tid >> 4) + i * 16;
-            const uint4 v = *reinterpret_cast<const uint4*>(A + min(a_off[i], a_last));
-            ra[i] = (r < r_end && a_mok) ? v : make_uint4(0u, 0u, 0u, 0u);
+            ra[i] = buf_load16(rsA, (r < r_end && a_mok) ? min(a_off[i], a_last) * 2u : BUF_OOB);
             a_off[i] += (unsigned)(BK * g_lda);
         }
 #pragma unroll
@@ -692,9 +692,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             if (!BCONV) off = min(off, b_lastrow + (unsigned)(g_ldb - (B16 ? 8 : 4)));
             if (BCONV && !ok) off = 0u;
             if constexpr (B16) {
-                const u16* Bp = reinterpret_cast<const u16*>(gB);
-                const uint4 v = *reinterpret_cast<const uint4*>(Bp + off + (unsigned)b_tapoff[i][0]);
-                rb16[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+                rb16[i] = buf_load16(rsB, ok ? (off + (unsigned)b_tapoff[i][0]) * 2u : BUF_OOB);
             } else {
                 const float* Bp = gB;
                 float4 v;
