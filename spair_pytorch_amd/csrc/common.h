@@ -66,6 +66,24 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 
+#if defined(__HIPCC__)
+// 16-byte load through a buffer descriptor: an offset past num_records returns zeros, so a masked lane needs no select on the result
+// and -- what matters -- no branch around the load (hipcc turns `ok ? *p : 0` into a conditional load, and a conditional VM op makes
+// every later wait a vmcnt(0)).  The descriptor spans the whole 32-bit offset range; masked lanes pass BUF_OOB.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define BUF_OOB 0xfffffff0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)0xffffff00u, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 // Sum over a 256-thread block (4 waves); result valid in every thread.
 __device__ __forceinline__ float block_reduce_sum_256(float v, float* smem4) {
     v = wave_reduce_sum(v);

@@ -66,21 +66,6 @@ __device__ __forceinline__ uint4 conv_load8(const u16* __restrict__ In, const Co
 }
 
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
-// 16-byte load through a buffer descriptor: an offset past num_records returns zeros, so a masked lane needs no select on the result
-// and -- what matters -- no branch around the load (hipcc turns `ok ? *p : 0` into a conditional load, and a conditional VM op makes
-// every later wait a vmcnt(0)).  The descriptor spans the whole 32-bit offset range; masked lanes pass BUF_OOB.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#define BUF_OOB 0xfffffff0u
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)0xffffff00u, 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 __device__ __forceinline__ float bf16_bits_to_float(u16 v) { return __uint_as_float(((unsigned int)v) << 16); }
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));

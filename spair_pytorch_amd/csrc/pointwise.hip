@@ -31,9 +31,11 @@ struct PwArgs {
     int M, L;
 };
 
-__device__ __forceinline__ uint4 ld16_or_zero(const u16* p, bool ok) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
-    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+// 16 bytes at element offset `off` of a bf16 tensor, zeros when !ok: a buffer load whose masked lanes go out of range (common.h) --
+// written as `ok ? *p : 0` hipcc made every one of these a conditional load behind its own vmcnt(0) (16 serialised round trips
+// for the first tile of a workgroup)
+__device__ __forceinline__ uint4 ld16_or_zero(__amdgpu_buffer_rsrc_t r, size_t off, bool ok) {
+    return buf_load16(r, ok ? (unsigned)(off * 2) : BUF_OOB);
 }
 
 // 8 bf16 of `v` zeroed where the matching bf16 of `m` is not > 0
@@ -61,10 +63,11 @@ __device__ __forceinline__ void pw_layer(const PwArgs& a, __bf16* As, __bf16* Ws
         constexpr int l1 = (l + 1 < PW_MAXL) ? l + 1 : l;      // (never dereferenced past the last layer: `more` is false there)
         const u16* Wn = reinterpret_cast<const u16*>(more ? a.W[l1] : a.W[l]);
         const int wr = more ? a.wrows[l1] : a.wrows[l], wc = more ? a.wcols[l1] : a.wcols[l], lw = more ? a.ldw[l1] : a.ldw[l];
+        const __amdgpu_buffer_rsrc_t rsW = buf_rsrc(Wn);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = s_r0 + i * 16;
-            wq[i] = ld16_or_zero(Wn + (size_t)min(row, wr - 1) * lw + min(s_kc, lw - 8), row < wr && s_kc < wc);
+            wq[i] = ld16_or_zero(rsW, (size_t)min(row, wr - 1) * lw + min(s_kc, lw - 8), row < wr && s_kc < wc);
         }
         if (BWD) {
             const u16* Mk = reinterpret_cast<const u16*>(a.mask[l]);
@@ -156,17 +159,22 @@ __global__ __launch_bounds__(256, 2) void k_pw_stack(PwArgs a) {
     // staging map: 128 rows x 16 chunks of 8 bf16 = 2048 chunks, 8 per thread: chunk f = tid + i*256 -> row f>>4, k-chunk f&15
     const int s_kc = (tid & 15) * 8, s_r0 = tid >> 4;
     {
-        const u16* X = reinterpret_cast<const u16*>(a.X);
-        const u16* W0 = reinterpret_cast<const u16*>(a.W[0]);
+        const __amdgpu_buffer_rsrc_t rsX = buf_rsrc(a.X), rsW0 = buf_rsrc(a.W[0]);
+        uint4 xq[8], wq0[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {       // all sixteen loads in flight before the first LDS write
             const int row = s_r0 + i * 16;
             const int mr = min(m0 + row, a.M - 1);
             const bool okx = (m0 + row) < a.M && s_kc < a.kx;
-            *reinterpret_cast<uint4*>(&As[row * PW_LD + s_kc]) = ld16_or_zero(X + (size_t)mr * a.ldx + min(s_kc, a.ldx - 8), okx);
+            xq[i] = ld16_or_zero(rsX, (size_t)mr * a.ldx + min(s_kc, a.ldx - 8), okx);
             const bool okw = row < a.wrows[0] && s_kc < a.wcols[0];
-            *reinterpret_cast<uint4*>(&Ws[row * PW_LD + s_kc]) =
-                ld16_or_zero(W0 + (size_t)min(row, a.wrows[0] - 1) * a.ldw[0] + min(s_kc, a.ldw[0] - 8), okw);
+            wq0[i] = ld16_or_zero(rsW0, (size_t)min(row, a.wrows[0] - 1) * a.ldw[0] + min(s_kc, a.ldw[0] - 8), okw);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = s_r0 + i * 16;
+            *reinterpret_cast<uint4*>(&As[row * PW_LD + s_kc]) = xq[i];
+            *reinterpret_cast<uint4*>(&Ws[row * PW_LD + s_kc]) = wq0[i];
         }
     }
     const int wrow0 = wave * 32;                 // this wave's 32 rows; all 128 columns
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_stack(PwArgs a) {
 int spair_pw_stack_fwd16(const void* X, const void* const* W, const int* ldw, const int* cout, const float* const* bias, void* const* Y,
                          float* Ylast, int ldlast, int M, int L, hipStream_t s) {
     if (L < 1 || L > PW_MAXL || M <= 0) return SPAIR_ERR_SHAPE;
+    if ((long long)M * PW_N * 2 >= 0xffffff00ll) return SPAIR_ERR_UNSUPPORTED;      // 32-bit byte offsets of the buffer loads
     PwArgs a;
     memset(&a, 0, sizeof(a));
     a.X = X; a.ldx = PW_N; a.kx = PW_N; a.M = M; a.L = L; a.Ylast = Ylast; a.ldlast = ldlast; a.nlast = cout[L - 1];
@@ -201,6 +210,7 @@ int spair_pw_stack_fwd16(const void* X, const void* const* W, const int* ldw, co
 int spair_pw_stack_bwd16(const void* dY, int ldd, int kd, const void* const* Wd, const int* ldw, const int* cout, const void* const* gate,
                          void* const* dX, int M, int L, hipStream_t s) {
     if (L < 1 || L > PW_MAXL || M <= 0 || kd > PW_N || (ldd & 7)) return SPAIR_ERR_SHAPE;
+    if ((long long)M * ldd * 2 >= 0xffffff00ll) return SPAIR_ERR_UNSUPPORTED;         // 32-bit byte offsets of the buffer loads
     PwArgs a;
     memset(&a, 0, sizeof(a));
     a.X = dY; a.ldx = ldd; a.kx = kd; a.M = M; a.L = L;
