@@ -82,6 +82,22 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+// Stores through a descriptor: a masked lane passes BUF_OOB and the range check drops its write -- the store is unconditional for the
+// compiler, so the pending-operation count stays known and a later wait for a LOAD is vmcnt(n), not vmcnt(0) (which on gfx9, one
+// in-order counter for loads and stores, also waits for the acknowledgement of every store before it).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned short bits) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned bits) {
+    __builtin_amdgcn_raw_buffer_store_b32((int)bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned lo, unsigned hi) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{lo, hi}, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, 0);
+}
 #endif
 
 // Sum over a 256-thread block (4 waves); result valid in every thread.
