@@ -224,11 +224,24 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict_
     const int nrow = min(C0_ROWS, Hout - oy0), nin = s * (nrow - 1) + 4;
     const int q = Cout >> 2, groups = 256 / q;
     const int cq = threadIdx.x % q, pg = threadIdx.x / q;
-    for (int i = threadIdx.x; i < nin * Hin; i += 256) {
-        const int ky = i / Hin, xx = i - ky * Hin;
-        const int sy = oy0 * s + ky - pre, sx = xx - pre;
-        const bool in = (unsigned)sy < (unsigned)I && (unsigned)sx < (unsigned)I;
-        xs[i] = in ? x[((size_t)b * I + sy) * I + sx] : 0.f;
+    {   // input rows: eight loads per thread in flight at once, through a buffer descriptor (a pixel of the zero padding goes out of
+        // range and reads 0; written `in ? x[..] : 0` each load was conditional and sat behind its own vmcnt(0): 7 round trips per WG)
+        const __amdgpu_buffer_rsrc_t rsx = buf_rsrc(x + (size_t)b * I * I);
+        const int total = nin * Hin;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 256) {
+            unsigned v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256;
+                const int ky = i / Hin, xx = i - ky * Hin;
+                const int sy = oy0 * s + ky - pre, sx = xx - pre;
+                const bool in = i < total && (unsigned)sy < (unsigned)I && (unsigned)sx < (unsigned)I;
+                v[e] = __builtin_amdgcn_raw_buffer_load_b32(rsx, in ? (sy * I + sx) * 4 : (int)BUF_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (i0 + e * 256 < total) xs[i0 + e * 256] = __uint_as_float(v[e]);
+        }
     }
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 wlo[16], whi[16];             // per tap: channels (0,1) and (2,3) of the quad -- the 64 FMAs of a pixel issue as 32 packed ones
