@@ -646,6 +646,16 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
         const float* pt = g.part + (size_t)tile * (bm * bn) + ml * bn + nl;
         const size_t sstride = (size_t)tiles * (bm * bn);
         int sp = sl;
+        for (; sp + 24 < g.nsplit; sp += 32) {          // four independent 16-byte loads in flight per thread
+            const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
+            const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 8) * sstride);
+            const float4 c = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 16) * sstride);
+            const float4 d = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 24) * sstride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s0.x += c.x; s0.y += c.y; s0.z += c.z; s0.w += c.w;
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        }
         for (; sp + 8 < g.nsplit; sp += 16) {
             const float4 a = *reinterpret_cast<const float4*>(pt + (size_t)sp * sstride);
             const float4 b = *reinterpret_cast<const float4*>(pt + (size_t)(sp + 8) * sstride);
