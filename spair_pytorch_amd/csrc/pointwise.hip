@@ -135,7 +135,7 @@ __device__ __forceinline__ void pw_layer(const PwArgs& a, __bf16* As, __bf16* Ws
     __syncthreads();
     // coalesced pass: (backward) gate by the saved activation's sign, store the layer output, keep it as the next input
     {
-        u16* Y = reinterpret_cast<u16*>(a.Y[l]);
+        const __amdgpu_buffer_rsrc_t rsY = buf_rsrc(a.Y[l]);      // rows past M store out of range: no branch around the store
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = s_r0 + i * 16;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void pw_layer(const PwArgs& a, __bf16* As, __bf16* Ws
                 v = relu_gate8(v, mq[i]);
                 *reinterpret_cast<uint4*>(&As[row * PW_LD + s_kc]) = v;
             }
-            if (m0 + row < a.M) *reinterpret_cast<uint4*>(Y + (size_t)(m0 + row) * PW_N + s_kc) = v;
+            buf_store16(rsY, (m0 + row < a.M) ? (unsigned)(((size_t)(m0 + row) * PW_N + s_kc) * 2) : BUF_OOB, v);
         }
     }
     // (the next iteration's first barrier orders these LDS writes before its MFMA reads)
