@@ -78,6 +78,8 @@ __device__ __forceinline__ void pw_layer(const PwArgs& a, __bf16* As, __bf16* Ws
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);        // the prefetch is ISSUED here: left to itself hipcc sinks these loads to their first use,
+                                              // behind the MFMAs and the second barrier, and the layer waits for them there
     __syncthreads();                          // As / Ws of this layer complete
     f32x4 acc[2][8];
 #pragma unroll
@@ -97,10 +99,10 @@ __device__ __forceinline__ void pw_layer(const PwArgs& a, __bf16* As, __bf16* Ws
             for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();                          // every wave is done reading As / Ws
-    if (more) {
+    // (unconditional on purpose: with the write under `if (more)` LLVM sinks the eight prefetch loads into that block -- behind the
+    //  MFMAs and this barrier -- and the layer then waits a full memory round trip for them; on the last layer the copy is unused)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(&Ws[(s_r0 + i * 16) * PW_LD + s_kc]) = wq[i];
-    }
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(&Ws[(s_r0 + i * 16) * PW_LD + s_kc]) = wq[i];
     // epilogue: C layout -> lane holds column j*16 + (lane&15), rows wrow0 + i*16 + (lane>>4)*4 + r
     const int ccol = lane & 15, crow = (lane >> 4) * 4;
     if (!BWD && !more) {                      // last forward layer: fp32, no relu, straight from the registers
