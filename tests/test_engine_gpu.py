@@ -163,3 +163,35 @@ def test_internal_noise_follows_torch_seed():
     assert lc != la
     eps = m._last["engine"]["noise"]["eps_attr"]
     assert abs(eps.mean().item()) < 0.05 and abs(eps.std().item() - 1.0) < 0.05
+
+
+def test_batch_split_equals_full_batch():
+    """Size-independent property at the bench geometry (128x128, 16x16 grid): samples are independent, so a batch of 32 run as two
+    'ranks' of 16 (world_size = 2: each back-propagates BCE_sum_local + KL_sum_local / (B_local * 2)) must give the full batch's loss
+    and gradient when the two are SUMMED -- the data-parallel contract of ddp.py, checked here without any collective."""
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.models import SPAIR
+    from spair_pytorch_amd.data import scattered_digits
+    I, strides, B = 128, (2, 2, 2, 1, 1, 1), 32
+    cfg.set_grid(I, strides)
+    G = gi.grid_side(I, strides)
+    x = torch.from_numpy(scattered_digits(11, B, I, 11)[0]).cuda()
+    noise = {k: torch.from_numpy(v).cuda() for k, v in gi.make_noise(12, B, G).items()}
+    w = {k: torch.from_numpy(v) for k, v in gi.make_weights(13, 1.0).items()}
+
+    def run(xs, ns, world):
+        m = SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype="bf16").to("cuda")
+        m.load_state_dict(w)
+        m.world_size = world
+        m.zero_grad()
+        loss, recon, z_where, z_pres = m(xs, 3000, noise=ns)
+        loss.backward()
+        return loss.item(), m.flat_gradients().double().clone(), recon
+
+    lf, gf, rf = run(x, noise, 1)
+    h = B // 2
+    la, ga, ra = run(x[:h], {k: v[:h] for k, v in noise.items()}, 2)
+    lb, gb, rb = run(x[h:], {k: v[h:] for k, v in noise.items()}, 2)
+    assert abs((la + lb) - lf) <= 1e-5 * abs(lf)
+    assert ((ga + gb) - gf).norm().item() <= 2e-3 * gf.norm().item()      # bf16 GEMM partial sums are grouped differently
+    assert (torch.cat([ra, rb]) - rf).abs().max().item() == 0.0
