@@ -195,3 +195,38 @@ def test_batch_split_equals_full_batch():
     assert abs((la + lb) - lf) <= 1e-5 * abs(lf)
     assert ((ga + gb) - gf).norm().item() <= 2e-3 * gf.norm().item()      # bf16 GEMM partial sums are grouped differently
     assert (torch.cat([ra, rb]) - rf).abs().max().item() == 0.0
+
+
+def test_full_size_step_is_finite_and_repeatable():
+    """BASELINE configs[1] at full size (B = 256, 128x128): every launch configuration the bench uses (grouped weight gradients, split-K
+    scratch, fused stem partials, XCD-ordered grids) -- the step must be finite, repeat to the bit in the loss, and its first
+    Adam update must lower the loss on the same batch and noise."""
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.models import SPAIR
+    from spair_pytorch_amd.optim import FusedAdam
+    from spair_pytorch_amd.data import scattered_digits
+    I, strides, B = 128, (2, 2, 2, 1, 1, 1), 256
+    cfg.set_grid(I, strides)
+    G = gi.grid_side(I, strides)
+    x = torch.from_numpy(scattered_digits(21, B, I, 11)[0]).cuda()
+    noise = {k: torch.from_numpy(v).cuda() for k, v in gi.make_noise(22, B, G).items()}
+    torch.manual_seed(3)
+    m = SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype="bf16").to("cuda")
+    opt = FusedAdam(m, lr=1e-4)
+
+    def step(update):
+        opt.zero_grad()
+        loss, recon, z_where, z_pres = m(x, 2500, noise=noise)
+        loss.backward()
+        g = m.flat_gradients()
+        assert torch.isfinite(loss).item() and torch.isfinite(g).all().item() and torch.isfinite(recon).all().item()
+        assert z_where.shape == (B, 4, G, G) and z_pres.shape == (B, 1, G, G)
+        if update:
+            opt.step()
+        return loss.item(), g.double().norm().item()
+
+    l0, n0 = step(False)
+    l1, n1 = step(True)
+    assert l0 == l1 and abs(n0 - n1) <= 1e-5 * n0
+    l2, _ = step(False)
+    assert l2 < l1
