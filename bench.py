@@ -99,11 +99,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # SPAIR_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a one-GPU box (all ranks on cuda:0, collectives through gloo)
+    backend = os.environ.get("SPAIR_DIST_BACKEND", "nccl")
+    if backend != "nccl" and torch.cuda.device_count() < world:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from spair_pytorch_amd import _lib as L
     from spair_pytorch_amd import config as cfg
