@@ -83,8 +83,8 @@ def hbm_copy_rates(dev, mb=1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--image", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
