@@ -229,7 +229,7 @@ static Ws carve(const SpairDims& d, void* base) {
     b.Za16 = w.Za16; b.dfeat16 = w.dfeat16;
     w.tn_part = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
-    w.aux = c.take<float>((size_t)d.B * d.I * d.I * 4);
+    w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);

@@ -13,27 +13,8 @@
 //    each sprite gradient is written exactly once, coalesced) and reduces d(z_where, pres, depth).
 // Workgroup -> (sample, tile) mapping is XCD-aware: all tiles of one sample run on one XCD so the
 // sample's sprites (HW * 6.3 KB) are fetched from HBM once and then hit in that XCD's L2.
-#include "cells.h"
-#include "stn_math.h"
-
-#define RT 16            // output tile side
-#define RCH 256          // objects culled per pass (= threads per block)
-
-// (grey, alpha) of texel idx of a sprite row: fp32 pairs, or bf16 pairs in the bf16 training step (the decoder GEMM writes them so)
-template <bool S16>
-__device__ __forceinline__ float2 ld_texel(const float* __restrict__ S, size_t idx) {
-    if constexpr (S16) {
-        const unsigned u = reinterpret_cast<const unsigned*>(S)[idx];
-        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
-    } else {
-        return reinterpret_cast<const float2*>(S)[idx];
-    }
-}
-
-struct Cand {
-    float ax, bx, ay, by, pres, depth;
-    int row;
-};
+#include <stdlib.h>
+#include "render_common.h"
 
 // sigmoid epilogue of the decoder (models.py:485-492): in place logits -> (grey, alpha)
 __global__ __launch_bounds__(256) void k_sprite_act(float* __restrict__ S, int ld, long long total, int per, int CH, float obj_scale,
@@ -49,30 +30,10 @@ __global__ __launch_bounds__(256) void k_sprite_act(float* __restrict__ S, int l
     *p = 1.f / (expf(-t) + 1.f);   // analytical sigmoid (modules.py:186-187)
 }
 
-// Source coordinate from the base (normalised) output coordinate -- the reference's own sequence (affine_grid, then
-// grid_sample's unnormalise).  Forward and backward MUST round identically: the compositing adjoint contains
-// (a*g - pre), which cancels to rounding level where one object dominates a pixel.
-__device__ __forceinline__ float src_from_base(float a, float b, float base, int nsrc, int ac, float& g) {
-    g = a * base + b;
-    return ac ? (g + 1.f) * 0.5f * (float)(nsrc - 1) : ((g + 1.f) * (float)nsrc - 1.f) * 0.5f;
-}
-__device__ __forceinline__ float src_of(float a, float b, int j, int nout, int nsrc, int ac) {
-    float g;
-    return src_from_base(a, b, stn_base(j, nout, ac), nsrc, ac, g);
-}
-// src_of() is affine in the output index: src_of(j) = c0 + j*slope.  The slope is formed analytically
-// (a difference of two src_of values would cancel ~5 digits).
-__device__ __forceinline__ void src_affine(float a, float b, int nout, int nsrc, int ac, float& c0, float& slope) {
-    const float bstep = ac ? (nout > 1 ? 2.f / (float)(nout - 1) : 0.f) : 2.f / (float)nout;
-    const float cm = ac ? 0.5f * (float)(nsrc - 1) : 0.5f * (float)nsrc;
-    slope = a * bstep * cm;
-    c0 = src_of(a, b, 0, nout, nsrc, ac);
-}
-
 template <bool S16>
 __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
-                                                    const float* __restrict__ x, float* __restrict__ recon, float4* __restrict__ aux,
+                                                    const float* __restrict__ x, float* __restrict__ recon, float2* __restrict__ aux,
                                                     float* __restrict__ bce_partial, int B, int HW, int I, int P, int ac) {
     __shared__ Cand cand[RCH];
     __shared__ unsigned short wlist[4][RCH];     // per wave (= a 16 x 4 pixel strip of the tile): the candidates that reach its rows
@@ -202,7 +163,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
         bce = -(xv * fmaxf(logf(r), -100.f) + (1.f - xv) * fmaxf(logf(1.f - r), -100.f));
         if (aux) {
             const float gr = (pre >= 0.f && pre <= 1.f) ? (r - xv) / fmaxf(r * (1.f - r), 1e-12f) : 0.f;
-            aux[pi] = make_float4(gr, invD, pre, 0.f);
+            aux[pi] = make_float2(gr * invD, pre);        // (dBCE/dpre / D, pre)
         }
     }
     bce = block_reduce_sum_256(bce, red);
@@ -244,7 +205,7 @@ __device__ __forceinline__ int rb_sweeps(int TU, int TV) {
 template <bool S16>
 __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                      const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
-                                                     const float4* __restrict__ aux, const float* __restrict__ gloss,
+                                                     const float2* __restrict__ aux, const float* __restrict__ gloss,
                                                      float* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
                                                      float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int P, int ac,
                                                      float obj_scale, float alpha_scale, int g_bf16) {
@@ -263,7 +224,7 @@ __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
     const int r = k * B + b;
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
-    const float4* auxb = aux + (size_t)b * I * I;
+    const float2* auxb = aux + (size_t)b * I * I;
     const float mult = ac ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
     // The object's geometry is the same for every thread, and gfx9 has no scalar float ALU: computed by all four waves it is ~300
     // VALU instructions per wave and object in a kernel that is VALU-issue bound.  Wave 0 computes it while the others already
@@ -354,14 +315,14 @@ __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
                 px = PX0 + (xi << wsh) + lx;
                 py = cy0 + yi * RPI + ly;
             };
-            float4 avn = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 avn = make_float2(0.f, 0.f);
             if (wave < nj) {
                 int px, py;
                 pixel_of(wave, px, py);
                 avn = auxb[min(py, cy1) * I + min(px, PX1)];
             }
             for (int j = wave; j < nj; j += RB_WAVES) {
-                const float4 av = avn;                                   // (dBCE/dpre, 1/D, pre, -)
+                const float2 av = avn;                                   // (dBCE/dpre / D, pre)
                 int px, py;
                 {
                     pixel_of(min(j + RB_WAVES, nj - 1), px, py);
@@ -381,11 +342,11 @@ __global__ __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
                 const float aT = t0.y * wx0 + t1.y * wx1, aB = t2.y * wx0 + t3.y * wx1;
                 const float mT = t0.z * wx0 + t1.z * wx1, mB = t2.z * wx0 + t3.z * wx1;
                 const float g = gT * wy0 + gB * wy1, a = (aT * wy0 + aB * wy1) * pr, m = mT * wy0 + mB * wy1;
-                const float go = inside ? av.x * gl * av.y : 0.f;       // dBCE/dpre / D
+                const float go = inside ? av.x * gl : 0.f;              // dBCE/dpre / D
                 const float Dm = m + 1e-9f;
                 const float d_g = go * a * Dm;
                 const float d_a = go * g * Dm;                           // wrt (alpha*pres)
-                const float d_m = go * (a * g - av.z);
+                const float d_m = go * (a * g - av.y);
                 float* q = pb + ((py - cy0) * pw + (px - PX0)) * 3;
                 q[0] = d_g; q[1] = d_a; q[2] = d_m;
                 if (!(sx >= oxl && sx < oxh && sy >= oyl && sy < oyh)) continue;
@@ -474,17 +435,32 @@ int render_num_blocks(int B, int I) {
     return B * t * t;
 }
 
-// s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type
+int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
+                float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, int s_bf16, hipStream_t s);
+int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
+                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
+                int ac, float obj_scale, float alpha_scale, hipStream_t s);
+// SPAIR_RENDER_V1=1 forces the first-generation kernels (A/B timing only)
+static bool render_force_v1() {
+    static const int v = getenv("SPAIR_RENDER_V1") ? atoi(getenv("SPAIR_RENDER_V1")) : 0;
+    return v != 0;
+}
+
+// s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type.  aux: B*I*I float2 (dBCE/dpre / D, pre).
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
                float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if (B <= 0 || HW <= 0 || I <= 0 || (ld_s & 1)) return SPAIR_ERR_SHAPE;
+    if (!render_force_v1()) {
+        const int rc = render_fwd2(S, ld_s, nbox, pres, depth, ld_pd, x, recon, aux, bce_partial, B, HW, I, P, ac, s_bf16, s);
+        if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
+    }
     if (s_bf16)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(render_num_blocks(B, I)), dim3(256), 0, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,
-                           reinterpret_cast<float4*>(aux), bce_partial, B, HW, I, P, ac);
+                           reinterpret_cast<float2*>(aux), bce_partial, B, HW, I, P, ac);
     else
     hipLaunchKernelGGL(k_render_fwd<false>, dim3(render_num_blocks(B, I)), dim3(256), 0, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,
-                       reinterpret_cast<float4*>(aux), bce_partial, B, HW, I, P, ac);
+                       reinterpret_cast<float2*>(aux), bce_partial, B, HW, I, P, ac);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
@@ -499,11 +475,11 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
     if (lds > 65536) return SPAIR_ERR_UNSUPPORTED;
     if (s_bf16)
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
-                           reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
+                           reinterpret_cast<const float2*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
                            alpha_scale, g_bf16);
     else
     hipLaunchKernelGGL(k_render_bwd<false>, dim3(B, HW), dim3(RB_T), lds, s, S, ld_s, nbox, pres, depth, ld_pd,
-                       reinterpret_cast<const float4*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
+                       reinterpret_cast<const float2*>(aux), gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac, obj_scale,
                        alpha_scale, g_bf16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;

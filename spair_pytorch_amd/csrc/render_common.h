@@ -1,0 +1,45 @@
+// Device helpers shared by the renderer kernels (render.hip: first-generation kernels, kept as the generic fallback and the fp32
+// backward; render2.hip: LDS-staged forward and the one-wave-per-object backward of the bf16 step).
+#pragma once
+#include "cells.h"
+#include "stn_math.h"
+
+#define RT 16            // output tile side
+#define RCH 256          // objects culled per pass (= threads per block)
+
+// (grey, alpha) of texel idx of a sprite row: fp32 pairs, or bf16 pairs in the bf16 training step (the decoder GEMM writes them so)
+template <bool S16>
+__device__ __forceinline__ float2 ld_texel(const float* __restrict__ S, size_t idx) {
+    if constexpr (S16) {
+        const unsigned u = reinterpret_cast<const unsigned*>(S)[idx];
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    } else {
+        return reinterpret_cast<const float2*>(S)[idx];
+    }
+}
+
+struct Cand {
+    float ax, bx, ay, by, pres, depth;
+    int row;
+};
+
+// Source coordinate from the base (normalised) output coordinate -- the reference's own sequence (affine_grid, then
+// grid_sample's unnormalise).  Forward and backward MUST round identically: the compositing adjoint contains
+// (a*g - pre), which cancels to rounding level where one object dominates a pixel.
+__device__ __forceinline__ float src_from_base(float a, float b, float base, int nsrc, int ac, float& g) {
+    g = a * base + b;
+    return ac ? (g + 1.f) * 0.5f * (float)(nsrc - 1) : ((g + 1.f) * (float)nsrc - 1.f) * 0.5f;
+}
+__device__ __forceinline__ float src_of(float a, float b, int j, int nout, int nsrc, int ac) {
+    float g;
+    return src_from_base(a, b, stn_base(j, nout, ac), nsrc, ac, g);
+}
+// src_of() is affine in the output index: src_of(j) = c0 + j*slope.  The slope is formed analytically
+// (a difference of two src_of values would cancel ~5 digits).
+__device__ __forceinline__ void src_affine(float a, float b, int nout, int nsrc, int ac, float& c0, float& slope) {
+    const float bstep = ac ? (nout > 1 ? 2.f / (float)(nout - 1) : 0.f) : 2.f / (float)nout;
+    const float cm = ac ? 0.5f * (float)(nsrc - 1) : 0.5f * (float)nsrc;
+    slope = a * bstep * cm;
+    c0 = src_of(a, b, 0, nout, nsrc, ac);
+}
+
