@@ -470,6 +470,11 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
                int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if ((ld_s & 1) || (ld_g & 1)) return SPAIR_ERR_ALIGN;
+    if (g_bf16 && s_bf16 && !render_force_v1()) {   // the bf16 step: one wave per object, sampling transposed on the matrix cores
+        const int rc = render_bwd2(S, ld_s, nbox, pres, depth, ld_pd, aux, gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac,
+                                   obj_scale, alpha_scale, s);
+        if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
+    }
     if (I > RB_CAP || (long long)I * I > 0x7fffffffLL / 4 || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)(P + 2) * (P + 2) * 4 + 3 * RB_CAP + I) * sizeof(float);
     if (lds > 65536) return SPAIR_ERR_UNSUPPORTED;

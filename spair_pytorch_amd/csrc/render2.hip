@@ -314,3 +314,309 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// BACKWARD  k_render_bwd2 (bf16 step: bf16 sprites in, bf16 d-logits out) -- one WAVE per object, nothing synchronised across
+// waves, no atomics:
+//   * the sprite goes to LDS once as a zero-bordered image of 8-byte texels {(grey, alpha) bf16 pair, importance fp32};
+//   * pass A walks the object's pixel footprint in chunks of <= 16 rows x 32 columns (32 or 16 pixels x 2 or 4 rows per
+//     iteration): re-samples the sprite (taps through per-column / per-row tables), forms the three per-pixel adjoints
+//     (wrt interpolated grey, alpha * pres, importance), accumulates d z_where in registers and leaves the adjoints in LDS
+//     as bf16 tiles [channel][pixel row][pixel column];
+//   * pass B is the transpose of the bilinear sampling, which is SEPARABLE:  dS_c = Wy^T . adj_c . Wx  with the hat weights
+//     Wx[px][u] = max(0, 1 - |sx(px) - u|), Wy[py][v] likewise.  Both products run on the matrix cores (fp32 accumulate):
+//     T_c = adj_c . Wx per chunk (v_mfma_f32_16x16x32_bf16, K = 32 pixel columns), then dS_c += Wy^T . T_c
+//     (v_mfma_f32_16x16x16_bf16, K = the chunk's 16 pixel rows) with the accumulator tile of T_c re-used directly as the B
+//     operand: its rows ARE the K index in that instruction's operand layout (row 4q + j of lane group q, element j).
+//     The first-generation kernel spent ~2/3 of its instructions in the per-texel gather loops this replaces.
+//   * epilogue: sigmoid' and the logit scales per texel, d pres / d depth reductions, d-logits staged through LDS and written
+//     as whole 16-byte pieces (the sprite gradient is contiguous).
+// The adjoints and the hat weights are rounded to bf16 for the matrix products (the d-logits are stored as bf16 anyway);
+// z_where gradients are fp32 throughout (pass A), pres / depth gradients come from the texel sums of the products.
+// ---------------------------------------------------------------------------------------------
+#define RB2_ADJ_LD 40                      // bf16 elements per adjoint tile row (80 B: conflict-free ds_read_b128 fragments)
+#define RB2_ROWS 16                        // pixel rows per chunk
+#define RB2_BIG 1.0e9f                      // source coordinate of a padding pixel: every hat weight 0
+#define RB2_ADJ_BYTES (3 * RB2_ROWS * RB2_ADJ_LD * 2)
+
+__host__ __device__ inline int rb2_lds_bytes(int P) { return (P + 2) * (P + 2) * 8 + RB2_ADJ_BYTES + 32 * 16 + RB2_ROWS * 16 + 32 * 4 + RB2_ROWS * 4; }
+
+// first / last index in [0, I-1] whose source coordinate lies in (-1, P); exact w.r.t. the forward's own coordinate formula
+template <int AC>
+__device__ __forceinline__ void rb2_range(float a, float b, float c0, float inv, int I, int P, int& lo, int& hi) {
+    float g;
+    lo = max((int)floorf((-1.f - c0) * inv) - 1, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (lo < I && src_from_base(a, b, stn_base(lo, I, AC), P, AC, g) <= -1.f) ++lo;
+    hi = min((int)ceilf(((float)P - c0) * inv) + 1, I - 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (hi >= 0 && src_from_base(a, b, stn_base(hi, I, AC), P, AC, g) >= (float)P) --hi;
+}
+
+__device__ __forceinline__ float rb2_hat(float s, float c) { return fmaxf(1.f - fabsf(s - c), 0.f); }
+// 8 hat weights max(0, 1 - |s_j - c|) as a bf16 MFMA fragment
+__device__ __forceinline__ bf16x8 rb2_hat8(const float4 s0, const float4 s1, float c) {
+    bf16x8 w;
+    w[0] = (__bf16)rb2_hat(s0.x, c); w[1] = (__bf16)rb2_hat(s0.y, c); w[2] = (__bf16)rb2_hat(s0.z, c); w[3] = (__bf16)rb2_hat(s0.w, c);
+    w[4] = (__bf16)rb2_hat(s1.x, c); w[5] = (__bf16)rb2_hat(s1.y, c); w[6] = (__bf16)rb2_hat(s1.z, c); w[7] = (__bf16)rb2_hat(s1.w, c);
+    return w;
+}
+__device__ __forceinline__ bf16x4 rb2_hat4(const float4 s, float c) {
+    bf16x4 w;
+    w[0] = (__bf16)rb2_hat(s.x, c); w[1] = (__bf16)rb2_hat(s.y, c); w[2] = (__bf16)rb2_hat(s.z, c); w[3] = (__bf16)rb2_hat(s.w, c);
+    return w;
+}
+typedef short rb2_s16x4 __attribute__((ext_vector_type(4)));
+
+struct Rb2Taps { uint2 q00, q01, q10, q11; };
+__device__ __forceinline__ Rb2Taps rb2_ld_taps(const char* tp, int rowb) {
+    Rb2Taps t;
+    t.q00 = *reinterpret_cast<const uint2*>(tp); t.q01 = *reinterpret_cast<const uint2*>(tp + 8);
+    t.q10 = *reinterpret_cast<const uint2*>(tp + rowb); t.q11 = *reinterpret_cast<const uint2*>(tp + rowb + 8);
+    return t;
+}
+
+template <int PT, int AC>
+__global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+                                                    const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
+                                                    const float2* __restrict__ aux, const float* __restrict__ gloss,
+                                                    __bf16* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
+                                                    float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int Prt,
+                                                    float obj_scale, float alpha_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    const int P = PT ? PT : Prt;
+    const int PS = P + 2;
+    const int lane = threadIdx.x;
+    uint2* Ssh = reinterpret_cast<uint2*>(smb);                                   // [PS][PS] {(grey, alpha) bf16 pair, importance}
+    char* adjT = smb + PS * PS * 8;                                               // [3][RB2_ROWS][RB2_ADJ_LD] bf16
+    float4* xt = reinterpret_cast<float4*>(adjT + RB2_ADJ_BYTES);                 // [32] {tap byte offset, frac, grid coord, -}
+    float4* yt = xt + 32;                                                         // [RB2_ROWS]
+    float* sxs = reinterpret_cast<float*>(yt + RB2_ROWS);                         // [32] source x of the chunk's pixel columns
+    float* sys = sxs + 32;                                                        // [RB2_ROWS]
+    // (sample, object): consecutive workgroup ids walk the samples, so with B % 8 == 0 every object of sample b lands on XCD b % 8
+    const int b = blockIdx.x, k = blockIdx.y;
+    const int r = k * B + b;
+    const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
+    const float gl = *gloss;
+    const float2* auxb = aux + (size_t)b * I * I;
+    const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
+    const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
+    const float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
+    const float mult = AC ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
+    float sx0, sxa, sy0, sya;
+    src_affine(ax, bx, I, P, AC, sx0, sxa);
+    src_affine(ay, by, I, P, AC, sy0, sya);
+    int PX0, PX1, PY0, PY1;
+    rb2_range<AC>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, P, PX0, PX1);
+    rb2_range<AC>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, P, PY0, PY1);
+    PX0 = __builtin_amdgcn_readfirstlane(PX0); PX1 = __builtin_amdgcn_readfirstlane(PX1);
+    PY0 = __builtin_amdgcn_readfirstlane(PY0); PY1 = __builtin_amdgcn_readfirstlane(PY1);
+    // ---- sprite -> LDS (zero border), adjoint tiles zeroed once (later chunks leave finite values under zero weights)
+    {
+        const char* Sr = reinterpret_cast<const char*>(S) + (size_t)r * ld_s * 2;
+        const int ppr = P >> 2, npieces = P * ppr;                      // 16-byte pieces (4 texels) per row / per sprite
+        for (int p0 = 0; p0 < npieces; p0 += 256) {
+            uint4 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const uint4*>(Sr + (size_t)min(p0 + 64 * i + lane, npieces - 1) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = p0 + 64 * i + lane;
+                if (p < npieces) {
+                    const int v = p / ppr, u0 = (p - v * ppr) * 4;
+                    uint2* d = Ssh + (v + 1) * PS + u0 + 1;
+                    const unsigned ga[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        d[t] = make_uint2(ga[t], __float_as_uint(fmaxf(__uint_as_float(ga[t] & 0xffff0000u) * pd, 0.01f)));
+                }
+            }
+        }
+        for (int e = lane; e < PS; e += 64) {
+            Ssh[e] = make_uint2(0u, 0u);
+            Ssh[(PS - 1) * PS + e] = make_uint2(0u, 0u);
+            Ssh[e * PS] = make_uint2(0u, 0u);
+            Ssh[e * PS + PS - 1] = make_uint2(0u, 0u);
+        }
+        for (int e = lane; e < RB2_ADJ_BYTES / 16; e += 64) reinterpret_cast<uint4*>(adjT)[e] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int pw = PX1 - PX0 + 1;
+    const int wsh = pw <= 16 ? 4 : 5, W = 1 << wsh, RPI = 64 >> wsh;
+    const int col = lane & (W - 1), rsub = lane >> wsh;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rowb = PS * 8;
+    float g_tx = 0.f, g_ty = 0.f, g_xs = 0.f, g_ys = 0.f;
+    f32x4 dS[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dS[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int py0 = PY0; py0 <= PY1; py0 += RB2_ROWS) {
+        const int nrw = min(RB2_ROWS, PY1 - py0 + 1);
+        if (lane < RB2_ROWS) {
+            const int yy = py0 + lane;
+            float gn = 0.f, s = RB2_BIG, f = 0.f;
+            int off = 0;
+            if (yy <= PY1) {
+                s = src_from_base(ay, by, stn_base(yy, I, AC), P, AC, gn);
+                const float f0 = fminf(fmaxf(floorf(s), -1.f), (float)(P - 1));
+                f = s - f0;
+                off = ((int)f0 + 1) * rowb;
+            }
+            yt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
+            sys[lane] = s;
+        }
+        f32x4 T[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) T[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int px0 = PX0; px0 <= PX1; px0 += W) {
+            if (lane < 32) {
+                const int xx = px0 + lane;
+                float gn = 0.f, s = RB2_BIG, f = 0.f;
+                int off = 0;
+                if (lane < W && xx <= PX1) {
+                    s = src_from_base(ax, bx, stn_base(xx, I, AC), P, AC, gn);
+                    const float f0 = fminf(fmaxf(floorf(s), -1.f), (float)(P - 1));
+                    f = s - f0;
+                    off = ((int)f0 + 1) * 8;
+                }
+                xt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
+                sxs[lane] = s;
+            }
+            // ---- pass A: adjoints of the chunk's pixels; the LDS reads of iteration it + 1 are issued before the arithmetic of iteration it
+            const int nit = (nrw + RPI - 1) >> (6 - wsh);
+            const float4 xe = xt[col];
+            const int xx = min(px0 + col, PX1);
+            const bool xvalid = px0 + col <= PX1;
+            const char* xb = smb + __float_as_int(xe.x);
+            const float fx = xe.y;
+            float2 avn = auxb[(size_t)min(py0 + rsub, PY1) * I + xx];
+            float4 yen = yt[rsub];
+            Rb2Taps tn = rb2_ld_taps(xb + __float_as_int(yen.x), rowb);
+            float4 yenn = yt[min(rsub + RPI, RB2_ROWS - 1)];
+            for (int it = 0; it < nit; ++it) {
+                const int row = it * RPI + rsub;
+                const float2 av = avn;
+                const float4 ye = yen;
+                const Rb2Taps t = tn;
+                avn = auxb[(size_t)min(py0 + row + RPI, PY1) * I + xx];
+                yen = yenn;
+                tn = rb2_ld_taps(xb + __float_as_int(yen.x), rowb);
+                yenn = yt[min(row + 2 * RPI, RB2_ROWS - 1)];
+                const bool valid = xvalid && (py0 + row <= PY1);
+                const float fy = ye.y;
+                const float g00 = __uint_as_float(t.q00.x << 16), a00 = __uint_as_float(t.q00.x & 0xffff0000u), m00 = __uint_as_float(t.q00.y);
+                const float g01 = __uint_as_float(t.q01.x << 16), a01 = __uint_as_float(t.q01.x & 0xffff0000u), m01 = __uint_as_float(t.q01.y);
+                const float g10 = __uint_as_float(t.q10.x << 16), a10 = __uint_as_float(t.q10.x & 0xffff0000u), m10 = __uint_as_float(t.q10.y);
+                const float g11 = __uint_as_float(t.q11.x << 16), a11 = __uint_as_float(t.q11.x & 0xffff0000u), m11 = __uint_as_float(t.q11.y);
+                // separable bilinear: x first, then y; x-derivative = (right - left), y-derivative = (bottom - top)
+                const float dTg = g01 - g00, dBg = g11 - g10, dTa = a01 - a00, dBa = a11 - a10, dTm = m01 - m00, dBm = m11 - m10;
+                const float hTg = fmaf(fx, dTg, g00), hBg = fmaf(fx, dBg, g10), hTa = fmaf(fx, dTa, a00), hBa = fmaf(fx, dBa, a10);
+                const float hTm = fmaf(fx, dTm, m00), hBm = fmaf(fx, dBm, m10);
+                const float eg = hBg - hTg, ea = hBa - hTa, em = hBm - hTm;
+                const float g = fmaf(fy, eg, hTg), a = fmaf(fy, ea, hTa) * pr, m = fmaf(fy, em, hTm);
+                const float dgx = fmaf(fy, dBg - dTg, dTg), dax = fmaf(fy, dBa - dTa, dTa), dmx = fmaf(fy, dBm - dTm, dTm);
+                const float go = valid ? av.x * gl : 0.f;             // dBCE/dpre / D
+                const float tt = go * (m + 1e-9f);
+                const float d_g = tt * a, d_a = tt * g;                // wrt grey, wrt (alpha * pres)
+                const float d_m = go * (a * g - av.y);
+                const float dap = d_a * pr;
+                const float g_sx = d_g * dgx + dap * dax + d_m * dmx;  // d / d(source x), pixel units
+                const float g_sy = d_g * eg + dap * ea + d_m * em;
+                g_tx += g_sx; g_xs = fmaf(g_sx, xe.z, g_xs);           // scaled by cgx / cgy after the loops
+                g_ty += g_sy; g_ys = fmaf(g_sy, ye.z, g_ys);
+                __bf16* q = reinterpret_cast<__bf16*>(adjT) + row * RB2_ADJ_LD + col;
+                q[0] = (__bf16)d_g;
+                q[RB2_ROWS * RB2_ADJ_LD] = (__bf16)d_a;
+                q[2 * RB2_ROWS * RB2_ADJ_LD] = (__bf16)d_m;
+            }
+            // ---- pass B, first product: T_c[py][u] += sum_px adj_c[py][px] * Wx[px][u]
+            const float4 s0 = *reinterpret_cast<const float4*>(sxs + 8 * fq), s1 = *reinterpret_cast<const float4*>(sxs + 8 * fq + 4);
+            const bf16x8 wx0 = rb2_hat8(s0, s1, (float)fr), wx1 = rb2_hat8(s0, s1, (float)(16 + fr));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(adjT + c * (RB2_ROWS * RB2_ADJ_LD * 2) + fr * (RB2_ADJ_LD * 2) + fq * 16);
+                T[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx0, T[c][0], 0, 0, 0);
+                T[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx1, T[c][1], 0, 0, 0);
+            }
+        }
+        // ---- second product: dS_c[v][u] += sum_py Wy[py][v] * T_c[py][u].  T's accumulator tile is the B operand as it stands
+        // (16x16x16: lane group q holds K = 4q .. 4q+3 = the tile rows of its four registers); Wy^T is built on the fly.
+        const float4 sq = *reinterpret_cast<const float4*>(sys + 4 * fq);
+        const bf16x4 wy0 = rb2_hat4(sq, (float)fr), wy1 = rb2_hat4(sq, (float)(16 + fr));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bf16x4 tb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tb[i] = (__bf16)T[c][nt][i];
+                dS[c][0][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy0), __builtin_bit_cast(rb2_s16x4, tb), dS[c][0][nt], 0, 0, 0);
+                dS[c][1][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy1), __builtin_bit_cast(rb2_s16x4, tb), dS[c][1][nt], 0, 0, 0);
+            }
+    }
+    // ---- epilogue: per texel sigmoid' and logit scales (models.py:485-492), d pres / d depth; d-logits staged in LDS (over the adjoint tiles)
+    float g_pr = 0.f, g_s2a = 0.f;
+    unsigned* ost = reinterpret_cast<unsigned*>(adjT);
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 16 * vt + 4 * fq + i, u = 16 * nt + fr;
+                if (v < P && u < P) {
+                    const uint2 sv = Ssh[(v + 1) * PS + u + 1];
+                    const float sg = __uint_as_float(sv.x << 16), sa = __uint_as_float(sv.x & 0xffff0000u);
+                    const float s0_ = dS[0][vt][nt][i], s1_ = dS[1][vt][nt][i], s2_ = dS[2][vt][nt][i];
+                    const bool act = (sa * pd) >= 0.01f;                 // importance not clamped
+                    const float s2a = act ? s2_ * sa : 0.f;
+                    g_pr = fmaf(s1_, sa, g_pr);
+                    g_s2a += s2a;
+                    const float ox = s0_ * sg * (1.f - sg) * obj_scale;
+                    const float oy = (s1_ * pr + (act ? s2_ * pd : 0.f)) * sa * (1.f - sa) * alpha_scale;
+                    __bf16 ob[2] = {(__bf16)ox, (__bf16)oy};
+                    ost[v * P + u] = *reinterpret_cast<unsigned*>(ob);
+                }
+            }
+    {
+        char* dst = reinterpret_cast<char*>(dlogits + (size_t)r * ld_g);
+        const int npieces = (P * P * 4) >> 4;
+        for (int p = lane; p < npieces; p += 64) *reinterpret_cast<uint4*>(dst + (size_t)p * 16) = reinterpret_cast<const uint4*>(ost)[p];
+    }
+    const float cgx = -mult * ax, cgy = -mult * ay;                  // d(source coord)/d(t) incl. the unnormalisation
+    g_tx = wave_reduce_sum(g_tx) * cgx; g_ty = wave_reduce_sum(g_ty) * cgy;
+    g_xs = wave_reduce_sum(g_xs) * cgx; g_ys = wave_reduce_sum(g_ys) * cgy;
+    g_pr = wave_reduce_sum(g_pr); g_s2a = wave_reduce_sum(g_s2a);
+    if (lane == 0) {
+        *reinterpret_cast<float4*>(dnbox + (size_t)r * 4) = make_float4(2.f * g_tx, 2.f * g_ty, g_xs, g_ys);
+        dpres[r] = g_pr + g_s2a * dp;
+        ddepth[r] = g_s2a * pr;
+    }
+}
+
+// bf16 sprites in, bf16 d-logits out.  SPAIR_ERR_UNSUPPORTED: the caller falls back to the first-generation kernel.
+int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
+                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
+                int ac, float obj_scale, float alpha_scale, hipStream_t s) {
+    if ((P & 3) || P > 32 || P < 4 || (ld_s & 7) || (ld_g & 7) || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15)) return SPAIR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)rb2_lds_bytes(P);
+    if (lds > 64 * 1024 || (size_t)P * P * 4 > RB2_ADJ_BYTES) return SPAIR_ERR_UNSUPPORTED;
+    const dim3 grid(B, HW), block(64);
+#define RB2_LAUNCH(PT_, AC_)                                                                                                              \
+    hipLaunchKernelGGL((k_render_bwd2<PT_, AC_>), grid, block, lds, s, S, ld_s, nbox, pres, depth, ld_pd, reinterpret_cast<const float2*>(aux), \
+                       gloss, reinterpret_cast<__bf16*>(dlogits), dnbox, dpres, ddepth, ld_g, B, HW, I, P, obj_scale, alpha_scale)
+    if (P == 28 && !ac) RB2_LAUNCH(28, 0);
+    else if (ac) RB2_LAUNCH(0, 1);
+    else RB2_LAUNCH(0, 0);
+#undef RB2_LAUNCH
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
