@@ -17,6 +17,7 @@
 //
 // The forward math per (pixel, object) is the same as in k_render_fwd (render.hip) up to the order of one multiplication
 // (alpha * pres is applied to the interpolated alpha instead of to each tap).
+#include <stdlib.h>
 #include "render_common.h"
 
 #ifndef RF_TC
@@ -51,6 +52,14 @@ __device__ __forceinline__ bool rf_axis(float s, int P, int& i0, float& w0, floa
     if (!cov) { a = 0.f; b = 0.f; i = 0; }
     i0 = i; w0 = a; w1 = b;
     return cov;
+}
+
+// stn_base() for the renderer kernels: with an image side that is a power of two (IP2) the division by n is a multiplication by the
+// exactly representable 1/n -- bit-identical to stn_base(), ~10 instructions cheaper per call.
+template <int AC, int IP2>
+__device__ __forceinline__ float rf_base(int j, int n, float inv_n) {
+    if constexpr (IP2 && !AC) return (2.f * (float)j + 1.f) * inv_n - 1.f;
+    else return stn_base(j, n, AC);
 }
 
 __device__ __forceinline__ int rf_scan_incl(int v, int lane) {
@@ -336,23 +345,27 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 // ---------------------------------------------------------------------------------------------
 #define RB2_ADJ_LD 40                      // bf16 elements per adjoint tile row (80 B: conflict-free ds_read_b128 fragments)
 #define RB2_ROWS 16                        // pixel rows per chunk
+#ifndef RB2_WAVES_PER_SIMD
+#define RB2_WAVES_PER_SIMD 4            // register budget: 128 (VGPR + AGPR)
+#endif
 #define RB2_BIG 1.0e9f                      // source coordinate of a padding pixel: every hat weight 0
 #define RB2_ADJ_BYTES (3 * RB2_ROWS * RB2_ADJ_LD * 2)
 
 __host__ __device__ inline int rb2_lds_bytes(int P) { return (P + 2) * (P + 2) * 8 + RB2_ADJ_BYTES + 32 * 16 + RB2_ROWS * 16 + 32 * 4 + RB2_ROWS * 4; }
 
 // first / last index in [0, I-1] whose source coordinate lies in (-1, P); exact w.r.t. the forward's own coordinate formula
-template <int AC>
-__device__ __forceinline__ void rb2_range(float a, float b, float c0, float inv, int I, int P, int& lo, int& hi) {
+template <int AC, int IP2>
+__device__ __forceinline__ void rb2_range(float a, float b, float c0, float inv, int I, float inv_I, int P, int& lo, int& hi) {
     float g;
-    lo = max((int)floorf((-1.f - c0) * inv) - 1, 0);
+    // src(j) ~ c0 + j / inv: the boundary index is within one of the estimate, two exact tests settle it
+    lo = max((int)floorf((-1.f - c0) * inv), 0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (lo < I && src_from_base(a, b, stn_base(lo, I, AC), P, AC, g) <= -1.f) ++lo;
-    hi = min((int)ceilf(((float)P - c0) * inv) + 1, I - 1);
+    for (int t = 0; t < 2; ++t)
+        if (lo < I && src_from_base(a, b, rf_base<AC, IP2>(lo, I, inv_I), P, AC, g) <= -1.f) ++lo;
+    hi = min((int)ceilf(((float)P - c0) * inv), I - 1);
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (hi >= 0 && src_from_base(a, b, stn_base(hi, I, AC), P, AC, g) >= (float)P) --hi;
+    for (int t = 0; t < 2; ++t)
+        if (hi >= 0 && src_from_base(a, b, rf_base<AC, IP2>(hi, I, inv_I), P, AC, g) >= (float)P) --hi;
 }
 
 __device__ __forceinline__ float rb2_hat(float s, float c) { return fmaxf(1.f - fabsf(s - c), 0.f); }
@@ -378,8 +391,8 @@ __device__ __forceinline__ Rb2Taps rb2_ld_taps(const char* tp, int rowb) {
     return t;
 }
 
-template <int PT, int AC>
-__global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+template <int PT, int AC, int IP2>
+__global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
                                                     const float2* __restrict__ aux, const float* __restrict__ gloss,
                                                     __bf16* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
@@ -409,8 +422,9 @@ __global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S,
     src_affine(ax, bx, I, P, AC, sx0, sxa);
     src_affine(ay, by, I, P, AC, sy0, sya);
     int PX0, PX1, PY0, PY1;
-    rb2_range<AC>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, P, PX0, PX1);
-    rb2_range<AC>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, P, PY0, PY1);
+    const float inv_I = 1.f / (float)I;
+    rb2_range<AC, IP2>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, inv_I, P, PX0, PX1);
+    rb2_range<AC, IP2>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, inv_I, P, PY0, PY1);
     PX0 = __builtin_amdgcn_readfirstlane(PX0); PX1 = __builtin_amdgcn_readfirstlane(PX1);
     PY0 = __builtin_amdgcn_readfirstlane(PY0); PY1 = __builtin_amdgcn_readfirstlane(PY1);
     // ---- sprite -> LDS (zero border), adjoint tiles zeroed once (later chunks leave finite values under zero weights)
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S,
             float gn = 0.f, s = RB2_BIG, f = 0.f;
             int off = 0;
             if (yy <= PY1) {
-                s = src_from_base(ay, by, stn_base(yy, I, AC), P, AC, gn);
+                s = src_from_base(ay, by, rf_base<AC, IP2>(yy, I, inv_I), P, AC, gn);
                 const float f0 = fminf(fmaxf(floorf(s), -1.f), (float)(P - 1));
                 f = s - f0;
                 off = ((int)f0 + 1) * rowb;
@@ -470,18 +484,13 @@ __global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S,
             yt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
             sys[lane] = s;
         }
-        f32x4 T[3][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) T[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int px0 = PX0; px0 <= PX1; px0 += W) {
             if (lane < 32) {
                 const int xx = px0 + lane;
                 float gn = 0.f, s = RB2_BIG, f = 0.f;
                 int off = 0;
                 if (lane < W && xx <= PX1) {
-                    s = src_from_base(ax, bx, stn_base(xx, I, AC), P, AC, gn);
+                    s = src_from_base(ax, bx, rf_base<AC, IP2>(xx, I, inv_I), P, AC, gn);
                     const float f0 = fminf(fmaxf(floorf(s), -1.f), (float)(P - 1));
                     f = s - f0;
                     off = ((int)f0 + 1) * 8;
@@ -489,28 +498,31 @@ __global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S,
                 xt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
                 sxs[lane] = s;
             }
-            // ---- pass A: adjoints of the chunk's pixels; the LDS reads of iteration it + 1 are issued before the arithmetic of iteration it
+            // ---- pass A: adjoints of the chunk's pixels, two row groups per trip (A / B register sets: the loads of one are issued
+            // before the arithmetic of the other)
             const int nit = (nrw + RPI - 1) >> (6 - wsh);
             const float4 xe = xt[col];
             const int xx = min(px0 + col, PX1);
             const bool xvalid = px0 + col <= PX1;
-            const char* xb = smb + __float_as_int(xe.x);
+            const unsigned xb = (unsigned)__float_as_int(xe.x);
             const float fx = xe.y;
-            float2 avn = auxb[(size_t)min(py0 + rsub, PY1) * I + xx];
-            float4 yen = yt[rsub];
-            Rb2Taps tn = rb2_ld_taps(xb + __float_as_int(yen.x), rowb);
-            float4 yenn = yt[min(rsub + RPI, RB2_ROWS - 1)];
-            for (int it = 0; it < nit; ++it) {
+            const float2* ap = auxb + xx;
+            const unsigned adj0 = (unsigned)(adjT - smb) + (unsigned)(rsub * RB2_ADJ_LD + col) * 2u;
+            const unsigned yt0 = (unsigned)(reinterpret_cast<char*>(yt) - smb) + (unsigned)rsub * 16u;
+            struct PxIn { float2 av; float4 ye; Rb2Taps t; };
+            auto load_px = [&](int it) {
+                PxIn in;
+                const int row = min(it * RPI + rsub, RB2_ROWS - 1);
+                in.av = ap[(unsigned)(min(py0 + row, PY1) * I)];
+                in.ye = *reinterpret_cast<const float4*>(smb + yt0 + (unsigned)(min(it * RPI, RB2_ROWS - RPI) * 16));
+                in.t = rb2_ld_taps(smb + (xb + (unsigned)__float_as_int(in.ye.x)), rowb);
+                return in;
+            };
+            auto do_px = [&](const PxIn& in, int it) {
                 const int row = it * RPI + rsub;
-                const float2 av = avn;
-                const float4 ye = yen;
-                const Rb2Taps t = tn;
-                avn = auxb[(size_t)min(py0 + row + RPI, PY1) * I + xx];
-                yen = yenn;
-                tn = rb2_ld_taps(xb + __float_as_int(yen.x), rowb);
-                yenn = yt[min(row + 2 * RPI, RB2_ROWS - 1)];
                 const bool valid = xvalid && (py0 + row <= PY1);
-                const float fy = ye.y;
+                const Rb2Taps& t = in.t;
+                const float fy = in.ye.y;
                 const float g00 = __uint_as_float(t.q00.x << 16), a00 = __uint_as_float(t.q00.x & 0xffff0000u), m00 = __uint_as_float(t.q00.y);
                 const float g01 = __uint_as_float(t.q01.x << 16), a01 = __uint_as_float(t.q01.x & 0xffff0000u), m01 = __uint_as_float(t.q01.y);
                 const float g10 = __uint_as_float(t.q10.x << 16), a10 = __uint_as_float(t.q10.x & 0xffff0000u), m10 = __uint_as_float(t.q10.y);
@@ -522,44 +534,50 @@ __global__ __launch_bounds__(64) void k_render_bwd2(const float* __restrict__ S,
                 const float eg = hBg - hTg, ea = hBa - hTa, em = hBm - hTm;
                 const float g = fmaf(fy, eg, hTg), a = fmaf(fy, ea, hTa) * pr, m = fmaf(fy, em, hTm);
                 const float dgx = fmaf(fy, dBg - dTg, dTg), dax = fmaf(fy, dBa - dTa, dTa), dmx = fmaf(fy, dBm - dTm, dTm);
-                const float go = valid ? av.x * gl : 0.f;             // dBCE/dpre / D
+                const float go = valid ? in.av.x * gl : 0.f;          // dBCE/dpre / D
                 const float tt = go * (m + 1e-9f);
                 const float d_g = tt * a, d_a = tt * g;                // wrt grey, wrt (alpha * pres)
-                const float d_m = go * (a * g - av.y);
+                const float d_m = go * (a * g - in.av.y);
                 const float dap = d_a * pr;
                 const float g_sx = d_g * dgx + dap * dax + d_m * dmx;  // d / d(source x), pixel units
                 const float g_sy = d_g * eg + dap * ea + d_m * em;
                 g_tx += g_sx; g_xs = fmaf(g_sx, xe.z, g_xs);           // scaled by cgx / cgy after the loops
-                g_ty += g_sy; g_ys = fmaf(g_sy, ye.z, g_ys);
-                __bf16* q = reinterpret_cast<__bf16*>(adjT) + row * RB2_ADJ_LD + col;
-                q[0] = (__bf16)d_g;
-                q[RB2_ROWS * RB2_ADJ_LD] = (__bf16)d_a;
-                q[2 * RB2_ROWS * RB2_ADJ_LD] = (__bf16)d_m;
+                g_ty += g_sy; g_ys = fmaf(g_sy, in.ye.z, g_ys);
+                char* q = smb + adj0 + (unsigned)(it * RPI * RB2_ADJ_LD * 2);
+                *reinterpret_cast<__bf16*>(q) = (__bf16)d_g;
+                *reinterpret_cast<__bf16*>(q + RB2_ROWS * RB2_ADJ_LD * 2) = (__bf16)d_a;
+                *reinterpret_cast<__bf16*>(q + 2 * RB2_ROWS * RB2_ADJ_LD * 2) = (__bf16)d_m;
+            };
+            PxIn inA = load_px(0);
+            for (int it = 0; it < nit; it += 2) {
+                const PxIn inB = load_px(it + 1);
+                do_px(inA, it);
+                inA = load_px(it + 2);
+                do_px(inB, it + 1);
             }
-            // ---- pass B, first product: T_c[py][u] += sum_px adj_c[py][px] * Wx[px][u]
+            // ---- pass B.  First product: T_c[py][u] = sum_px adj_c[py][px] * Wx[px][u] for this chunk (fresh accumulators: nothing of
+            // pass B is live during pass A).  Second product right behind it: dS_c[v][u] += sum_py Wy[py][v] * T_c[py][u].  T's
+            // accumulator tile is the B operand of v_mfma_f32_16x16x16_bf16 as it stands (lane group q holds K = 4q .. 4q+3 = the tile
+            // rows of its four registers); Wy^T is built on the fly in the same order.
             const float4 s0 = *reinterpret_cast<const float4*>(sxs + 8 * fq), s1 = *reinterpret_cast<const float4*>(sxs + 8 * fq + 4);
             const bf16x8 wx0 = rb2_hat8(s0, s1, (float)fr), wx1 = rb2_hat8(s0, s1, (float)(16 + fr));
+            const float4 sq = *reinterpret_cast<const float4*>(sys + 4 * fq);
+            const bf16x4 wy0 = rb2_hat4(sq, (float)fr), wy1 = rb2_hat4(sq, (float)(16 + fr));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(adjT + c * (RB2_ROWS * RB2_ADJ_LD * 2) + fr * (RB2_ADJ_LD * 2) + fq * 16);
-                T[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx0, T[c][0], 0, 0, 0);
-                T[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx1, T[c][1], 0, 0, 0);
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 T0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx0, z, 0, 0, 0);
+                const f32x4 T1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wx1, z, 0, 0, 0);
+                bf16x4 tb0, tb1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { tb0[i] = (__bf16)T0[i]; tb1[i] = (__bf16)T1[i]; }
+                dS[c][0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy0), __builtin_bit_cast(rb2_s16x4, tb0), dS[c][0][0], 0, 0, 0);
+                dS[c][1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy1), __builtin_bit_cast(rb2_s16x4, tb0), dS[c][1][0], 0, 0, 0);
+                dS[c][0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy0), __builtin_bit_cast(rb2_s16x4, tb1), dS[c][0][1], 0, 0, 0);
+                dS[c][1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy1), __builtin_bit_cast(rb2_s16x4, tb1), dS[c][1][1], 0, 0, 0);
             }
         }
-        // ---- second product: dS_c[v][u] += sum_py Wy[py][v] * T_c[py][u].  T's accumulator tile is the B operand as it stands
-        // (16x16x16: lane group q holds K = 4q .. 4q+3 = the tile rows of its four registers); Wy^T is built on the fly.
-        const float4 sq = *reinterpret_cast<const float4*>(sys + 4 * fq);
-        const bf16x4 wy0 = rb2_hat4(sq, (float)fr), wy1 = rb2_hat4(sq, (float)(16 + fr));
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                bf16x4 tb;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tb[i] = (__bf16)T[c][nt][i];
-                dS[c][0][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy0), __builtin_bit_cast(rb2_s16x4, tb), dS[c][0][nt], 0, 0, 0);
-                dS[c][1][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy1), __builtin_bit_cast(rb2_s16x4, tb), dS[c][1][nt], 0, 0, 0);
-            }
     }
     // ---- epilogue: per texel sigmoid' and logit scales (models.py:485-492), d pres / d depth; d-logits staged in LDS (over the adjoint tiles)
     float g_pr = 0.f, g_s2a = 0.f;
@@ -607,15 +625,18 @@ int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
                 int ac, float obj_scale, float alpha_scale, hipStream_t s) {
     if ((P & 3) || P > 32 || P < 4 || (ld_s & 7) || (ld_g & 7) || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15)) return SPAIR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)rb2_lds_bytes(P);
+    static const int extra_lds = getenv("SPAIR_RB2_EXTRA_LDS") ? atoi(getenv("SPAIR_RB2_EXTRA_LDS")) : 0;     // occupancy experiments only
+    const size_t lds = (size_t)rb2_lds_bytes(P) + extra_lds;
     if (lds > 64 * 1024 || (size_t)P * P * 4 > RB2_ADJ_BYTES) return SPAIR_ERR_UNSUPPORTED;
     const dim3 grid(B, HW), block(64);
-#define RB2_LAUNCH(PT_, AC_)                                                                                                              \
-    hipLaunchKernelGGL((k_render_bwd2<PT_, AC_>), grid, block, lds, s, S, ld_s, nbox, pres, depth, ld_pd, reinterpret_cast<const float2*>(aux), \
-                       gloss, reinterpret_cast<__bf16*>(dlogits), dnbox, dpres, ddepth, ld_g, B, HW, I, P, obj_scale, alpha_scale)
-    if (P == 28 && !ac) RB2_LAUNCH(28, 0);
-    else if (ac) RB2_LAUNCH(0, 1);
-    else RB2_LAUNCH(0, 0);
+#define RB2_LAUNCH(PT_, AC_, IP2_)                                                                                                        \
+    hipLaunchKernelGGL((k_render_bwd2<PT_, AC_, IP2_>), grid, block, lds, s, S, ld_s, nbox, pres, depth, ld_pd,                            \
+                       reinterpret_cast<const float2*>(aux), gloss, reinterpret_cast<__bf16*>(dlogits), dnbox, dpres, ddepth, ld_g, B, HW, I, \
+                       P, obj_scale, alpha_scale)
+    const bool ip2 = (I & (I - 1)) == 0;
+    if (P == 28 && !ac && ip2) RB2_LAUNCH(28, 0, 1);
+    else if (ac) RB2_LAUNCH(0, 1, 0);
+    else RB2_LAUNCH(0, 0, 0);
 #undef RB2_LAUNCH
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
