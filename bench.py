@@ -29,20 +29,22 @@ SLOT_NAMES = ["prep", "backbone_fwd", "cells_fwd", "decoder_fwd", "count_kl", "r
               "dec_out_wgrad", "dec_out_dgrad"]
 
 
-def cpu_baseline(image_side, strides, batch, steps=2):
-    """The CPU oracle (oracle/spair_oracle.py, a restatement of the reference's PyTorch path) timed on this
-    box's host cores on a bounded sample of the same workload.  Reported baseline only -- never the product."""
+# Speed of the oracle relative to the REAL reference, measured in the build container (8 vCPU, torch 2.10 CPU) where both run:
+# reference 55.7 img/s (48x48, 6x6 grid, B=16) and 3.9 img/s (128x128, 16x16 grid, B=16) -- BASELINE.md section 2 -- against the oracle's
+# 64.7 and 4.55 img/s on the same machine and thread count.  The reference itself never travels to the GPU box.
+ORACLE_OVER_REFERENCE = {"config1_48px_b16": 64.7 / 55.7, "config2_128px_b16": 4.55 / 3.9}
+
+
+def _oracle_steps(image_side, strides, batch, kmax, steps, threads):
     from oracle import spair_oracle as orc
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import golden_inputs as gi
     from spair_pytorch_amd.data import scattered_digits
-    ncpu = min(16, len(os.sched_getaffinity(0)))       # the GPU box's CPU share (16 per GPU)
-    torch.set_num_threads(ncpu)
+    torch.set_num_threads(threads)
     cfg = orc.OracleConfig(image_shape=(1, image_side, image_side), conv_strides=tuple(strides))
     p = {k: torch.from_numpy(v).clone().requires_grad_(not k.startswith("attn.")) for k, v in gi.make_weights(3, 1.0).items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
-    x = torch.from_numpy(scattered_digits(99, batch, image_side, 11)[0])
+    x = torch.from_numpy(scattered_digits(99, batch, image_side, kmax)[0])
     G = gi.grid_side(image_side, strides)
     times = []
     for it in range(steps + 1):
@@ -56,8 +58,30 @@ def cpu_baseline(image_side, strides, batch, steps=2):
             orc.adam_step({k: t for k, t in p.items()}, {k: t.grad for k, t in p.items()}, m, v2, it + 1)
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / steps
-    return dict(value=batch / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="oracle fwd+bwd+Adam, 128x128, 16x16 grid, batch %d, %d timed steps after 1 warm-up (%.2f s/step)" % (batch, steps, dt))
+    return dict(images_per_sec=batch / dt, s_per_step=dt, batch=batch, timed_steps=steps, threads=torch.get_num_threads())
+
+
+def cpu_baseline(strides):
+    """The CPU oracle (oracle/spair_oracle.py, a restatement of the reference's PyTorch path, pinned to it by tests/golden) timed on
+    this box's host cores, as SURVEY 8(d) / BASELINE.md section 3 prescribe: BASELINE config 1 (48x48, 6x6 grid, B=16) and config 2's
+    geometry (128x128, 16x16 grid) at B=16, 5 timed steps after 1 warm-up on all cores, plus 1-core runs (bounded: the 128x128
+    1-core run uses B=4 and 2 timed steps).  Reported baseline only -- never the product, never the optimisation target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    ncpu = min(16, len(os.sched_getaffinity(0)))       # the GPU box's CPU share (16 per GPU)
+    runs = {
+        "config1_48px_b16": _oracle_steps(48, strides, 16, 3, 5, ncpu),
+        "config1_48px_b16_1core": _oracle_steps(48, strides, 16, 3, 5, 1),
+        "config2_128px_b16": _oracle_steps(128, strides, 16, 11, 5, ncpu),
+        "config2_128px_b4_1core": _oracle_steps(128, strides, 4, 11, 2, 1),
+    }
+    main = runs["config2_128px_b16"]
+    ratio = {k: ORACLE_OVER_REFERENCE[k] for k in ORACLE_OVER_REFERENCE}
+    return dict(value=main["images_per_sec"], unit="images/sec", cores=main["threads"], kind="port",
+                sample="oracle fwd+bwd+Adam on the bench workload's geometry (128x128, 16x16 grid), batch 16, 5 timed steps after 1 warm-up "
+                       "(%.2f s/step) on %d threads; nproc=%d" % (main["s_per_step"], main["threads"], len(os.sched_getaffinity(0))),
+                runs=runs, ratio_to_reference=ratio,
+                ratio_note="oracle img/s divided by the real reference's img/s, both measured in the build container (8 vCPU); "
+                           "divide a `runs` figure by it to estimate the reference on this box")
 
 
 def hbm_copy_rates(dev, mb=1024):
@@ -89,6 +113,10 @@ def main():
     ap.add_argument("--image", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-step", type=int, default=2000, help="global_step of the first timed step (count-prior / wheel schedules)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="BASELINE configs[4]: after the main measurement, time the step at global_step in {0,2000,4000,6000,7000,8000,10000}")
+    ap.add_argument("--sweep-steps", type=int, default=15)
     ap.add_argument("--prof-every", type=int, default=4, help="record the per-kernel HIP event pairs on every n-th timed step")
     ap.add_argument("--prof-mask", type=lambda v: int(v, 0), default=-1, help="bit mask of the engine's event-pair slots to record (-1 = all)")
     args = ap.parse_args()
@@ -130,14 +158,16 @@ def main():
     B = args.batch
     x = torch.from_numpy(scattered_digits(1234 + rank, B, args.image, 11)[0]).to(dev)   # resident in HBM
     torch.manual_seed(7 + rank)                            # noise seed, per rank
-    gstep = [2000]
+    gstep = [args.global_step]
+    last = {}
 
     def step():
         opt.zero_grad()
         loss, recon, z_where, z_pres = model(x, gstep[0])
+        last["z_pres"] = z_pres
         loss.backward()
         if world > 1:
-            ddp.allreduce_gradients(model.flat_gradients())
+            ddp.allreduce_gradients(model)       # three buckets behind the backward's readiness events, on a communication stream
         opt.step()
         gstep[0] += 1
         return loss
@@ -244,17 +274,46 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     roof = dict(kernels[dominant], kernel=dominant) if dominant else None
 
+    if args.image == 128 and B == 256 and d.G == 16:
+        which = "BASELINE configs[1]" if world == 1 else "BASELINE configs[2] (configs[1] per GPU, DDP over %d GPUs)" % world
+    elif args.image == 256 and B == 64 and d.G == 32:
+        which = "BASELINE configs[3] (STN gather stress)"
+    else:
+        which = "custom (not a BASELINE config)"
+    workload = ("%s: %dx%d synthetic scattered digits (<=11), %dx%d grid, batch %d/GPU, fwd+bwd+Adam, global_step %d+ (wheel %s)"
+                % (which, args.image, args.image, d.G, d.G, B, args.global_step, "off" if args.global_step >= 1000 else "on"))
     out = dict(metric="SPAIR train images/sec + ELBO, 128x128 scattered-MNIST, batch 256", value=world * B * K / dt, unit="images/sec",
                n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=dt / K * 1e3, higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(workload="BASELINE configs[1]: 128x128 synthetic scattered digits (<=11), 16x16 grid, batch %d/GPU, "
-                                    "fwd+bwd+Adam, global_step>=2000 (wheel off)" % B,
-                           global_batch=world * B, image=args.image, grid=d.G, parallelism="dp%d" % world),
+               config=dict(workload=workload, global_batch=world * B, image=args.image, grid=d.G, global_step=args.global_step,
+                           parallelism="dp%d" % world),
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
+    if args.sweep and world == 1:
+        # BASELINE configs[4] on one GPU: the count-prior schedule (config.py:65-69, models.py:186-188) changes z_pres and with it the
+        # renderer's active-cell density; same model state, only global_step differs between the points
+        from spair_pytorch_amd.models import step_scalars
+        sweep = []
+        snap = (model.flat_parameters().clone(), opt.state_dict())
+        snap = (snap[0], {k: (v.clone() if torch.is_tensor(v) else v) for k, v in snap[1].items()})
+        for gs in (0, 2000, 4000, 6000, 7000, 8000, 10000):
+            model.flat_parameters().copy_(snap[0])         # every point starts from the same model and optimizer state
+            opt.load_state_dict(snap[1])
+            gstep[0] = gs
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.sweep_steps):
+                step()
+            torch.cuda.synchronize()
+            ms_s = (time.perf_counter() - t1) / args.sweep_steps * 1e3
+            st_ = step_scalars(gs, B)
+            sweep.append(dict(global_step=gs, count_prior_prob=float(st_.count_prior_prob), wheel=float(st_.wheel), ms_per_step=ms_s,
+                              images_per_sec=B / ms_s * 1e3, mean_z_pres=float(last["z_pres"].mean().item())))
+        out["sweep"] = sweep
     out["hbm_measured"] = hbm_copy_rates(dev)      # what this box sustains, beside the vendor 8 TB/s the roofline divides by
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.image, strides, batch=8)
+        out["cpu_baseline"] = cpu_baseline(strides)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -70,6 +70,15 @@ int spair_forward(const SpairDims* d, const SpairStep* st, const float* params, 
 int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x,
                    const float* eps_box, const float* eps_attr, const float* eps_depth, const float* u_pres,
                    void* workspace, const float* grad_loss, float* grads, void* stream);
+/* Data-parallel hook (the reference is single-device, train.py:27-30): the backward completes the gradients in three
+ * contiguous ranges of `grads` -- [0] decoder, [1] box/encoder/z/obj nets, [2] edge element + backbone, in that order.
+ * spair_grad_buckets returns the ranges (element offsets); spair_backward_ev is spair_backward that additionally records the
+ * caller-created hipEvent_t ev_* (null = skip) when the corresponding range is final, so its all-reduce can overlap the rest. */
+int spair_grad_buckets(const SpairDims* d, int64_t* lo3, int64_t* hi3);
+int spair_backward_ev(const SpairDims* d, const SpairStep* st, const float* params, const float* x,
+                      const float* eps_box, const float* eps_attr, const float* eps_depth, const float* u_pres,
+                      void* workspace, const float* grad_loss, float* grads, void* stream,
+                      void* ev_decoder, void* ev_cells, void* ev_backbone);
 /* torch.optim.Adam(lr) defaults (train.py:44) on flat buffers, one launch. */
 int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                float beta1, float beta2, float eps, int step, void* stream);
@@ -152,8 +161,8 @@ int spair_stn_glimpse_bwd(const float* x, const float* nbox, int B, const float*
                           float* dnbox, int R, int C, int I, int P, int align_corners, void* stream);
 /* renderer: inverse STN + importance-weighted composite + BCE (models.py:485-547) */
 int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
-                     const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P,
-                     int align_corners, void* stream);
+                     const float* x, float* recon, float* aux /* B*I*I float2: (dBCE/dpre / D, pre) */, float* bce_partial,
+                     int B, int HW, int C, int I, int P, int align_corners, void* stream);
 int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                      const float* aux, const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth,
                      int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);

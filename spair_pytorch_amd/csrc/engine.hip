@@ -1003,9 +1003,37 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     return spair_gemm_tn16_impl(g, false, true, c.s);      // A and B both bf16 rows
 }
 
+// Gradient readiness: the backward finishes the three parameter groups in this order -- decoder, per-cell nets, then the backbone together
+// with the edge element -- and each group is one contiguous range of the flat gradient buffer (spair_grad_buckets).  ev[i] (a caller-created
+// hipEvent_t, or null) is recorded on whichever internal stream completes group i, so a data-parallel caller can start that range's
+// all-reduce on its own stream while the remaining backward kernels run.
+extern "C" int spair_grad_buckets(const SpairDims* d, int64_t* lo3, int64_t* hi3) {
+    if (!d || !lo3 || !hi3) return SPAIR_ERR_SHAPE;
+    const ParamLayout P = make_param_layout(*d);
+    lo3[0] = P.lin[LIN_DEC0].w; hi3[0] = P.attn_gamma;        // decoder (first ready)
+    lo3[1] = P.lin[LIN_BOX0].w; hi3[1] = P.lin[LIN_DEC0].w;   // box / encoder / z / obj nets
+    lo3[2] = 0; hi3[2] = P.lin[LIN_BOX0].w;                   // edge element + backbone (last)
+    return SPAIR_OK;
+}
+
+static int record_ready(void* ev, hipStream_t s) {
+    if (ev && hipEventRecord((hipEvent_t)ev, s) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    return SPAIR_OK;
+}
+
+extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
+                                 const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace,
+                                 const float* grad_loss, float* grads, void* stream, void* ev_decoder, void* ev_cells, void* ev_backbone);
+
 extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
                               const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace,
                               const float* grad_loss, float* grads, void* stream) {
+    return spair_backward_ev(d, st, params, x, eps_box, eps_attr, eps_depth, u_pres, workspace, grad_loss, grads, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const float* params, const float* x, const float* eps_box,
+                                 const float* eps_attr, const float* eps_depth, const float* u_pres, void* workspace,
+                                 const float* grad_loss, float* grads, void* stream, void* ev_decoder, void* ev_cells, void* ev_backbone) {
     Ctx c;
     TRY(make_ctx(c, d, st, params, x, eps_box, eps_attr, eps_depth, u_pres, workspace, stream));
     if (!grad_loss || !grads) return SPAIR_ERR_SHAPE;
@@ -1041,6 +1069,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
         TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
         TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
+        TRY(record_ready(ev_decoder, c.s));
         if (side) { c.s = main_s; c.tn_scratch = nullptr; }
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
@@ -1050,6 +1079,7 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
         TRY(bwd_lin(c, LIN_DEC1, SP_DEC_H2, c.w.dHd2, SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 0, N, c.w.Hd1, SP_DEC_H1));
         TRY(wgrad_lin(c, LIN_DEC0, c.w.dHd1, SP_DEC_H1, c.w.Za, L.ld_rec, grads, N));
         TRY(bwd_lin(c, LIN_DEC0, SP_DEC_H1, c.w.dHd1, SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, nullptr, 0));
+        TRY(record_ready(ev_decoder, c.s));
     }
     // per-cell chain, reverse wavefront order
     const int ps_cells = prof_begin(PS_CELLS_BWD, c.s);
@@ -1112,12 +1142,14 @@ extern "C" int spair_backward(const SpairDims* d, const SpairStep* st, const flo
     TRY(wgrad_lin(c, LIN_OBJ2, P.dOo, L.ld_oo, P.Ho2, SP_LDH, grads, N));
     }
     prof_end(ps_wg, c.s);
+    TRY(record_ready(ev_cells, c.s));
     if (side) {
         if (hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
         c.s = main_s;
     }
     { ProfScope ps(PS_BACKBONE_BWD, c.s); TRY(backbone_bwd(c, grads)); }
     if (side && hipStreamWaitEvent(main_s, side->ev[3], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // join
+    TRY(record_ready(ev_backbone, main_s));
     return SPAIR_OK;
 }
 

@@ -103,6 +103,10 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, x, step, noise):
         loss_terms, recon, z_where, z_pres = model._run_forward(x, step, noise, train=True)
         ctx.model, ctx.x, ctx.step, ctx.noise = model, x, step, noise
+        # the saved activations live in the engine's workspace, not in autograd: remember WHICH forward filled it (and keep the
+        # engine alive), so a backward through a workspace that a later forward has overwritten raises instead of being silently wrong
+        ctx.engine = model._last["engine"]
+        ctx.generation = ctx.engine["generation"]
         ctx.mark_non_differentiable(recon, z_where, z_pres)
         ctx.set_materialize_grads(False)     # otherwise autograd zero-fills a gradient for each non-differentiable output (17 MB per step)
         model._loss_terms = loss_terms
@@ -112,7 +116,11 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, g_loss, g_recon, g_zw, g_zp):
         if g_loss is None:
             return None, None, None, None, None
-        ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float())
+        if ctx.engine["generation"] != ctx.generation:
+            raise L.SpairHipError(
+                "backward() of a SPAIR forward whose saved activations were overwritten by a later forward of the same batch size "
+                "(the engine keeps ONE set of activations per batch size; call backward before the next forward of that size)")
+        ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float(), ctx.engine)
         return None, None, None, None, None      # the parameter gradients went straight into the flat buffer
 
 
@@ -135,6 +143,8 @@ class SPAIR(nn.Module):
         self._flat = None
         self._flat_grad = None
         self._engines = {}
+        self.max_engines = 2         # workspaces kept alive (one per batch size, least recently used dropped): train + eval / last partial batch
+        self._grad_buckets = None    # set by spair_pytorch_amd.ddp.attach: readiness events for the overlapped all-reduce
         self._anchor = None
         self._loss_terms = None
         self.dist_param, self.dist = {}, {}
@@ -274,11 +284,15 @@ class SPAIR(nn.Module):
                                       (batch, self.image_shape, self.backbone.topology))
             G, A = d.G, d.A
             dev = self.device
-            e = dict(dims=d,
+            e = dict(dims=d, generation=0,
                      workspace=torch.zeros(nbytes, dtype=torch.uint8, device=dev),   # zero-initialised ONCE
                      noise=dict(eps_box=torch.empty(batch, 4, G, G, device=dev), eps_attr=torch.empty(batch, A, G, G, device=dev),
                                 eps_depth=torch.empty(batch, 1, G, G, device=dev), u_pres=torch.empty(batch, 1, G, G, device=dev)))
-            self._engines = {batch: e}   # one live workspace (they are GBs at B=256)
+            while len(self._engines) >= max(1, self.max_engines):      # workspaces are GBs at B=256: keep the most recent few
+                self._engines.pop(next(iter(self._engines)))
+        else:
+            self._engines.pop(batch)
+        self._engines[batch] = e         # most recently used last
         return e
 
     def _draw_noise(self, e):
@@ -300,6 +314,7 @@ class SPAIR(nn.Module):
         st = step_scalars(step, B, self.world_size, train)
         if noise.get('_seed') is not None:
             st.draw_noise, st.noise_seed = 1, int(noise['_seed'])
+        e["generation"] += 1              # whatever this workspace held for an earlier forward is gone now
         self._last = dict(engine=e, st=st)
         L.check(L.lib().spair_forward(ctypes.byref(d), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
                                       L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),
@@ -307,13 +322,18 @@ class SPAIR(nn.Module):
                                       L.stream()), "spair_forward")
         return loss_terms, recon, z_where, z_pres
 
-    def _run_backward(self, x, step, noise, g_loss):
-        e = self._engine(x.shape[0])
+    def _run_backward(self, x, step, noise, g_loss, e=None):
+        e = e if e is not None else self._engine(x.shape[0])
         st = step_scalars(step, x.shape[0], self.world_size, True)
         self._bind_grads()
-        L.check(L.lib().spair_backward(ctypes.byref(e['dims']), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
-                                       L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),
-                                       L.ptr(e['workspace']), L.ptr(g_loss), L.ptr(self._flat_grad), L.stream()), "spair_backward")
+        gb = self._grad_buckets
+        ev = gb.handles() if gb is not None else [ctypes.c_void_p(0)] * 3
+        L.check(L.lib().spair_backward_ev(ctypes.byref(e['dims']), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
+                                          L.ptr(noise['eps_attr']), L.ptr(noise['eps_depth']), L.ptr(noise['u_pres']),
+                                          L.ptr(e['workspace']), L.ptr(g_loss), L.ptr(self._flat_grad), L.stream(), ev[0], ev[1], ev[2]),
+                "spair_backward")
+        if gb is not None:
+            gb.pending = True             # ddp.allreduce_gradients(model) consumes the three events
 
     # ---- public API ------------------------------------------------------------------------------------
     def forward(self, x, global_step=0, noise=None):

@@ -16,8 +16,16 @@ class FusedAdam:
     def _state(self):
         flat = self.model.flat_parameters()
         if self._state_for != flat.data_ptr():
+            # (re)flattened parameters (first use, model.to(), load_state_dict(assign=True)): the moments follow the buffer -- copied when
+            # the layout is unchanged, so that step_count and the bias correction stay consistent with them
+            old_m, old_v = getattr(self, "exp_avg", None), getattr(self, "exp_avg_sq", None)
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
+            if old_m is not None and old_m.numel() == flat.numel():
+                self.exp_avg.copy_(old_m.to(flat.device))
+                self.exp_avg_sq.copy_(old_v.to(flat.device))
+            elif old_m is not None:
+                self.step_count = 0
             self._state_for = flat.data_ptr()
         return flat
 
@@ -34,6 +42,7 @@ class FusedAdam:
                 "spair_adam")
 
     def state_dict(self):
+        self._state()
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps)
 
     def load_state_dict(self, sd):
@@ -41,3 +50,6 @@ class FusedAdam:
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lr = float(sd.get("lr", self.lr))
+        self.betas = tuple(sd.get("betas", self.betas))
+        self.eps = float(sd.get("eps", self.eps))

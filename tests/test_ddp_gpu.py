@@ -1,0 +1,78 @@
+"""Two real processes (gloo, both on the one GPU of the box) run the HIP step on the two halves of a golden batch with the bucketed,
+overlapped gradient all-reduce of spair_pytorch_amd.ddp; the reduced gradients, the global loss terms and the Adam update must equal
+the single-process step on the whole batch.  The N = 8 RCCL run itself is the driver's (bench.py --gpus N)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from helpers import load_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_two_ranks_overlapped_allreduce_equals_global_batch(tmp_path, dtype, tol):
+    name = "c1_b8_step1001"
+    out = str(tmp_path / "rank0.npz")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPAIR_DIST_BACKEND="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out, name, dtype], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    r = np.load(out)
+
+    # single process, whole batch, same weights / image / noise
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.models import SPAIR
+    from spair_pytorch_amd.optim import FusedAdam
+    z, case = load_case(name)
+    cfg.set_grid(case["I"], case["strides"])
+    m = SPAIR([1, case["I"], case["I"]], None, torch.device("cuda"), compute_dtype=dtype).to("cuda")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gi.make_weights(case["wseed"], case["wscale"]).items()})
+    opt = FusedAdam(m, lr=1e-4)
+    opt.zero_grad()
+    x = torch.from_numpy(z["x"]).cuda()
+    noise = {k: torch.from_numpy(z[k]).cuda() for k in ("eps_box", "eps_attr", "eps_depth", "u_pres")}
+    loss = m(x, int(z["global_step"]), noise=noise)[0]
+    loss.backward()
+    g = m.flat_gradients().cpu().numpy().astype(np.float64)
+    t = m.loss_terms().cpu().numpy()
+    opt.step()
+    p = m.flat_parameters().cpu().numpy()
+    assert np.allclose(r["terms"][:9], t[:9], rtol=max(tol, 1e-5), atol=1e-4), (r["terms"][:9], t[:9])
+    covered = np.zeros(g.size, bool)
+    for lo, hi in r["ranges"]:
+        assert not covered[lo:hi].any()
+        covered[lo:hi] = True
+        ref = g[lo:hi]
+        d = np.abs(r["grads"][lo:hi] - ref).max()
+        assert d <= tol * np.abs(ref).max() + 1e-7, (int(lo), int(hi), d, np.abs(ref).max())
+    assert np.abs(g[~covered]).max() == 0.0            # only the grad-less attn.* slots are outside the buckets
+    # after Adam the replicas' parameters equal the single-process ones (the update is sign-like: compare loosely in bf16)
+    assert np.abs(r["params"] - p).max() <= (1e-6 if dtype == "f32" else 2.1e-4)
