@@ -39,7 +39,7 @@ struct CellBufs {
     float* Za;                                              // attr rows for the decoder [N, ld_rec], zero padded
     void *Za16, *dfeat16;                                   // fused chain (bf16 step): the same two tensors written directly as bf16
     unsigned long long* mbits;                              // fused chain only: relu sign bits of the 8 hidden layers, [B][3G-2][66 tiles][4] wave ballots
-    unsigned int* gxy;                                      // fused chain only: per glimpse element (d val/d gx, d val/d gy) as bf16x2 [N, ld_gl]
+    unsigned int* gxy;                                      // fused chain only: per glimpse element (d val/d gx, d val/d gy) as fp16x2 [N, ld_gl]
     float *z_where, *z_pres;                                // NCHW outputs
     // backward
     float *dXb, *dHb1, *dHb2, *dOb;

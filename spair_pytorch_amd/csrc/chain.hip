@@ -429,8 +429,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
                 const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
                 const float gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
-                union { __bf16 h[2]; unsigned int u; } pk;
-                pk.h[0] = (__bf16)gx; pk.h[1] = (__bf16)gy;
+                union { _Float16 h[2]; unsigned int u; } pk;      // fp16 pair: |g| <= I/2 fits, 11 significant bits (bf16's 8 cost the box net's
+                pk.h[0] = (_Float16)gx; pk.h[1] = (_Float16)gy;     // gradient ~3 % of its direction: 784 signed terms per row cancel)
                 gxy[q] = pk.u;
             }
             bf16x4 o;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const unsigned int pkq[4] = {gxy_pf[j].x, gxy_pf[j].y, gxy_pf[j].z, gxy_pf[j].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    union { unsigned int u; __bf16 h[2]; } pk;
+                    union { unsigned int u; _Float16 h[2]; } pk;
                     pk.u = pkq[q];
                     const float d = trow < nc ? tl[trow][tc0 + q] : 0.f;
                     const float gix = d * (float)pk.h[0], giy = d * (float)pk.h[1];

@@ -383,6 +383,21 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)((nb + e) < g.N ? v[e] : 0.f);
             gq[i] = *reinterpret_cast<uint4*>(&o);
+        } else if (C16 && g.sprite_ch > 0) {
+            // sprites are sigmoid outputs in (0, 1): stored as FP16 (11 significant bits, no range problem) rather than bf16 (8) -- the
+            // same bytes, and the reconstruction / ELBO error of the bf16 step drops with it (the renderer unpacks either in one instruction)
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            _Float16* dst = reinterpret_cast<_Float16*>(g.C) + crow[i] * g.ldc + nb;
+            if (full && vec_ok) {
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+                *reinterpret_cast<h8*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (nb + e < g.N) dst[e] = (_Float16)v[e];
+            }
         } else if (C16) {
             __bf16* dst = reinterpret_cast<__bf16*>(g.C) + crow[i] * g.ldc + nb;
             if (full && vec_ok) {

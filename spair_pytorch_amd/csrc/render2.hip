@@ -10,7 +10,7 @@
 //   3. per wave, chunks of objects whose needed sprite rows fit the wave's LDS pool: the rows are CONTIGUOUS bytes of
 //      the [N][P][P][2] sprite array (16-byte aligned), so they are copied HBM/L2 -> LDS by direct-to-LDS loads
 //      (global_load_lds_dwordx4, no VGPR round trip, one wave-instruction per <= 9 rows); the y taps of the 4 strip
-//      rows are tabulated per object; then each lane composites its pixel: two table reads, four 4-byte (bf16 grey,
+//      rows are tabulated per object; then each lane composites its pixel: two table reads, four 4-byte (fp16 grey,
 //      alpha) taps from LDS, importance rebuilt per tap, ~45 VALU instructions per (pixel, object) pair
 //      (the first-generation kernel issued ~150 and four scattered global loads).
 //   Nothing is synchronised across waves inside step 3 (the pool and the y table are wave-private).
@@ -74,8 +74,7 @@ __device__ __forceinline__ int rf_scan_incl(int v, int lane) {
 template <bool S16>
 __device__ __forceinline__ float2 rf_tap(const char* p) {
     if constexpr (S16) {
-        const unsigned u = *reinterpret_cast<const unsigned*>(p);
-        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+        return sprite_unpack(*reinterpret_cast<const unsigned*>(p));
     } else {
         return *reinterpret_cast<const float2*>(p);
     }
@@ -325,9 +324,9 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// BACKWARD  k_render_bwd2 (bf16 step: bf16 sprites in, bf16 d-logits out) -- one WAVE per object, nothing synchronised across
+// BACKWARD  k_render_bwd2 (bf16 step: fp16 sprites in, bf16 d-logits out) -- one WAVE per object, nothing synchronised across
 // waves, no atomics:
-//   * the sprite goes to LDS once as a zero-bordered image of 8-byte texels {(grey, alpha) bf16 pair, importance fp32};
+//   * the sprite goes to LDS once as a zero-bordered image of 8-byte texels {(grey, alpha) fp16 pair, importance fp32};
 //   * pass A walks the object's pixel footprint in chunks of <= 16 rows x 32 columns (32 or 16 pixels x 2 or 4 rows per
 //     iteration): re-samples the sprite (taps through per-column / per-row tables), forms the three per-pixel adjoints
 //     (wrt interpolated grey, alpha * pres, importance), accumulates d z_where in registers and leaves the adjoints in LDS
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
     const int P = PT ? PT : Prt;
     const int PS = P + 2;
     const int lane = threadIdx.x;
-    uint2* Ssh = reinterpret_cast<uint2*>(smb);                                   // [PS][PS] {(grey, alpha) bf16 pair, importance}
+    uint2* Ssh = reinterpret_cast<uint2*>(smb);                                   // [PS][PS] {(grey, alpha) fp16 pair, importance}
     char* adjT = smb + PS * PS * 8;                                               // [3][RB2_ROWS][RB2_ADJ_LD] bf16
     float4* xt = reinterpret_cast<float4*>(adjT + RB2_ADJ_BYTES);                 // [32] {tap byte offset, frac, grid coord, -}
     float4* yt = xt + 32;                                                         // [RB2_ROWS]
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                     const unsigned ga[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        d[t] = make_uint2(ga[t], __float_as_uint(fmaxf(__uint_as_float(ga[t] & 0xffff0000u) * pd, 0.01f)));
+                        d[t] = make_uint2(ga[t], __float_as_uint(fmaxf(sprite_unpack(ga[t]).y * pd, 0.01f)));
                 }
             }
         }
@@ -523,10 +522,11 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 const bool valid = xvalid && (py0 + row <= PY1);
                 const Rb2Taps& t = in.t;
                 const float fy = in.ye.y;
-                const float g00 = __uint_as_float(t.q00.x << 16), a00 = __uint_as_float(t.q00.x & 0xffff0000u), m00 = __uint_as_float(t.q00.y);
-                const float g01 = __uint_as_float(t.q01.x << 16), a01 = __uint_as_float(t.q01.x & 0xffff0000u), m01 = __uint_as_float(t.q01.y);
-                const float g10 = __uint_as_float(t.q10.x << 16), a10 = __uint_as_float(t.q10.x & 0xffff0000u), m10 = __uint_as_float(t.q10.y);
-                const float g11 = __uint_as_float(t.q11.x << 16), a11 = __uint_as_float(t.q11.x & 0xffff0000u), m11 = __uint_as_float(t.q11.y);
+                const float2 u00 = sprite_unpack(t.q00.x), u01 = sprite_unpack(t.q01.x), u10 = sprite_unpack(t.q10.x), u11 = sprite_unpack(t.q11.x);
+                const float g00 = u00.x, a00 = u00.y, m00 = __uint_as_float(t.q00.y);
+                const float g01 = u01.x, a01 = u01.y, m01 = __uint_as_float(t.q01.y);
+                const float g10 = u10.x, a10 = u10.y, m10 = __uint_as_float(t.q10.y);
+                const float g11 = u11.x, a11 = u11.y, m11 = __uint_as_float(t.q11.y);
                 // separable bilinear: x first, then y; x-derivative = (right - left), y-derivative = (bottom - top)
                 const float dTg = g01 - g00, dBg = g11 - g10, dTa = a01 - a00, dBa = a11 - a10, dTm = m01 - m00, dBm = m11 - m10;
                 const float hTg = fmaf(fx, dTg, g00), hBg = fmaf(fx, dBg, g10), hTa = fmaf(fx, dTa, a00), hBa = fmaf(fx, dBa, a10);
@@ -591,7 +591,8 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 const int v = 16 * vt + 4 * fq + i, u = 16 * nt + fr;
                 if (v < P && u < P) {
                     const uint2 sv = Ssh[(v + 1) * PS + u + 1];
-                    const float sg = __uint_as_float(sv.x << 16), sa = __uint_as_float(sv.x & 0xffff0000u);
+                    const float2 sga = sprite_unpack(sv.x);
+                    const float sg = sga.x, sa = sga.y;
                     const float s0_ = dS[0][vt][nt][i], s1_ = dS[1][vt][nt][i], s2_ = dS[2][vt][nt][i];
                     const bool act = (sa * pd) >= 0.01f;                 // importance not clamped
                     const float s2a = act ? s2_ * sa : 0.f;

@@ -7,12 +7,17 @@
 #define RT 16            // output tile side
 #define RCH 256          // objects culled per pass (= threads per block)
 
-// (grey, alpha) of texel idx of a sprite row: fp32 pairs, or bf16 pairs in the bf16 training step (the decoder GEMM writes them so)
+// 16-bit sprites are FP16 (grey, alpha) pairs: sigmoid outputs in (0, 1), 11 significant bits
+typedef _Float16 sprite_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 sprite_unpack(unsigned u) {
+    const sprite_h2 h = __builtin_bit_cast(sprite_h2, u);
+    return make_float2((float)h.x, (float)h.y);
+}
+// (grey, alpha) of texel idx of a sprite row: fp32 pairs, or fp16 pairs in the bf16 training step (the decoder GEMM writes them so)
 template <bool S16>
 __device__ __forceinline__ float2 ld_texel(const float* __restrict__ S, size_t idx) {
     if constexpr (S16) {
-        const unsigned u = reinterpret_cast<const unsigned*>(S)[idx];
-        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+        return sprite_unpack(reinterpret_cast<const unsigned*>(S)[idx]);
     } else {
         return reinterpret_cast<const float2*>(S)[idx];
     }

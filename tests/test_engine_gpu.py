@@ -72,26 +72,45 @@ def test_fp32_step_matches_reference(name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["c1_b16_step1", "c1_b8_step1001", "c2_b2_step1001"])
+# Per-case bounds of the bf16 step against the reference's fixtures.  Evidence: profiles/r02_bf16_parity_table.txt (tools/bf16_parity_table.py,
+# every tensor of every case).  loss: BASELINE.json asks for 1e-3 relative; with fp16 sprites 2e-5 .. 1.2e-4 is observed.  recon: absolute, on a
+# [0, 1] image.  Gradients: |g| / |g_ref| - 1 and the cosine, per tensor.  The backbone / z / obj / decoder / encoder-output tensors sit at
+# cos >= 0.99 everywhere; the box network and the encoder's first layers are the sensitive ones (their gradient is a sum over few rows --
+# B*G*G = 242 .. 576 in the small cases -- of terms that pass through the STN's image gradients and 3G-2 dependent bf16 stages):
+# 0.96 at 288 rows, 0.92 on the reference's default 11x11 grid with batch 2 and with the 2x weight scale of step 7001, >= 0.992 from 512 rows up.
+BF16_BOUNDS = {
+    #                          loss    recon   z_where  norm    cos
+    "c1_b16_step1":            (2.5e-4, 0.010,  0.002,   0.03,   0.99),     # training wheel on: only encoder / decoder receive gradients
+    "c1_b8_step1001":          (2.5e-4, 0.010,  0.002,   0.06,   0.95),
+    "c1_b8_step7001":          (2.5e-4, 0.080,  0.005,   0.16,   0.90),     # sharp count prior, weights x2: the numerically hardest fixture
+    "c2_b2_step1001":          (2.5e-4, 0.015,  0.002,   0.02,   0.99),     # the bench geometry (128x128, 16x16 grid)
+    "ref_default_b2_step1001": (2.5e-4, 0.060,  0.002,   0.06,   0.90),
+    "c4_b1_step1001":          (2.5e-4, 0.010,  0.002,   0.02,   0.99),     # 256x256, 32x32 grid
+}
+
+
+@pytest.mark.parametrize("name", list(gi.CASES))
 def test_bf16_step_within_north_star_tolerance(name):
-    """BASELINE.json: ELBO within 1e-3 relative of the CPU reference on the same batch and noise."""
+    """BASELINE.json: ELBO within 1e-3 relative of the CPU reference on the same batch and noise (observed <= 1.2e-4, bound 2.5e-4)."""
+    tol_loss, tol_recon, tol_zw, tol_norm, min_cos = BF16_BOUNDS[name]
     z, case = load_case(name)
     m = build_model(case, "bf16")
     x = torch.from_numpy(z["x"]).cuda()
     noise = {k: torch.from_numpy(z[k]).cuda() for k in ("eps_box", "eps_attr", "eps_depth", "u_pres")}
     m.zero_grad()
     loss, recon, z_where, z_pres = m(x, int(z["global_step"]), noise=noise)
-    assert abs(loss.item() - float(z["loss"])) <= 1e-3 * abs(float(z["loss"]))
-    assert np.abs(recon.cpu().numpy() - z["recon_x"]).max() < 0.08
-    assert np.abs(z_where.cpu().numpy() - z["z_where"]).max() < 0.03
+    assert abs(loss.item() - float(z["loss"])) <= tol_loss * abs(float(z["loss"]))
+    assert np.abs(recon.cpu().numpy() - z["recon_x"]).max() < tol_recon
+    assert np.abs(z_where.cpu().numpy() - z["z_where"]).max() < tol_zw
     loss.backward()
-    # gradients: direction and size of every tensor agree with the reference to bf16 accuracy
+    bad = []
     for k, p in m.named_parameters():
         if k.startswith("attn."):
             continue
         gn = float(p.grad.double().norm().item())
         ref_n = float(z["gradnorm_" + k])
-        assert abs(gn - ref_n) <= 0.08 * ref_n + 1e-5, (k, gn, ref_n)
+        if abs(gn - ref_n) > tol_norm * ref_n + 1e-5:
+            bad.append((k, "norm", gn / max(ref_n, 1e-30)))
         # direction: full tensor when the fixture holds it, the fixed sample of elements otherwise
         g = p.grad.detach().double().cpu().flatten().numpy()
         if "grad_" + k in z.files:
@@ -100,7 +119,82 @@ def test_bf16_step_within_north_star_tolerance(name):
             g, ref = g[z["gradidx_" + k]], z["gradsample_" + k].astype(np.float64)
         if np.linalg.norm(ref) > 1e-6 * max(1.0, ref_n):
             cos = float(np.dot(g, ref) / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
-            assert cos >= 0.9, (k, cos)      # bf16 operands through a 46-step dependent chain: 0.95-0.999 observed; a layout bug gives ~0
+            if cos < min_cos:
+                bad.append((k, "cos", cos))
+    assert not bad, bad
+
+
+def _bench_model(dtype, I, seed=3):
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.models import SPAIR
+    cfg.set_grid(I, (2, 2, 2, 1, 1, 1))
+    torch.manual_seed(seed)                    # train.py:39
+    return SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype=dtype).to("cuda")
+
+
+def test_bf16_vs_f32_mode_full_bench_batch():
+    """BASELINE configs[1] at its full size (B=256, 128x128, 16x16 grid), which the CPU reference cannot run (85 GB): the bf16 step against
+    the fp32-MFMA mode of the same engine (itself pinned to the reference on the small fixtures) on the same weights, scenes and noise."""
+    from spair_pytorch_amd.data import scattered_digits
+    x = torch.from_numpy(scattered_digits(1234, 256, 128, 11)[0]).cuda()
+    out = {}
+    for dtype in ("f32", "bf16"):
+        m = _bench_model(dtype, 128)
+        torch.manual_seed(7)                   # the noise seed comes from torch's CPU generator: same draws in both modes
+        m.zero_grad()
+        loss, recon, z_where, z_pres = m(x, 2000)
+        loss.backward()
+        out[dtype] = dict(loss=loss.item(), terms=m.loss_terms().cpu().numpy().copy(), recon=recon.cpu().numpy(), z_where=z_where.cpu().numpy(),
+                          z_pres=z_pres.cpu().numpy(), grad=m.flat_gradients().double().cpu().numpy().copy(),
+                          slices={k: v for k, v in m._slices.items()})
+        del m
+        torch.cuda.empty_cache()
+    a, b = out["f32"], out["bf16"]
+    assert np.isfinite(b["grad"]).all()
+    assert abs(b["loss"] - a["loss"]) <= 3e-4 * abs(a["loss"]), (a["loss"], b["loss"])          # observed 1.0e-4
+    assert np.abs(b["terms"][1:9] - a["terms"][1:9]).max() <= 3e-4 * abs(a["loss"])
+    assert np.abs(b["z_where"] - a["z_where"]).max() < 5e-3 and np.abs(b["z_pres"] - a["z_pres"]).max() < 5e-3
+    assert np.abs(b["recon"] - a["recon"]).mean() < 1e-3
+    # 65,536 rows per gradient sum: every tensor's direction and size agree closely.  Observed (tools/exp/fullbatch_bf16_f32.py): cos >= 0.9997
+    # and |g| within 0.4 % for 43 of the 49 tensors; the stem weight (cos 0.9897), the box net's first layer (cos 0.9887) and the box net's
+    # body / latent head (|g| 2.4 - 3.3 % low, cos >= 0.994) are the outliers, the same with the fused and the per-wavefront chain.
+    bad = []
+    for k, (off, cnt, shp) in a["slices"].items():
+        if k.startswith("attn."):
+            continue
+        ga, gb = a["grad"][off:off + cnt], b["grad"][off:off + cnt]
+        na, nb_ = np.linalg.norm(ga), np.linalg.norm(gb)
+        cos = float(np.dot(ga, gb) / (na * nb_ + 1e-30))
+        if cos < 0.985 or abs(nb_ / na - 1.0) > 0.04:
+            bad.append((k, cos, nb_ / na))
+    assert not bad, bad
+
+
+def test_bf16_trajectory_tracks_f32_mode():
+    """60 optimizer steps from the same initial weights, scenes and noise stream: the bf16 ELBO follows the fp32-mode ELBO step by step while
+    the two runs are still the same trajectory (20 steps: <= 1e-3 relative, 1.2e-4 observed; afterwards fp32 atomics make even two fp32 runs
+    drift apart), both fall, and they end within 5 % of each other."""
+    from spair_pytorch_amd.data import scattered_digits
+    from spair_pytorch_amd.optim import FusedAdam
+    x = torch.from_numpy(scattered_digits(5, 16, 48, 3)[0]).cuda()
+    traj = {}
+    for dtype in ("f32", "bf16"):
+        m = _bench_model(dtype, 48)
+        opt = FusedAdam(m, lr=1e-4)
+        torch.manual_seed(11)
+        losses = []
+        for s in range(60):
+            opt.zero_grad()
+            loss = m(x, 1000 + s)[0]
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        traj[dtype] = torch.stack(losses).cpu().numpy().astype(np.float64)
+    a, b = traj["f32"], traj["bf16"]
+    assert np.isfinite(b).all()
+    assert (np.abs(b[:20] - a[:20]) / np.abs(a[:20])).max() <= 1e-3
+    assert b[-1] < 0.8 * b[0] and a[-1] < 0.8 * a[0]
+    assert abs(b[-1] - a[-1]) <= 0.05 * abs(a[-1])
 
 
 def test_adam_step_matches_torch():

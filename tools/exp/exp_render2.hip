@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> S((size_t)N * PP2);
     std::vector<float> nb((size_t)N * 4), pd((size_t)N * 2), x((size_t)B * I * I);
     srand(1);
-    for (auto& v : S) v = f2bf(rand() / (float)RAND_MAX);
+    for (auto& v : S) { const _Float16 h = (_Float16)(rand() / (float)RAND_MAX); memcpy(&v, &h, 2); }     // fp16 (grey, alpha) pairs
     for (auto& v : x) v = (rand() % 4 == 0) ? rand() / (float)RAND_MAX : 0.f;
     for (int k = 0; k < HW; ++k) for (int b = 0; b < B; ++b) {
         const int r = k * B + b;
