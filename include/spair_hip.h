@@ -9,7 +9,11 @@
  *     library relies on never-written pad columns staying zero);
  *   - work is enqueued on `stream` (a hipStream_t) and never synchronises;
  *   - return 0 on success, a negative SPAIR_ERR_* code otherwise (shape / dtype / launch);
- *   - stateless and re-entrant: all state lives in the buffers the caller passes.
+ *   - all step state lives in the buffers the caller passes.  The only library-owned objects are one low-priority helper HIP stream
+ *     (+ 6 fork/join events) per device, created under a lock on first use or by spair_init(), and the opt-in profiling event pool
+ *     (spair_prof_*, lock-protected, off by default).  Calls on different devices or different caller streams may run concurrently
+ *     from different host threads as long as they use different workspaces; create the helper stream with spair_init() before
+ *     capturing a step into a hipGraph.
  */
 #pragma once
 #include <stddef.h>
@@ -50,6 +54,9 @@ typedef struct SpairStep {
                                 * does, but on the helper stream beside the backbone); the buffers must be writable */
     unsigned long long noise_seed;
 } SpairStep;
+
+/* Optional: create the current device's helper stream now (otherwise on the first spair_forward / spair_backward). */
+int spair_init(void);
 
 /* ---- parameter / workspace layout -------------------------------------------------------- */
 /* Flat fp32 parameter buffer; tensor i of the reference state_dict (same key, same shape). */
@@ -159,6 +166,13 @@ int spair_stn_glimpse_fwd(const float* x, const float* nbox, int B, float* glimp
                           int I, int P, int align_corners, void* stream);
 int spair_stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dglimpse, int ld_gl,
                           float* dnbox, int R, int C, int I, int P, int align_corners, void* stream);
+/* stn(sprites, z_where, [I,I], inverse=True) materialised (modules.py:256-269): sprites [N,C,P,P] -> out [N,C,I,I], bilinear, zeros
+ * padding, inverse affine in closed form; backward ACCUMULATES into dsprites [N,C,P,P] and dnbox [N,4] (zero them first).  Only for
+ * callers of the reference's helper -- the training step never materialises this tensor (spair_render_fwd fuses it). */
+int spair_stn_inverse_fwd(const float* sprites, const float* nbox, float* out, int N, int C, int P, int I, int align_corners,
+                          void* stream);
+int spair_stn_inverse_bwd(const float* sprites, const float* nbox, const float* grad_out, float* dsprites, float* dnbox, int N,
+                          int C, int P, int I, int align_corners, void* stream);
 /* renderer: inverse STN + importance-weighted composite + BCE (models.py:485-547) */
 int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                      const float* x, float* recon, float* aux /* B*I*I float2: (dBCE/dpre / D, pre) */, float* bce_partial,

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "cells.h"
@@ -46,10 +47,13 @@ struct ProfState {
     hipEvent_t ev[2 * SP_PROF_POOL];
     int slot[SP_PROF_POOL];
 };
-static ProfState g_prof;
+static ProfState g_prof;            // opt-in, process-wide, guarded by g_prof_mu (bench.py only; off by default)
+static std::mutex g_prof_mu;
 
 static inline int prof_begin(int slot, hipStream_t s) {
-    if (slot < 0 || !g_prof.enabled || !((g_prof.mask >> slot) & 1ull) || g_prof.used >= SP_PROF_POOL) return -1;
+    if (slot < 0 || !g_prof.enabled) return -1;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!((g_prof.mask >> slot) & 1ull) || g_prof.used >= SP_PROF_POOL) return -1;
     const int i = g_prof.used++;
     g_prof.slot[i] = slot;
     hipEventRecord(g_prof.ev[2 * i], s);
@@ -65,6 +69,7 @@ struct ProfScope {
 };
 
 extern "C" int spair_prof_enable(int enable) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (enable && g_prof.n_events == 0) {
         for (int i = 0; i < 2 * SP_PROF_POOL; ++i)
             if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return SPAIR_ERR_LAUNCH;
@@ -75,9 +80,14 @@ extern "C" int spair_prof_enable(int enable) {
     return SPAIR_OK;
 }
 // Restricts the recorded regions to the slots whose bit is set (default: all).
-extern "C" int spair_prof_select(unsigned long long mask) { g_prof.mask = mask; return SPAIR_OK; }
+extern "C" int spair_prof_select(unsigned long long mask) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof.mask = mask;
+    return SPAIR_OK;
+}
 // Synchronises on the recorded events (call only outside the timed region); ms[slot] += elapsed, counts[slot] += 1.
 extern "C" int spair_prof_read(float* ms, int* counts, int nslots) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (int i = 0; i < g_prof.used; ++i) {
         float t = 0.f;
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return SPAIR_ERR_LAUNCH;
@@ -330,25 +340,37 @@ struct Ctx {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[6];
-    int dev = -1;
 };
-static SideStream g_side;
+// One helper stream + its fork/join events PER DEVICE, created once under a lock (first use, or spair_init() ahead of a hipGraph
+// capture -- stream / event creation is not capturable).  They carry no data between calls: every call forks from and joins back
+// into the caller's stream, so concurrent steps on different caller streams of one device only share the helper queue's ordering.
+#define SP_MAX_DEVICES 64
+static SideStream g_side[SP_MAX_DEVICES];
+static std::mutex g_side_mu;
 static int side_stream(SideStream*& out) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return SPAIR_ERR_LAUNCH;
-    if (g_side.s == nullptr || g_side.dev != dev) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SP_MAX_DEVICES) return SPAIR_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    SideStream& sd = g_side[dev];
+    if (sd.s == nullptr) {
         // lowest priority: what runs here (weight gradients, KL terms, preparation) has slack, the caller's stream carries the
         // dependent chain -- when both have workgroups to place, the chain's go first
         int prio_least = 0, prio_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = 0;
         if (getenv("SPAIR_SIDE_PRIO")) prio_least = atoi(getenv("SPAIR_SIDE_PRIO"));
-        if (hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_least) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least) != hipSuccess) return SPAIR_ERR_LAUNCH;
         for (int i = 0; i < 6; ++i)
-            if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return SPAIR_ERR_LAUNCH;
-        g_side.dev = dev;
+            if (hipEventCreateWithFlags(&sd.ev[i], hipEventDisableTiming) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        sd.s = st;
     }
-    out = &g_side;
+    out = &sd;
     return SPAIR_OK;
+}
+// Creates the current device's helper stream ahead of time (optional; spair_forward / spair_backward do it on first use).
+extern "C" int spair_init(void) {
+    SideStream* sd = nullptr;
+    return side_stream(sd);
 }
 // everything enqueued on `to` after this call runs after everything enqueued on `from` before it
 static int stream_link(hipStream_t from, hipStream_t to, hipEvent_t e) {

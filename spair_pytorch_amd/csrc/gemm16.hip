@@ -522,6 +522,14 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     if (g.accumulate) return SPAIR_ERR_UNSUPPORTED;
     if (!conv && (long long)g.M * g.lda >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;   // 32-bit element offsets
     if ((long long)g.N * g.ldb >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+    if (conv) {      // the gathered operand and the (possibly row-mapped) output are addressed with 32-bit element offsets too
+        const long long rows_in = (long long)ceil_div(g.M, g.conv.Hout * g.conv.Wout) * g.conv.Hin * g.conv.Win;
+        if (rows_in * g.conv.Cin >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+    }
+    {
+        const long long rows_out = g.use_cmap ? (long long)ceil_div(g.M, g.cmap.Hout * g.cmap.Wout) * g.cmap.Hc * g.cmap.Wc : (long long)g.M;
+        if (rows_out * g.ldc >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+    }
     // K tile: 64 (73.7 KB of LDS, 2 workgroups per CU) or 32 (41 KB, 3 per CU, the epilogue staged in two passes).  Measured: the
     // long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out data gradient 0.099 vs 0.128 ms), the short-K
     // ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148 ms).  SPAIR_NT16_BK=32|64 forces one.

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void k_metrics(const float* __restrict__ z_whe
         __syncthreads();
     }
     if (tid == 0) {
-        per_sample[2 * b] = ap_sum / count[b];                                                   // metric.py:45
+        // metric.py:45 divides by the object count; an EMPTY scene (count 0: 0/0 = NaN in the reference, whose dataset has none) is
+        // marked with -1 here and left out of the batch mean instead of poisoning it
+        per_sample[2 * b] = count[b] > 0.f ? ap_sum / count[b] : -1.f;
         per_sample[2 * b + 1] = count[b] - np_;                                                  // metric.py:55
     }
 }
@@ -72,8 +74,12 @@ __global__ __launch_bounds__(256) void k_metrics(const float* __restrict__ z_whe
 __global__ void k_metrics_final(const float* __restrict__ per_sample, int B, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float a = 0.f, c = 0.f;
-    for (int b = 0; b < B; ++b) { a += per_sample[2 * b]; c += per_sample[2 * b + 1]; }       // fixed order: deterministic
-    out[0] = a / (float)B;
+    int nv = 0;
+    for (int b = 0; b < B; ++b) {                                                              // fixed order: deterministic
+        if (per_sample[2 * b] >= 0.f) { a += per_sample[2 * b]; ++nv; }
+        c += per_sample[2 * b + 1];
+    }
+    out[0] = a / (float)max(nv, 1);                                                            // == a / B when no scene is empty
     out[1] = c / (float)B;
 }
 

@@ -33,6 +33,51 @@ def backbone_geometry(image_hw, topology):
     return pre, post, n, j, r
 
 
+def _hip_linear(x, weight, bias, relu=False):
+    """y = relu?(x @ weight.T + bias) through spair_gemm_nt (exact fp32 MFMA mode): [M,K] x [N,K] -> [M,N]."""
+    import ctypes
+    from . import _lib as L
+    if not x.is_cuda:
+        raise L.SpairHipError("tensors must live on the MI355X; there is no CPU path")
+    M, K = x.shape
+    N = weight.shape[0]
+    Kp = (K + 3) // 4 * 4
+    A = x.detach().float().contiguous()
+    W = weight.detach().float().contiguous()
+    if Kp != K:      # the GEMM wants K % 4 == 0: zero columns change nothing
+        A = torch.nn.functional.pad(A, (0, Kp - K))
+        W = torch.nn.functional.pad(W, (0, Kp - K))
+    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    L.check(L.lib().spair_gemm_nt(L.ptr(A), Kp, L.ptr(W), Kp, L.ptr(out), N, M, N, Kp, L.ptr(b), None, 0, int(relu), 0, 0, L.stream()),
+            "spair_gemm_nt")
+    return out
+
+
+def _hip_conv_nhwc(x, weight, bias, stride, relu):
+    """NHWC valid convolution as the implicit GEMM of spair_gemm_nt_conv (fp32 mode): x [B,H,W,C], weight OIHW -> [B,Ho,Wo,O]."""
+    import ctypes
+    from . import _lib as L
+    B, H, W_, C = x.shape
+    O, Ci, kh, kw = weight.shape
+    assert Ci == C
+    Cp = (C + 3) // 4 * 4
+    xw = x.detach().float()
+    w = weight.detach().float().permute(0, 2, 3, 1)          # [O, kh, kw, Ci]: the K order of the gather
+    if Cp != C:
+        xw = torch.nn.functional.pad(xw, (0, Cp - C))
+        w = torch.nn.functional.pad(w, (0, Cp - C))
+    xw, w = xw.contiguous(), w.contiguous().view(O, kh * kw * Cp)
+    Ho, Wo = (H - kh) // stride + 1, (W_ - kw) // stride + 1
+    out = torch.empty(B, Ho, Wo, O, device=x.device, dtype=torch.float32)
+    conv = (ctypes.c_int * 13)(H, W_, Cp, Ho, Wo, kh, kw, stride, stride, 1, 1, 0, 0)
+    K = kh * kw * Cp
+    b = bias.detach().float().contiguous()
+    L.check(L.lib().spair_gemm_nt_conv(L.ptr(xw), conv, L.ptr(w), K, L.ptr(out), O, B * Ho * Wo, O, K, L.ptr(b), None, 0, int(relu), 0, None, 0,
+                                       L.stream()), "spair_gemm_nt_conv")
+    return out
+
+
 class Backbone(Module):
     """modules.py:12-111.  Keeps ``net`` (conv_0..conv_out), ``padding``, ``n_grid_cells``,
     ``grid_cell_size``; ``forward`` is executed by the HIP engine, not by this module."""
@@ -66,7 +111,16 @@ class Backbone(Module):
         return torch.Size([self.n_out_channels, n, n])
 
     def forward(self, x):
-        raise RuntimeError("Backbone.forward runs inside the HIP engine (SPAIR.forward); it has no PyTorch path")
+        """modules.py:107-111 on its own: pad, then the conv stack as implicit GEMMs (spair_gemm_nt_conv, exact fp32 MFMA mode).
+        Inference helper (no autograd graph): the training step runs the backbone inside the fused engine (SPAIR.forward)."""
+        from . import _lib as L
+        if not x.is_cuda:
+            raise L.SpairHipError("Backbone.forward: the input must live on the MI355X; there is no CPU path")
+        h = self.padding(x.detach().float()).permute(0, 2, 3, 1).contiguous()       # NHWC
+        convs = [m for m in self.net if isinstance(m, Conv2d)]
+        for i, conv in enumerate(convs):
+            h = _hip_conv_nhwc(h, conv.weight, conv.bias, int(conv.stride[0]), relu=(i < len(convs) - 1))
+        return h.permute(0, 3, 1, 2).contiguous()
 
 
 class SequentialMultipleOutput(Module):
@@ -78,7 +132,30 @@ class SequentialMultipleOutput(Module):
         self.output_layers = ModuleList(list(outputs.values()))
 
     def forward(self, x):
-        raise RuntimeError("executed by the HIP engine")
+        """modules.py:282-284: the body, then a GENERATOR over the heads' outputs.  Linear layers run through spair_gemm_nt
+        (fp32 mode); inference helper, no autograd graph (training runs these nets inside the fused per-cell kernels)."""
+        h = hip_mlp_forward(self.body, x)
+        return (_hip_linear(h, layer.weight, layer.bias) for layer in self.output_layers)
+
+
+def hip_mlp_forward(seq, x):
+    """Linear / ReLU stack of build_MLP through the HIP GEMM (a following ReLU is fused into the GEMM epilogue)."""
+    mods = list(seq)
+    h = x
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, Linear):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], ReLU)
+            h = _hip_linear(h, m.weight, m.bias, relu=relu)
+            i += 2 if relu else 1
+        elif isinstance(m, ReLU):
+            h = torch.relu(h)
+            i += 1
+        else:
+            h = m(h)
+            i += 1
+    return h
 
 
 def build_MLP(n_in, output=None, multiple_output=None, hidden_layers=None, activation=None, internal_activation=ReLU):
@@ -128,25 +205,59 @@ def exponential_decay(global_step, device=None, start=0.0, end=0.0, decay_rate=0
     return float(value)
 
 
+class _StnFn(torch.autograd.Function):
+    """stn() as a differentiable operator over the HIP kernels: forward direction = border-padded glimpse gather (gradient wrt
+    z_where; the image is data), inverse = zero-padded placement of sprites on the canvas (gradients wrt sprites and z_where)."""
+
+    @staticmethod
+    def forward(ctx, image, z_where, size, inverse):
+        from . import _lib as L
+        N, C, H, W = image.shape
+        img = image.detach().contiguous().float()
+        zw = z_where.detach().contiguous().float()
+        ac = int(cfg.ALIGN_CORNERS)
+        if inverse:
+            out = torch.empty(N, C, size, size, device=img.device, dtype=torch.float32)
+            L.check(L.lib().spair_stn_inverse_fwd(L.ptr(img), L.ptr(zw), L.ptr(out), N, C, H, size, ac, L.stream()), "spair_stn_inverse_fwd")
+        else:
+            out = torch.empty(N, C * size * size, device=img.device, dtype=torch.float32)
+            L.check(L.lib().spair_stn_glimpse_fwd(L.ptr(img), L.ptr(zw), N, L.ptr(out), C * size * size, N, C, H, size, ac, L.stream()),
+                    "spair_stn_glimpse_fwd")
+            out = out.view(N, C, size, size)
+        ctx.save_for_backward(img, zw)
+        ctx.size, ctx.inverse = size, inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        img, zw = ctx.saved_tensors
+        N, C, H, W = img.shape
+        g = g.contiguous().float()
+        ac = int(cfg.ALIGN_CORNERS)
+        dzw = torch.zeros(N, 4, device=img.device, dtype=torch.float32)
+        if ctx.inverse:
+            dimg = torch.zeros_like(img)
+            L.check(L.lib().spair_stn_inverse_bwd(L.ptr(img), L.ptr(zw), L.ptr(g), L.ptr(dimg), L.ptr(dzw), N, C, H, ctx.size, ac, L.stream()),
+                    "spair_stn_inverse_bwd")
+            return dimg, dzw, None, None
+        per = C * ctx.size * ctx.size
+        L.check(L.lib().spair_stn_glimpse_bwd(L.ptr(img), L.ptr(zw), N, L.ptr(g.view(N, per)), per, L.ptr(dzw), N, C, H, ctx.size, ac,
+                                              L.stream()), "spair_stn_glimpse_bwd")
+        return None, dzw, None, None
+
+
 def stn(image, z_where, output_dims, device=None, inverse=False):
-    """modules.py:216-273.  Forward direction (glimpse extraction, border padding) runs the HIP
-    gather kernel; ``image`` [N,C,H,W] float32 on the GPU, ``z_where`` [N,4]=(xt,yt,xs,ys).
-    The inverse direction is only ever used inside the fused renderer (models.py:515) and is
-    not materialised on its own."""
+    """modules.py:216-273.  ``image`` [N,C,H,W] float32 on the GPU, ``z_where`` [N,4] = (xt,yt,xs,ys), square sizes.
+    Forward direction: glimpse extraction (border padding), differentiable wrt z_where.  ``inverse=True``: the sprites are placed
+    on an ``output_dims`` canvas through the inverse affine (zeros padding), differentiable wrt both arguments; this materialises
+    [N,C,I,I], which the training step itself never does (the renderer fuses it)."""
     from . import _lib as L
-    if inverse:
-        raise NotImplementedError("inverse stn is fused into the renderer (spair_render_fwd); it never materialises [N,C,H,W]")
     if not image.is_cuda:
         raise L.SpairHipError("stn: tensors must live on the MI355X; there is no CPU path")
     N, C, H, W = image.shape
-    assert H == W and output_dims[0] == output_dims[1]
-    P = int(output_dims[0])
-    image = image.contiguous().float()
-    zw = z_where.detach().contiguous().float()
-    out = torch.empty(N, C * P * P, device=image.device, dtype=torch.float32)
-    L.check(L.lib().spair_stn_glimpse_fwd(L.ptr(image), L.ptr(zw), N, L.ptr(out), C * P * P, N, C, H, P,
-                                          int(cfg.ALIGN_CORNERS), L.stream()), "spair_stn_glimpse_fwd")
-    return out.view(N, C, P, P)
+    assert H == W and int(output_dims[0]) == int(output_dims[1]), "square images / glimpses only"
+    return _StnFn.apply(image, z_where, int(output_dims[0]), bool(inverse))
 
 
 def to_C_H_W(t):

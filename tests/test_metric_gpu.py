@@ -54,3 +54,29 @@ def test_metrics_full_size_vs_oracle():
     a = metric.object_count_accuracy(zp.cuda(), cnt.cuda())
     assert abs(m.item() - ref_m.item()) <= 5e-6 * max(1.0, abs(ref_m.item()))
     assert abs(a.item() - ref_a.item()) <= 1e-5 * max(1.0, abs(ref_a.item()))
+
+
+def test_map_skips_empty_scenes_and_accepts_flat_counts():
+    """The reference divides each sample's AP sum by its object count (metric.py:45): an empty scene is 0/0 there.  The device metric
+    leaves empty scenes out of the batch mean; a count tensor of shape [B] means the same as [B,1]."""
+    from oracle import metric_oracle as mo
+    from spair_pytorch_amd import metric
+    g = torch.Generator().manual_seed(9)
+    B, G, I, K = 8, 6, 48, 3
+    zw = torch.rand(B, 4, G, G, generator=g) * 0.8
+    zw[:, 2:] = torch.rand(B, 2, G, G, generator=g) * 0.3 + 0.05
+    zp = torch.rand(B, 1, G, G, generator=g)
+    cnt = torch.tensor([1, 2, 0, 3, 1, 0, 2, 3]).float()
+    bb = torch.zeros(B, K, 4)
+    for b in range(B):
+        n = int(cnt[b])
+        wh = torch.rand(n, 2, generator=g) * 10 + 6
+        bb[b, :n, 2:] = wh
+        bb[b, :n, :2] = torch.rand(n, 2, generator=g) * (I - wh)
+    keep = cnt > 0
+    ref = mo.mAP(zw[keep], zp[keep], bb[keep], cnt[keep].view(-1, 1), I)
+    m = metric.mAP(zw.cuda(), zp.cuda(), bb.cuda(), cnt.cuda(), image_side=I)            # counts of shape [B]
+    assert torch.isfinite(m).all()
+    assert abs(m.item() - ref.item()) <= 5e-6 * max(1.0, abs(ref.item()))
+    m2 = metric.mAP(zw.cuda(), zp.cuda(), bb.cuda(), cnt.view(-1, 1).cuda(), image_side=I)
+    assert m2.item() == m.item()
