@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspair_hip.so")
+LIB_PATH = os.environ.get("SPAIR_HIP_LIB") or os.path.join(_HERE, "libspair_hip.so")     # the override is for A/B builds of the same ABI
 
 _ERR = {-1: "bad shape", -2: "unsupported dtype", -3: "kernel launch failed", -4: "unsupported configuration",
         -5: "misaligned leading dimension / size"}

@@ -56,7 +56,10 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
 // boundaries and barriers: pipe_fill() for layer l+1 is issued right after the MFMAs of layer l.
 constexpr int NW = 8;                     // waves per workgroup
 constexpr int NTH = NW * 64;
-constexpr int RD = 12;
+#ifndef CHAIN_RD
+#define CHAIN_RD 12      // measured: 16 / 20 / 24 fragments in flight per wave change nothing (0.91 -> 0.93-0.95 ms)
+#endif
+constexpr int RD = CHAIN_RD;
 struct WPipe { uint4 q[RD]; };
 
 template <int KT, int NT, int NT0>

@@ -85,16 +85,29 @@ __device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int 
 // matrix is 1: the bias gradient) -- and d act0 is never written to HBM (321 MB out + 321 MB back in at config 2).  Each
 // workgroup leaves a [128][17] fp32 partial; spair_gemm_nt16_impl sums them (two small passes, no atomics).
 #define STEM_PART_FLOATS (128 * 17)
-template <bool ACONV, bool C16, bool STEM, int BK>
+// LDS operand tiles: SWZ = rows of exactly BK elements (128 or 64 bytes) with the 16-byte chunk index XOR-ed by a function of the row
+// -- chunk ^ (row & 7) at BK 64, chunk ^ (-(row >> 2) & 3) at BK 32 -- which makes every ds_read_b128 fragment read and every
+// ds_write_b128 staging write conflict-free (ds_read_b128 serves lanes {0-3, 12-15, 20-27} etc. together: with rows padded by
+// 16 bytes instead, 7 of each group's 16 lanes shared a bank pair with another, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 - 0.46).
+template <int BK>
+__device__ __forceinline__ int nt16_swz(int row) { return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3); }
+
+// GL (needs SWZ): the operand tiles go HBM/L2 -> LDS by direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPR round trip, no
+// ds_write pass; a wave-instruction writes 1 KiB = 8 (BK 64) or 16 (BK 32) whole unpadded tile rows at base + lane * 16, so the XOR
+// swizzle is applied on the SOURCE side: the lane that owns LDS chunk c of row r fetches global chunk c ^ swz(r)); masked lanes pass an
+// out-of-range offset and the range check writes zeros.
+template <bool ACONV, bool C16, bool STEM, int BK, bool SWZ, bool GL>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT g) {
+    static_assert(!GL || SWZ, "direct-to-LDS staging needs the unpadded swizzled tile");
     static_assert(BK == 64 || BK == 32, "K tile");
-    constexpr int BM = 128, BN = 128, LD = BK + 8;
+    constexpr int BM = 128, BN = 128, LD = SWZ ? BK : BK + 8;
     constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
     constexpr int KQ = BK / 8, RPI = 256 / KQ;                          // 16-byte chunks per tile row; rows staged per pass of the block
     constexpr int NA = BM * KQ / 256, NB = BN * KQ / 256;               // 16-byte chunks per thread: 4 + 4 (BK 64), 2 + 2 (BK 32)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-    __bf16* As0 = smem;                       // [2][BM*LD]
-    __bf16* Bs0 = smem + 2 * BM * LD;         // [2][BN*LD]
+    constexpr int NBUF = (GL && BK == 32) ? 3 : 2;      // direct-to-LDS at BK 32: a 3-deep ring, two K tiles in flight behind a counted wait
+    __bf16* As0 = smem;                       // [NBUF][BM*LD]
+    __bf16* Bs0 = smem + NBUF * BM * LD;      // [NBUF][BN*LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     // Address arithmetic is the bottleneck of a conv gather if done naively (a 64-bit multiply chain per 16-byte chunk made both
     // conv kernels VALU-issue bound): every row's element offset is computed ONCE (32-bit), the tap's offset once per K tile, and a
     // chunk's address is one add.  Tensors must stay below 2^31 elements (checked by the launcher).
-    const int kq = tid % KQ;
+    const int kq_slot = tid % KQ;                                        // this thread's LDS chunk slot in its rows
+    const int kq = GL ? (kq_slot ^ nt16_swz<BK>(tid / KQ)) : kq_slot;   // ... and the global k-chunk it fetches (GL: source-side swizzle)
     ConvTap16 a_ct;
     unsigned a_base[NA];                 // element offset of (b, y*sy+oy, x*sx+ox, 0) (conv) or of row m (plain)
     int a_y[NA], a_x[NA];                // conv: y*sy+oy, x*sx+ox for the bounds test of data-gradient gathers
@@ -197,13 +211,54 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = buf_load16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB);
     };
+    const int kqs = (SWZ && !GL) ? (kq ^ nt16_swz<BK>(tid / KQ)) : kq_slot;       // RPI is a multiple of 8 (BK 64) / of 16 (BK 32): the same for every pass
+    // GL: the same offsets, the loads land in LDS buffer `buf` directly
+    auto glds16 = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, __bf16* tile, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + (i * 256 + wave * 64) * 16), 16,
+                                                 (int)byte_off, 0, 0, 0);
+    };
+    auto glds_tiles = [&](int k0, int buf) {
+        __bf16* As = As0 + buf * BM * LD;
+        __bf16* Bs = Bs0 + buf * BN * LD;
+        const int k = k0 + kq * 8;
+        const bool kok = k < g.K;
+        const bool live = k0 < g.K;                      // wave-uniform
+        const unsigned kc = (unsigned)min(k, Klast);
+        if (ACONV) {
+            int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
+            if (BK == 64 && g.n_ktab > 0) {
+                const unsigned e = g.ktab[min(k0 >> 6, g.n_ktab - 1)];
+                t_ky = (int)(e >> 24); t_kx = (int)((e >> 16) & 255u); t_ci = (int)(e & 0xffffu) + kq * 8;
+            }
+            const int dy = t_ky * g.conv.dky, dx = t_kx * g.conv.dkx;
+            const unsigned tapoff = (unsigned)((dy * g.conv.Win + dx) * g.conv.Cin + min(t_ci, g.conv.Cin - 8));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                bool ok = a_ok[i] && kok;
+                unsigned off = a_base[i] + tapoff;
+                if (need_bounds) {
+                    const int sy = a_y[i] + dy, sx = a_x[i] + dx;
+                    const bool in = sy >= 0 && sy < g.conv.Hin && sx >= 0 && sx < g.conv.Win;
+                    ok = ok && in;
+                    off = in ? off : 0u;
+                }
+                glds16(rsA, (ok && live) ? off * 2u : BUF_OOB, As, i);
+            }
+            if (live) ctap_advance(g.conv, a_ct, BK, tap_wraps);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(rsA, (a_ok[i] && kok) ? (a_base[i] + kc) * 2u : BUF_OOB, As, i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB, Bs, i);
+    };
     auto store_tiles = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
         __bf16* As = As0 + buf * BM * LD;
         __bf16* Bs = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[(tid / KQ + i * RPI) * LD + kq * 8]) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[(tid / KQ + i * RPI) * LD + kqs * 8]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[(tid / KQ + i * RPI) * LD + kq * 8]) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[(tid / KQ + i * RPI) * LD + kqs * 8]) = rb[i];
     };
 
     f32x4 acc[TM][TN];
@@ -216,14 +271,16 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     auto mfma_tile = [&](int buf) {
         const __bf16* As = As0 + buf * BM * LD;
         const __bf16* Bs = Bs0 + buf * BN * LD;
-        const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15), kg = (lane >> 4) * 8;
+        const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15);
+        const int sw = SWZ ? nt16_swz<BK>(lane & 15) : 0;       // the fragment rows differ from lane & 15 by multiples of 16
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
+            const int kg = ((ks * 4 + (lane >> 4)) ^ sw) * 8;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + ks * 32 + kg]);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + kg]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + ks * 32 + kg]);
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + kg]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,6 +288,40 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     };
+    if constexpr (GL && NBUF == 3) {
+        // ring of three: tile kt+2 is issued before the MFMAs of tile kt; the wait before the (raw) barrier only retires tile kt+1's
+        // NA + NB loads -- tile kt+2 stays in flight across it (a __syncthreads() would drain it: it waits vmcnt(0) with LDS-DMA pending).
+        // Buffer (kt+2) % 3 was last read in step kt-1, behind that step's barrier.
+        glds_tiles(0, 0);
+        glds_tiles(BK, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int bcur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int bnext2 = bcur == 0 ? 2 : bcur - 1;       // (kt + 2) % 3
+            glds_tiles((kt + 2) * BK, bnext2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(bcur);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+            __builtin_amdgcn_s_barrier();
+            bcur = bcur == 2 ? 0 : bcur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue re-uses the operand buffers
+        __syncthreads();
+    } else if constexpr (GL) {
+        glds_tiles(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            glds_tiles((kt + 1) * BK, (kt + 1) & 1);     // the other buffer: last read one iteration ago, behind the previous barrier
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
     load_tiles(0, ra, rb);
     store_tiles(0, ra, rb);
     __syncthreads();
@@ -246,6 +337,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
             store_tiles((kt + 1) & 1, ra, rb);      // the other buffer: last read one iteration ago, behind the previous barrier
             __syncthreads();
         }
+    }
     }
 
     // epilogue.  The accumulators go through LDS (the operand buffers are free now) so that everything that touches HBM is a
@@ -536,7 +628,10 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     static const int bk_env = [] { const char* e = getenv("SPAIR_NT16_BK"); return e ? atoi(e) : 0; }();
     if (g.n_ktab > 0 && (!conv || g.n_ktab > 64 || g.n_ktab * 64 != g.K || (g.conv.Cin & 63))) return SPAIR_ERR_SHAPE;
     const int bk = g.n_ktab > 0 ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
-    size_t lds = (size_t)2 * (128 + 128) * (bk + 8) * 2;
+    static const int swz = [] { const char* e = getenv("SPAIR_NT16_SWZ"); return e ? atoi(e) : 1; }();      // 0: padded rows (A/B timing)
+    static const int glds = [] { const char* e = getenv("SPAIR_NT16_GLDS"); return e ? atoi(e) : 1; }();    // 0: operands staged through registers
+    const int nbuf = (swz && glds && bk == 32) ? 3 : 2;
+    size_t lds = std::max((size_t)nbuf * (128 + 128) * (bk + (swz ? 0 : 8)) * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
     if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
@@ -547,15 +642,21 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
         grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.xcd_tiles_n);
         grid.y = 1;
     }
-#define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
+#define NT16_LAUNCH_SW(AC, C16, ST, BKV, SW, GLV)                                                               \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV>),              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV, SW, GLV>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV>), grid, dim3(256), lds, s, g);                     \
+        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV, SW, GLV>), grid, dim3(256), lds, s, g);            \
+    } while (0)
+#define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
+    do {                                                                                                          \
+        if (swz && glds) NT16_LAUNCH_SW(AC, C16, ST, BKV, true, true);                                            \
+        else if (swz) NT16_LAUNCH_SW(AC, C16, ST, BKV, true, false);                                              \
+        else NT16_LAUNCH_SW(AC, C16, ST, BKV, false, false);                                                      \
     } while (0)
 #define NT16_LAUNCH(AC, C16, ST)                                                                                 \
     do { if (bk == 32) NT16_LAUNCH_BK(AC, C16, ST, 32); else NT16_LAUNCH_BK(AC, C16, ST, 64); } while (0)
@@ -575,6 +676,7 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     else { if (g.c_bf16) NT16_LAUNCH(false, true, false); else NT16_LAUNCH(false, false, false); }
 #undef NT16_LAUNCH
 #undef NT16_LAUNCH_BK
+#undef NT16_LAUNCH_SW
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
