@@ -260,6 +260,85 @@ def stn(image, z_where, output_dims, device=None, inverse=False):
     return _StnFn.apply(image, z_where, int(output_dims[0]), bool(inverse))
 
 
+def _topology_conv_args(layer):
+    return int(layer.get('filters', layer.get('out_channels'))), int(layer['kernel_size']), int(layer['stride'])
+
+
+class ObjectConvEncoder(Module):
+    """Convolutional glimpse encoder from ``cfg.CONV_OBJECT_ENCODER_TOPOLOGY`` (config.py:15-20), the variant the reference sketches in
+    models.py:606-631 but never makes runnable (``Linear(123, ..)`` / ``self.linear`` undefined).  Opt-in and PARITY UNPINNED: the layer
+    sizes follow the topology's own comments (28 -> 13 -> 6 -> 2 -> 2, 32 channels), flattened in (C, H, W) order into ``out``.
+    ``forward`` runs every convolution as the implicit GEMM of spair_gemm_nt_conv (exact fp32 MFMA mode) and the head through
+    spair_gemm_nt; inference helper (no autograd graph) -- the training step uses the MLP encoder inside the fused chain."""
+
+    def __init__(self, input_size, output_size, topology=None):
+        super().__init__()
+        n_prev, h, w = input_size
+        topo = [dict(t) for t in (topology if topology is not None else cfg.CONV_OBJECT_ENCODER_TOPOLOGY)]
+        net = OrderedDict()
+        self.shapes = [(n_prev, h, w)]
+        for i, layer in enumerate(topo):
+            f, k, st = _topology_conv_args(layer)
+            net['conv_%d' % i] = Conv2d(n_prev, f, kernel_size=k, stride=st)
+            net['act_%d' % i] = ReLU()
+            n_prev, h, w = f, (h - k) // st + 1, (w - k) // st + 1
+            self.shapes.append((n_prev, h, w))
+        self.conv = Sequential(net)
+        self.out = Linear(n_prev * h * w, output_size)
+
+    def forward(self, x):
+        h = x.detach().float().permute(0, 2, 3, 1).contiguous()
+        for m in self.conv:
+            if isinstance(m, Conv2d):
+                h = _hip_conv_nhwc(h, m.weight, m.bias, int(m.stride[0]), relu=True)       # every conv is followed by a ReLU
+        flat = h.permute(0, 3, 1, 2).contiguous().flatten(start_dim=1)
+        return _hip_linear(flat, self.out.weight, self.out.bias)
+
+
+class ObjectConvDecoder(Module):
+    """The mirrored decoder (models.py:633-665, equally non-functional there): ``Linear`` to the encoder's last feature map, then transposed
+    convolutions of the reversed topology, ``output_padding`` chosen so that the encoder's sizes are retraced (2 -> 2 -> 6 -> 13 -> 28),
+    no activation after the last one.  Each ConvTranspose2d runs on the HIP implicit-GEMM kernel as a stride-1 convolution of the
+    zero-upsampled, (k-1)-padded input with the flipped kernel.  Opt-in, parity unpinned, inference helper."""
+
+    def __init__(self, input_size, output_channel, encoder_shapes=None, topology=None):
+        super().__init__()
+        topo = [dict(t) for t in (topology if topology is not None else cfg.CONV_OBJECT_ENCODER_TOPOLOGY)]
+        if encoder_shapes is None:
+            encoder_shapes = ObjectConvEncoder([output_channel, cfg.OBJECT_SHAPE[0], cfg.OBJECT_SHAPE[1]], 1, topo).shapes
+        self.top = encoder_shapes[-1]
+        self.inp = Linear(input_size, self.top[0] * self.top[1] * self.top[2])
+        net = OrderedDict()
+        n_prev, h = self.top[0], self.top[1]
+        for i, layer in enumerate(reversed(topo)):
+            _, k, st = _topology_conv_args(layer)
+            target = encoder_shapes[len(topo) - 1 - i]
+            f = target[0]
+            op = target[1] - ((h - 1) * st + k)
+            assert 0 <= op < max(st, 1) or (st == 1 and op == 0), "topology cannot be mirrored"
+            net['conv_transposed_%d' % i] = nn.ConvTranspose2d(n_prev, f, kernel_size=k, stride=st, output_padding=op)
+            if i < len(topo) - 1:
+                net['act_%d' % i] = ReLU()
+            n_prev, h = f, target[1]
+        self.conv = Sequential(net)
+
+    def forward(self, z):
+        n = z.shape[0]
+        h = _hip_linear(z.detach().float(), self.inp.weight, self.inp.bias).view(n, *self.top).permute(0, 2, 3, 1).contiguous()
+        mods = list(self.conv)
+        for i, m in enumerate(mods):
+            if not isinstance(m, nn.ConvTranspose2d):
+                continue
+            k, st, op = int(m.kernel_size[0]), int(m.stride[0]), int(m.output_padding[0])
+            B, H, W, C = h.shape
+            up = torch.zeros(B, (H - 1) * st + 1 + 2 * (k - 1) + op, (W - 1) * st + 1 + 2 * (k - 1) + op, C, device=h.device)
+            up[:, k - 1:k - 1 + (H - 1) * st + 1:st, k - 1:k - 1 + (W - 1) * st + 1:st, :] = h
+            w = m.weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()          # [Cin,Cout,k,k] -> conv weight [Cout,Cin,k,k], flipped
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], ReLU)
+            h = _hip_conv_nhwc(up, w, m.bias, 1, relu=relu)
+        return h.permute(0, 3, 1, 2).contiguous()
+
+
 def to_C_H_W(t):
     assert t.shape[1] == t.shape[2] and t.shape[3] != t.shape[2], 'are you sure this tensor is in [B, H, W, C] format?'
     return t.permute(0, 3, 1, 2)

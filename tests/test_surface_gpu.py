@@ -133,3 +133,27 @@ def test_stale_activations_raise_and_engines_are_cached():
     loss3 = m(x, 1001, noise=noise)[0]
     loss3.backward()
     assert torch.allclose(m.flat_gradients(), g1, rtol=1e-4, atol=1e-5)
+
+
+def test_conv_object_encoder_decoder_variant():
+    """the opt-in convolutional glimpse encoder / decoder built from CONV_OBJECT_ENCODER_TOPOLOGY (config.py:15-20; the
+    reference's own classes, models.py:606-665, cannot run) -- HIP implicit-GEMM forward against torch's fp32 CPU conv / conv_transpose on
+    the same weights.  Parity with the reference is unpinned by construction."""
+    from spair_pytorch_amd.modules import ObjectConvDecoder, ObjectConvEncoder
+    torch.manual_seed(1)
+    enc = ObjectConvEncoder([1, 28, 28], 100)
+    assert enc.shapes == [(1, 28, 28), (32, 13, 13), (32, 6, 6), (32, 2, 2), (32, 2, 2)]
+    x = torch.rand(9, 1, 28, 28)
+    with torch.no_grad():
+        ref = enc.out(enc.conv(x).flatten(start_dim=1))
+    out = enc.cuda().forward(x.cuda())
+    assert out.shape == (9, 100)
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dec = ObjectConvDecoder(50, 2)
+    z = torch.randn(9, 50)
+    with torch.no_grad():
+        refd = dec.conv(dec.inp(z).view(9, *dec.top))
+    assert refd.shape == (9, 2, 28, 28)
+    outd = dec.cuda().forward(z.cuda())
+    assert outd.shape == refd.shape
+    assert np.abs(outd.cpu().numpy() - refd.numpy()).max() <= 2e-5 * max(1.0, float(refd.abs().max()))

@@ -27,13 +27,13 @@ for k in sorted(set(f) | set(w)):
 for tot, k, calls, rd, wr in sorted(rows, reverse=True)[:24]:
     print("%-46s %8d %12.1f %12.1f %12.1f" % (k[:46], calls, rd, wr, tot))
 
-if len(sys.argv) > 3:      # optional: the four kernels bench.py prices, as JSON
+if len(sys.argv) > 3:      # optional: the four kernels bench.py prices, as JSON (matched by substring: template arguments / mangling vary)
     import json
-    names = {"chain_bwd": "k_chain_bwd", "chain_fwd": "void k_chain_fwd<true>", "render_fwd": "void k_render_fwd<true>", "render_bwd": "void k_render_bwd<true>"}
+    names = {"chain_bwd": "k_chain_bwd", "chain_fwd": "k_chain_fwd", "render_fwd": "k_render_fwd", "render_bwd": "k_render_bwd"}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1`; "
                      "FETCH_SIZE doubled (gfx950), per launch"}
     for key, kn in names.items():
         for tot, k, calls, rd, wr in rows:
-            if k == kn:
-                out[key] = {"read_MB": round(rd, 1), "write_MB": round(wr, 1)}
+            if kn in k:
+                out[key] = {"read_MB": round(rd, 1), "write_MB": round(wr, 1), "kernel": k[:60]}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
