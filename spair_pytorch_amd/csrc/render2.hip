@@ -295,6 +295,212 @@ __global__ __launch_bounds__(256) void k_render_fwd2(const float* __restrict__ S
     if (tid == 0) bce_partial[blockIdx.x] = bce;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_render_fwd3: the same composite loop as k_render_fwd2 with the per-tile preparation cut from ~930 to ~450 instructions per wave
+// (it outweighed the composite loop itself):
+//   * the tile cull uses v_rcp and a small safety margin (false positives only cost zero weights); the exact inverse-affine parameters
+//     (IEEE divisions, as the backward computes them) are formed once per surviving object by the first lanes of wave 0;
+//   * BOTH tap tables (16 tile columns, 16 tile rows per object) are built once per tile pass by all 256 threads; the per-strip cull,
+//     the staged row range and the LDS slot of every object then follow from the y table in a handful of instructions per wave, and
+//     there is no per-chunk y table any more: the composite loop adds a per-object (scalar) slot base to the tabulated row index;
+//   * the per-strip object list is a 64-bit ballot in scalar registers, walked with s_ff1.
+// ---------------------------------------------------------------------------------------------
+#ifndef RF3_ROWS
+#define RF3_ROWS 48       // sprite rows a wave stages per chunk (>= P)
+#endif
+__host__ __device__ inline int rf3_shared_bytes() { return RF_TC * 32 + 2 * RF_TC * 256 + 512 + 64 + 16; }
+__host__ __device__ inline int rf3_wave_bytes(int P, int texb) { return RF3_ROWS * P * texb; }
+
+template <bool S16, int PT, int AC, int IP2>
+__global__ __launch_bounds__(256) void k_render_fwd3(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
+                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
+                                                     const float* __restrict__ x, float* __restrict__ recon, float2* __restrict__ aux,
+                                                     float* __restrict__ bce_partial, int B, int HW, int I, int Prt) {
+    extern __shared__ __attribute__((aligned(16))) char sm3[];
+    constexpr int TEXB = S16 ? 4 : 8;                 // bytes per (grey, alpha) texel
+    constexpr int ES = S16 ? 2 : 4;                   // bytes per sprite element
+    const int P = PT ? PT : Prt;
+    const int ROWB = P * TEXB;
+    const int POOL = RF3_ROWS * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RfCand* cand = reinterpret_cast<RfCand*>(sm3);
+    float4* xtab = reinterpret_cast<float4*>(sm3 + RF_TC * 32);                    // [RF_TC][16] {tap byte offset in the row, w0, w1, pres}
+    float4* ytab = xtab + RF_TC * 16;                                              // [RF_TC][16] {first tap row, w0, w1, pres * depth}
+    unsigned short* tl = reinterpret_cast<unsigned short*>(ytab + RF_TC * 16);
+    int* cnt = reinterpret_cast<int*>(tl + 256);
+    float* red = reinterpret_cast<float*>(cnt + 16);
+    char* pool = sm3 + rf3_shared_bytes() + wave * rf3_wave_bytes(P, TEXB);
+    const unsigned pool_off = (unsigned)(pool - sm3);
+    const float inv_I = 1.f / (float)I;
+
+    const int tiles_x = (I + RT - 1) / RT, tiles = tiles_x * tiles_x;
+    int b, tile;
+    if ((B & 7) == 0) {   // XCD-aware: blocks id, id+8, ... share an XCD (round-robin dispatch)
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = (j / tiles) * 8 + xcd;
+        tile = j % tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x % tiles;
+    }
+    const int tx0 = (tile % tiles_x) * RT, ty0 = (tile / tiles_x) * RT;
+    const int lx = lane & 15, ly4 = lane >> 4;
+    const int px = tx0 + lx, py = ty0 + 4 * wave + ly4;
+    const bool inside = px < I && py < I;
+    const int tx1 = min(tx0 + RT, I) - 1, ty1 = min(ty0 + RT, I) - 1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const char* Sb = reinterpret_cast<const char*>(S);
+    // this pixel's target value: wanted only in the epilogue, fetched now
+    const size_t pi = ((size_t)b * I + min(py, I - 1)) * I + min(px, I - 1);
+    const float xv = x[pi];
+    // base coordinates of the tile's first / last column and row (for the cull)
+    float gd;
+    const float bx0 = rf_base<AC, IP2>(tx0, I, inv_I), bx1 = rf_base<AC, IP2>(tx1, I, inv_I);
+    const float by0 = rf_base<AC, IP2>(ty0, I, inv_I), by1 = rf_base<AC, IP2>(ty1, I, inv_I);
+
+    float num = 0.f, den = 0.f;
+    for (int k0 = 0; k0 < HW; k0 += 256) {
+        // ---- 1. cull 256 objects against the tile: reciprocal instead of the IEEE divisions, bounds widened by 1e-2 texel
+        {
+            const int k = k0 + tid;
+            bool hit = false;
+            if (k < HW) {
+                const int r = k * B + b;
+                const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
+                const float ax = __builtin_amdgcn_rcpf(nb.z), ay = __builtin_amdgcn_rcpf(nb.w);
+                const float bx = -(2.f * nb.x - 1.f) * ax, by = -(2.f * nb.y - 1.f) * ay;
+                const float lo = -1.01f, hi = (float)P + 0.01f;
+                hit = src_from_base(ax, bx, bx1, P, AC, gd) > lo && src_from_base(ax, bx, bx0, P, AC, gd) < hi &&
+                      src_from_base(ay, by, by1, P, AC, gd) > lo && src_from_base(ay, by, by0, P, AC, gd) < hi;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += cnt[w];
+            if (hit) tl[base + __popcll(bal & below)] = (unsigned short)tid;
+        }
+        __syncthreads();
+        const int nt = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        for (int p0 = 0; p0 < nt; p0 += RF_TC) {
+            const int ntc = min(RF_TC, nt - p0);
+            // ---- 2. exact parameters of the pass's objects (the same expressions as the backward's)
+            if (tid < ntc) {
+                const int kk = k0 + tl[p0 + tid];
+                const int r = kk * B + b;
+                const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
+                const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
+                RfCand c;
+                c.ax = 1.f / nb.z; c.bx = -tx / nb.z; c.ay = 1.f / nb.w; c.by = -ty / nb.w;
+                c.pres = pres[(size_t)r * ld_pd];
+                c.pd = c.pres * depth[(size_t)r * ld_pd];
+                c.row = r; c.pad = 0;
+                cand[tid] = c;
+            }
+            __syncthreads();
+            // ---- 3. tap tables: 16 tile columns and 16 tile rows per object
+            for (int e = tid; e < ntc * 32; e += 256) {
+                const int c = e >> 5, yaxis = (e >> 4) & 1, idx = e & 15;
+                const RfCand cd = cand[c];
+                const int pos = min((yaxis ? ty0 : tx0) + idx, I - 1);
+                float w0, w1;
+                int i0;
+                rf_axis(src_from_base(yaxis ? cd.ay : cd.ax, yaxis ? cd.by : cd.bx, rf_base<AC, IP2>(pos, I, inv_I), P, AC, gd), P, i0, w0, w1);
+                if (yaxis) ytab[c * 16 + idx] = make_float4(__int_as_float(i0), w0, w1, cd.pd);
+                else xtab[c * 16 + idx] = make_float4(__uint_as_float((unsigned)(i0 * TEXB)), w0, w1, cd.pres);
+            }
+            __syncthreads();
+            // ---- 4. this wave's strip: which objects reach it, which sprite rows they need, where those rows go
+            bool hs = false;
+            int bytes = 0, v0 = 0;
+            unsigned goff = 0;
+            if (lane < ntc) {
+                float4* ye = ytab + lane * 16 + 4 * wave;
+                int lo = P, hi = -1;
+                bool cv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 e = ye[q];
+                    cv[q] = (e.y + e.z) > 0.f && (ty0 + 4 * wave + q) < I;
+                    const int i0 = __float_as_int(e.x);
+                    lo = cv[q] ? min(lo, i0) : lo;
+                    hi = cv[q] ? max(hi, i0 + 1) : hi;
+                }
+                hs = hi >= 0;
+                if (hs) {
+                    v0 = lo;
+                    bytes = (hi - lo + 1) * ROWB;
+                    goff = (unsigned)cand[lane].row * (unsigned)(ld_s * ES) + (unsigned)(lo * ROWB);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (!cv[q]) reinterpret_cast<int*>(ye + q)[0] = lo;          // zero-weight rows keep their taps inside the staged rows
+                }
+            }
+            const int cum = rf_scan_incl(bytes, lane);
+            const unsigned sbase = pool_off + (unsigned)(cum - bytes) - (unsigned)(v0 * ROWB);     // + tabulated row * ROWB = first tap's row
+            unsigned long long todo = __ballot(hs);
+            int cbase = 0;
+            while (todo) {
+                const bool fits = ((todo >> lane) & 1ull) && (cum - cbase) <= POOL;
+                const unsigned long long chunk = __ballot(fits);                     // a prefix of `todo`: cum is monotone
+                // stage the chunk's sprite rows
+                for (unsigned long long m = chunk; m; m &= m - 1) {
+                    const int c = __builtin_ctzll(m);
+                    const unsigned so = __builtin_amdgcn_readlane(goff, c);
+                    const int nb_ = __builtin_amdgcn_readlane(bytes, c);
+                    const int slot = __builtin_amdgcn_readlane(cum, c) - nb_ - cbase;
+                    for (int o0 = 0; o0 < nb_; o0 += 1024) {
+                        if (o0 + lane * 16 < nb_) {
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Sb + (size_t)so + o0 + lane * 16),
+                                                             (__attribute__((address_space(3))) void*)(pool + slot + o0), 16, 0, 0);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // composite
+                for (unsigned long long m = chunk; m; m &= m - 1) {
+                    const int c = __builtin_ctzll(m);
+                    const unsigned sb = __builtin_amdgcn_readlane(sbase, c) - (unsigned)cbase;
+                    const float4 xi = xtab[c * 16 + lx];
+                    const float4 yi = ytab[c * 16 + 4 * wave + ly4];
+                    const char* tp = sm3 + (__float_as_uint(xi.x) + (unsigned)__float_as_int(yi.x) * (unsigned)ROWB + sb);
+                    const float2 t00 = rf_tap<S16>(tp), t01 = rf_tap<S16>(tp + TEXB), t10 = rf_tap<S16>(tp + ROWB), t11 = rf_tap<S16>(tp + ROWB + TEXB);
+                    const float w00 = yi.y * xi.y, w01 = yi.y * xi.z, w10 = yi.z * xi.y, w11 = yi.z * xi.z;
+                    const float pd = yi.w;
+                    float g = w00 * t00.x, a = w00 * t00.y, mm = w00 * fmaxf(t00.y * pd, 0.01f);
+                    g = fmaf(w01, t01.x, g); a = fmaf(w01, t01.y, a); mm = fmaf(w01, fmaxf(t01.y * pd, 0.01f), mm);
+                    g = fmaf(w10, t10.x, g); a = fmaf(w10, t10.y, a); mm = fmaf(w10, fmaxf(t10.y * pd, 0.01f), mm);
+                    g = fmaf(w11, t11.x, g); a = fmaf(w11, t11.y, a); mm = fmaf(w11, fmaxf(t11.y * pd, 0.01f), mm);
+                    a *= xi.w;
+                    num += g * a * (mm + 1e-9f);
+                    den += mm;
+                }
+                const int last = 63 - __builtin_clzll(chunk);
+                cbase = __builtin_amdgcn_readlane(cum, last);
+                todo &= ~chunk;
+            }
+            __syncthreads();
+        }
+        if (k0 + 256 < HW) __syncthreads();      // the next cull rewrites cnt[0..3] / tl
+    }
+    float bce = 0.f;
+    if (inside) {
+        const float D = den + (float)HW * 1e-9f;   // every object adds 1e-9 (models.py:527)
+        const float invD = 1.f / D;
+        const float pre = num * invD;
+        const float r = fminf(fmaxf(pre, 0.f), 1.f);
+        recon[pi] = r;
+        // torch BCE: log clamped at -100; backward denominator max(r(1-r), 1e-12)
+        bce = -(xv * fmaxf(logf(r), -100.f) + (1.f - xv) * fmaxf(logf(1.f - r), -100.f));
+        if (aux) {
+            const float gr = (pre >= 0.f && pre <= 1.f) ? (r - xv) / fmaxf(r * (1.f - r), 1e-12f) : 0.f;
+            aux[pi] = make_float2(gr * invD, pre);
+        }
+    }
+    bce = block_reduce_sum_256(bce, red);
+    if (tid == 0) bce_partial[blockIdx.x] = bce;
+}
+
 // SPAIR_ERR_UNSUPPORTED: the caller falls back to the first-generation kernel
 int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
                 float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, int s_bf16, hipStream_t s) {
@@ -302,11 +508,38 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
     if ((P * texb) % 16 != 0 || ((size_t)ld_s * es) % 16 != 0 || P > RF_ROWS || P < 2 || P > 255) return SPAIR_ERR_UNSUPPORTED;
     if ((unsigned long long)B * HW * ld_s * es >= (1ull << 32)) return SPAIR_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(S) & 15) != 0) return SPAIR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)rf_shared_bytes() + 4 * (size_t)rf_wave_bytes(P, texb);
-    if (lds > 160 * 1024) return SPAIR_ERR_UNSUPPORTED;
+    static const int gen = getenv("SPAIR_RENDER_FWD_GEN") ? atoi(getenv("SPAIR_RENDER_FWD_GEN")) : 3;      // 2: k_render_fwd2 (A/B timing)
     const int t = (I + RT - 1) / RT;
     const dim3 grid(B * t * t), block(256);
     float2* aux2 = reinterpret_cast<float2*>(aux);
+    if (gen == 3 && P <= RF3_ROWS) {
+        const size_t lds3 = (size_t)rf3_shared_bytes() + 4 * (size_t)rf3_wave_bytes(P, texb);
+        if (lds3 > 160 * 1024) return SPAIR_ERR_UNSUPPORTED;
+        const bool ip2 = (I & (I - 1)) == 0;
+#define RF3_LAUNCH(S16_, PT_, AC_, IP2_)                                                                                                \
+    do {                                                                                                                                \
+        if (lds3 > 64 * 1024 &&                                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_fwd3<S16_, PT_, AC_, IP2_>),                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)                                   \
+            return SPAIR_ERR_LAUNCH;                                                                                                    \
+        hipLaunchKernelGGL((k_render_fwd3<S16_, PT_, AC_, IP2_>), grid, block, lds3, s, S, ld_s, nbox, pres, depth, ld_pd, x, recon,     \
+                           aux2, bce_partial, B, HW, I, P);                                                                             \
+    } while (0)
+        if (s_bf16) {
+            if (P == 28 && !ac && ip2) RF3_LAUNCH(true, 28, 0, 1);
+            else if (ac) RF3_LAUNCH(true, 0, 1, 0);
+            else RF3_LAUNCH(true, 0, 0, 0);
+        } else {
+            if (P == 28 && !ac && ip2) RF3_LAUNCH(false, 28, 0, 1);
+            else if (ac) RF3_LAUNCH(false, 0, 1, 0);
+            else RF3_LAUNCH(false, 0, 0, 0);
+        }
+#undef RF3_LAUNCH
+        SPAIR_CHECK_LAUNCH();
+        return SPAIR_OK;
+    }
+    const size_t lds = (size_t)rf_shared_bytes() + 4 * (size_t)rf_wave_bytes(P, texb);
+    if (lds > 160 * 1024) return SPAIR_ERR_UNSUPPORTED;
 #define RF_LAUNCH(S16_, PT_)                                                                                                            \
     do {                                                                                                                                \
         if (lds > 64 * 1024 &&                                                                                                          \
