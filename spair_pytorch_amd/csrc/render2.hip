@@ -643,6 +643,13 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
     // (sample, object): consecutive workgroup ids walk the samples, so with B % 8 == 0 every object of sample b lands on XCD b % 8
     const int b = blockIdx.x, k = blockIdx.y;
     const int r = k * B + b;
+    // the sprite's first 256 16-byte pieces (all of it at P = 28) are requested before anything else: their latency overlaps the
+    // latency of the parameter loads and the geometry arithmetic instead of following it
+    const char* Sr = reinterpret_cast<const char*>(S) + (size_t)r * ld_s * 2;
+    const int ppr = P >> 2, npieces = P * ppr;                      // 16-byte pieces (4 texels) per row / per sprite
+    uint4 q_first[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q_first[i] = *reinterpret_cast<const uint4*>(Sr + (size_t)min(64 * i + lane, npieces - 1) * 16);
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
     const float2* auxb = aux + (size_t)b * I * I;
@@ -661,12 +668,11 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
     PY0 = __builtin_amdgcn_readfirstlane(PY0); PY1 = __builtin_amdgcn_readfirstlane(PY1);
     // ---- sprite -> LDS (zero border), adjoint tiles zeroed once (later chunks leave finite values under zero weights)
     {
-        const char* Sr = reinterpret_cast<const char*>(S) + (size_t)r * ld_s * 2;
-        const int ppr = P >> 2, npieces = P * ppr;                      // 16-byte pieces (4 texels) per row / per sprite
         for (int p0 = 0; p0 < npieces; p0 += 256) {
             uint4 q[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const uint4*>(Sr + (size_t)min(p0 + 64 * i + lane, npieces - 1) * 16);
+            for (int i = 0; i < 4; ++i)
+                q[i] = p0 == 0 ? q_first[i] : *reinterpret_cast<const uint4*>(Sr + (size_t)min(p0 + 64 * i + lane, npieces - 1) * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = p0 + 64 * i + lane;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 const float g_sy = d_g * eg + dap * ea + d_m * em;
                 g_tx += g_sx; g_xs = fmaf(g_sx, xe.z, g_xs);           // scaled by cgx / cgy after the loops
                 g_ty += g_sy; g_ys = fmaf(g_sy, in.ye.z, g_ys);
-                char* q = smb + adj0 + (unsigned)(it * RPI * RB2_ADJ_LD * 2);
+                char* q = smb + adj0 + (unsigned)(it * RPI * RB2_ADJ_LD * 2);      // (pairing columns into 4-byte stores by DPP was measured: 263 -> 325 us)
                 *reinterpret_cast<__bf16*>(q) = (__bf16)d_g;
                 *reinterpret_cast<__bf16*>(q + RB2_ROWS * RB2_ADJ_LD * 2) = (__bf16)d_a;
                 *reinterpret_cast<__bf16*>(q + 2 * RB2_ROWS * RB2_ADJ_LD * 2) = (__bf16)d_m;
