@@ -349,8 +349,16 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
+#ifdef CHAIN_SUBSTAMP
+            asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));      // MFMA results complete
+            CH_STAMP();
+#endif
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
             wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
+#ifdef CHAIN_SUBSTAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            CH_STAMP();
+#endif
         } else {
             copy_rows_b16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
         }
