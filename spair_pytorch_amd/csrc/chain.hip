@@ -310,10 +310,12 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         prefetch(min(t + 1, T - 1), tid);
         CH_STAMP();
         // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread
-        for (int idx = tid; idx < MT * (KC / 4); idx += NTH) {
+        // (only the wavefront's nc live rows: the tile's other rows keep whatever finite values an earlier wavefront left -- their
+        //  outputs are never stored)
+        for (int idx = tid; idx < nc * (KC / 4); idx += NTH) {
             const int row = idx / (KC / 4), c4 = (idx - row * (KC / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nc && c4 < F + CTX) {
+            if (c4 < F + CTX) {
                 if (c4 < F) {
                     v = *reinterpret_cast<const float4*>(&feat_sh[row][c4]);
                 } else {
@@ -385,28 +387,36 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             *reinterpret_cast<bf16x4*>(&XtZ[row * LD_XT + i]) = o;
             if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xz) + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = o;
         }
-        if (tid < nc) {
-            const int h = row_h[tid], w = row_w[tid];
-            const size_t r = row_r[tid];
-            float eps[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) eps[k] = noise_sh[tid][k];
-            const BoxFwd o = box_forward(&Ost[tid * LD_O + NP], eps, H, h, w);
-            float* st = P.stat + r * SP_LDSTAT;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                st[ST_MU_BOX + k] = o.mu[k];
-                st[ST_SD_BOX + k] = o.sd[k];
-                rec_cur[tid][k] = o.box[k];
-                nb_sh[tid][k] = o.nbox[k];
-                XtZ[tid * LD_XT + NP + k] = (__bf16)o.box[k];
-                XtO[tid * LD_XT + NP + k] = (__bf16)o.box[k];
-                P.rec[r * L.ld_rec + k] = o.box[k];
-                reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + k] = (__bf16)o.box[k];
-                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + k] = (__bf16)o.box[k];
-                P.nbox[r * 4 + k] = o.nbox[k];
-                P.z_where[(((size_t)b * 4 + k) * G + h) * G + w] = o.nbox[k];
+        // one latent per lane: threads 64 .. 64 + 4*nc (wave 1, so that wave 0 is free for the copy loop above); lane k of a row owns
+        // z_k -> (cell_y, cell_x, height, width)[k] -> box / nbox element k ^ 1
+        if (tid >= 64 && tid < 64 + 4 * nc) {
+            const int row = (tid - 64) >> 2, k = (tid - 64) & 3, o = k ^ 1;
+            const int h = row_h[row], w = row_w[row];
+            const size_t r = row_r[row];
+            const float* lat = &Ost[row * LD_O + NP];
+            const float mu = freeze_val(H.wheel, lat[k]);
+            const float sd = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(lat[4 + k])));
+            const float sg = sigmoidf_(clamp10(mu + sd * noise_sh[row][k]));
+            float bv, nv;                               // box_forward (cell_math.h), element by element
+            if (k < 2) {
+                bv = (H.max_yx - H.min_yx) * sg + H.min_yx;                         // cell_y (k = 0), cell_x (k = 1)
+                nv = H.cell_over_img * (bv + (float)(k == 0 ? h : w));              // yt, xt
+            } else {
+                bv = (H.max_hw - H.min_hw) * sg + H.min_hw;                         // height (k = 2), width (k = 3)
+                nv = bv * H.anchor / H.img;                                         // ys, xs
             }
+            float* st = P.stat + r * SP_LDSTAT;
+            st[ST_MU_BOX + k] = mu;
+            st[ST_SD_BOX + k] = sd;
+            rec_cur[row][o] = bv;
+            nb_sh[row][o] = nv;
+            XtZ[row * LD_XT + NP + o] = (__bf16)bv;
+            XtO[row * LD_XT + NP + o] = (__bf16)bv;
+            P.rec[r * L.ld_rec + o] = bv;
+            reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
+            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
+            P.nbox[r * 4 + o] = nv;
+            P.z_where[(((size_t)b * 4 + o) * G + h) * G + w] = nv;
         }
         lds_barrier();
         CH_STAMP();
@@ -578,6 +588,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         CH_STAMP();
+        // this row's presence noise, read now: the pres stage below shares its barrier interval with park(), which overwrites noise_sh
+        const float u_pres_reg = noise_sh[min(tid, MT - 1)][4 + A_ + 1];
         if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 1>(Hb, LD_H, nullptr, 0, a.w[CW_OBJ2], pipe, acc, wave, lane);
@@ -591,13 +603,13 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
             const size_t r = row_r[tid];
-            const float u = noise_sh[tid][4 + A_ + 1];
-            const float pres = pres_forward(Ost[tid * LD_O], u, H);
+            const float pres = pres_forward(Ost[tid * LD_O], u_pres_reg, H);
             rec_cur[tid][REC - 1] = pres;
             P.rec[r * L.ld_rec + REC - 1] = pres;
             P.z_pres[((size_t)b * G + h) * G + w] = pres;
         }
-        lds_barrier();
+        // (no barrier: nothing below reads what the pres threads write, and they no longer read noise_sh; the next wavefront's row-setup
+        //  barrier orders all of it before S0)
         park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
         if (tid < MB_TILES * 4) P.mbits[((size_t)b * T + t) * (MB_TILES * 4) + tid] = mbf_sh[tid];     // one coalesced 2 KB store
         CH_STAMP();
@@ -1063,25 +1075,32 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + i]) = o;
             if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dOb) + (size_t)row_r[row] * L.ld_ob + i) = o;
         }
-        if (tid < MT) {
-            float dlat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (tid < nc) {
-                const size_t r = row_r[tid];
-                const float* bd = bundle_sh[tid];
+        // one latent per lane (threads 64 .. 64 + 4*MT, wave 1: wave 0 runs the copy loop above): lane k of a row owns z_k, i.e. the
+        // gradients of box / nbox element k ^ 1 and the latent's mean and log-std (box_backward, cell_math.h, element by element)
+        if (tid >= 64 && tid < 64 + 4 * MT) {
+            const int row = (tid - 64) >> 2, k = (tid - 64) & 3, o = k ^ 1;
+            float d_mu = 0.f, d_ls = 0.f;
+            if (row < nc) {
+                const size_t r = row_r[row];
+                const float* bd = bundle_sh[row];
                 const float* st = bd + BD_ST;
-                float gn[4], gb[4], eps[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    gn[k] = gnb[tid][k] + bd[BD_GNB + k];
-                    gb[k] = grec[tid][k] + tailZ[tid][NP + k] + tailO[tid][NP + k];
-                    eps[k] = bd[BD_EB + k];
-                }
-                box_backward(gn, gb, st + ST_MU_BOX, st + ST_SD_BOX, eps, bd + BD_OBL, zp_sh[tid], ks, H, dlat);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + k] = (__bf16)dlat[k];
+                const float gn = gnb[row][o] + bd[BD_GNB + o];
+                const float gb = grec[row][o] + tailZ[row][NP + o] + tailO[row][NP + o];
+                const float mu = st[ST_MU_BOX + k], sd = st[ST_SD_BOX + k], eps = bd[BD_EB + k], lls = bd[BD_OBL + k], zp = zp_sh[row];
+                const float gq = k < 2 ? (gb + gn * H.cell_over_img) * (H.max_yx - H.min_yx) : (gb + gn * H.anchor / H.img) * (H.max_hw - H.min_hw);
+                const float z = mu + sd * eps;
+                const float sg = sigmoidf_(clamp10(z));
+                const float g_z = gq * sg * (1.f - sg) * in10(z);
+                const float m = prior_sh[k], ps = prior_sh[6 + k];
+                d_mu = (g_z + ks * zp * (mu - m) / (ps * ps)) * (1.f - H.wheel);
+                const float g_sd = (g_z * eps + ks * zp * (sd / (ps * ps) - 1.f / sd)) * (1.f - H.wheel);
+                const float sl = sigmoidf_(clamp10(lls));
+                d_ls = g_sd * 2.f * sl * (1.f - sl) * in10(lls);
+                reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + k] = (__bf16)d_mu;
+                reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + 4 + k] = (__bf16)d_ls;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) Aa[tid * LD_H + NP + k] = (__bf16)dlat[k];
+            Aa[row * LD_H + NP + k] = (__bf16)d_mu;
+            Aa[row * LD_H + NP + 4 + k] = (__bf16)d_ls;
         }
         lds_barrier();
         CB_STAMP();

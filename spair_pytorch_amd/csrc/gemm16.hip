@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     constexpr int KQ = BK / 8, RPI = 256 / KQ;                          // 16-byte chunks per tile row; rows staged per pass of the block
     constexpr int NA = BM * KQ / 256, NB = BN * KQ / 256;               // 16-byte chunks per thread: 4 + 4 (BK 64), 2 + 2 (BK 32)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-    constexpr int NBUF = (GL && BK == 32) ? 3 : 2;      // direct-to-LDS at BK 32: a 3-deep ring, two K tiles in flight behind a counted wait
+#ifndef NT16_RING64
+#define NT16_RING64 0     // 1: the 3-deep ring at BK 64 too (96 KB of LDS: one workgroup per CU) -- A/B builds only
+#endif
+    constexpr int NBUF = (GL && (BK == 32 || NT16_RING64)) ? 3 : 2;      // direct-to-LDS at BK 32: a 3-deep ring, two K tiles in flight behind a counted wait
     __bf16* As0 = smem;                       // [NBUF][BM*LD]
     __bf16* Bs0 = smem + NBUF * BM * LD;      // [NBUF][BN*LD]
 
@@ -630,7 +633,7 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     const int bk = g.n_ktab > 0 ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
     static const int swz = [] { const char* e = getenv("SPAIR_NT16_SWZ"); return e ? atoi(e) : 1; }();      // 0: padded rows (A/B timing)
     static const int glds = [] { const char* e = getenv("SPAIR_NT16_GLDS"); return e ? atoi(e) : 1; }();    // 0: operands staged through registers
-    const int nbuf = (swz && glds && bk == 32) ? 3 : 2;
+    const int nbuf = (swz && glds && (bk == 32 || NT16_RING64)) ? 3 : 2;
     size_t lds = std::max((size_t)nbuf * (128 + 128) * (bk + (swz ? 0 : 8)) * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
     if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
