@@ -207,6 +207,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float Ost[MT * LD_O];
     __shared__ __attribute__((aligned(16))) float recs[4][MT][REC];
     __shared__ float nb_sh[MT][4];
+    __shared__ __attribute__((aligned(16))) uint2 gtab[MT][2][PG];          // glimpse source coordinates per (row, axis, index)
     __shared__ int row_r[MT], row_h[MT], row_w[MT], row_cp[MT];
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ short nbr_sh[32 * 32 * 4];
@@ -421,37 +422,62 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         lds_barrier();
         CH_STAMP();
         // ---- z_what: glimpse (modules.py:216-273, border padding) + encoder MLP (models.py:383-391)
+        // The source coordinates are separable: 28 column and 28 row coordinates per cell, tabulated first (one entry per thread:
+        // first tap index | "second tap inside" | "not clipped", fractional weight) instead of being re-derived by every element
+        // (5 coordinate evaluations per 4 elements were ~40 % of the sampling stage's instructions).
+        for (int e = tid; e < nc * 2 * PG; e += NTH) {
+            const int row = e / (2 * PG), rem = e - row * (2 * PG), axis = rem >= PG ? 1 : 0, gi = rem - axis * PG;
+            float cc, mm;
+            stn_src_coord_b(nb_sh[row][axis ? 3 : 2], 2.f * nb_sh[row][axis ? 1 : 0] - 1.f, pbase_sh[gi], a.I, a.ac, true, cc, mm);
+            const int c0 = (int)floorf(cc);
+            gtab[row][axis][gi] = make_uint2((unsigned)c0 | ((c0 + 1) < a.I ? 0x10000u : 0u) | (mm != 0.f ? 0x20000u : 0u), __float_as_uint(cc - (float)c0));
+        }
+        lds_barrier();
+        const float gmult = a.ac ? 0.5f * (float)(a.I - 1) : 0.5f * (float)a.I;      // d(source pixel coordinate) / d(normalised coordinate) where not clipped
         for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
             const int i = e / PG, j0 = e - i * PG;              // P % 4 == 0: the 4 elements share the row i
-            float iy, my;
-            stn_src_coord_b(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, pbase_sh[i], a.I, a.ac, true, iy, my);
-            const int y0 = (int)floorf(iy);
-            const float wy1 = iy - (float)y0, wy0 = 1.f - wy1;
-            const bool yin = (y0 + 1) < a.I;
+            const uint2 ye = gtab[row][1][i];
+            const int y0 = (int)(ye.x & 0xffffu);
+            const float wy1 = __uint_as_float(ye.y), wy0 = 1.f - wy1;
+            const bool yin = (ye.x & 0x10000u) != 0u;
+            const float my = (ye.x & 0x20000u) ? gmult : 0.f;
             const int r0o = y0 * a.I, r1o = (yin ? y0 + 1 : y0) * a.I;
             const float* img = a.x + (size_t)b * a.I * a.I;
             auto px = [&](int o) -> float {
                 if constexpr (IMG) return (float)img_sh[o];
                 else return img[o];
             };
+            const uint4 xa = *reinterpret_cast<const uint4*>(&gtab[row][0][j0]), xb = *reinterpret_cast<const uint4*>(&gtab[row][0][j0 + 2]);
+            const unsigned xw[4] = {xa.x, xa.z, xb.x, xb.z}, xf[4] = {xa.y, xa.w, xb.y, xb.w};
             float out[4];
             unsigned int gxy[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float ix, mx;
-                stn_src_coord_b(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, pbase_sh[j0 + q], a.I, a.ac, true, ix, mx);
-                const int x0 = (int)floorf(ix);
-                const float wx1 = ix - (float)x0, wx0 = 1.f - wx1;
-                const int x1 = ((x0 + 1) < a.I) ? x0 + 1 : x0;
-                const float m1 = ((x0 + 1) < a.I) ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
+                const int x0 = (int)(xw[q] & 0xffffu);
+                const bool xin = (xw[q] & 0x10000u) != 0u;
+                const float mx = (xw[q] & 0x20000u) ? gmult : 0.f;
+                const float wx1 = __uint_as_float(xf[q]), wx0 = 1.f - wx1;
+#ifdef GT_CHECK
+                {
+                    float ix, mx2, iy2, my2;
+                    stn_src_coord_b(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, pbase_sh[j0 + q], a.I, a.ac, true, ix, mx2);
+                    stn_src_coord_b(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, pbase_sh[i], a.I, a.ac, true, iy2, my2);
+                    const int x0b = (int)floorf(ix), y0b = (int)floorf(iy2);
+                    const bool bad = x0b != x0 || (ix - (float)x0b) != wx1 || mx2 != mx || (((x0b + 1) < a.I) != xin) || y0b != y0 ||
+                                     (iy2 - (float)y0b) != wy1 || my2 != my || (((y0b + 1) < a.I) != yin);
+                    if (bad && a.stamps) atomicAdd(reinterpret_cast<unsigned long long*>(a.stamps) + 4000, 1ull);
+                }
+#endif
+                const int x1 = xin ? x0 + 1 : x0;
+                const float m1 = xin ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
                 const float v00 = px(r0o + x0), v01 = m1 * px(r0o + x1), v10 = n1 * px(r1o + x0), v11 = m1 * n1 * px(r1o + x1);
                 out[q] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
                 // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
                 const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
                 const float gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
-                union { _Float16 h[2]; unsigned int u; } pk;      // fp16 pair: |g| <= I/2 fits, 11 significant bits (bf16's 8 cost the box net's
-                pk.h[0] = (_Float16)gx; pk.h[1] = (_Float16)gy;     // gradient ~3 % of its direction: 784 signed terms per row cancel)
+                union { _Float16 h[2]; unsigned int u; } pk;      // fp16 pair: |g| <= I/2 fits, 11 significant bits
+                pk.h[0] = (_Float16)gx; pk.h[1] = (_Float16)gy;
                 gxy[q] = pk.u;
             }
             bf16x4 o;

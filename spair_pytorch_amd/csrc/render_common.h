@@ -32,8 +32,8 @@ struct Cand {
 // grid_sample's unnormalise).  Forward and backward MUST round identically: the compositing adjoint contains
 // (a*g - pre), which cancels to rounding level where one object dominates a pixel.
 __device__ __forceinline__ float src_from_base(float a, float b, float base, int nsrc, int ac, float& g) {
-    g = a * base + b;
-    return ac ? (g + 1.f) * 0.5f * (float)(nsrc - 1) : ((g + 1.f) * (float)nsrc - 1.f) * 0.5f;
+    g = fmaf(a, base, b);       // explicit: the forward and the backward kernels must agree on this coordinate to the bit (see stn_math.h)
+    return ac ? (g + 1.f) * 0.5f * (float)(nsrc - 1) : fmaf(g + 1.f, (float)nsrc, -1.f) * 0.5f;
 }
 __device__ __forceinline__ float src_of(float a, float b, int j, int nout, int nsrc, int ac) {
     float g;

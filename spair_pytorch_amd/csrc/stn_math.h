@@ -15,10 +15,12 @@ __host__ __device__ __forceinline__ float stn_base(int j, int n, int align_corne
 // Same as stn_src_coord below with the base coordinate supplied by the caller (a table lookup instead of a division per element).
 __host__ __device__ __forceinline__ void stn_src_coord_b(float scale, float shift, float base, int nsrc, int align_corners, bool border,
                                                          float& coord, float& mult) {
-    const float g = scale * base + shift;
+    // explicit fused multiply-adds: left to the compiler, the contraction of a*b + c depends on the surrounding code, and two kernels
+    // (or a table and a direct evaluation) that must agree on a coordinate would differ in its last bit
+    const float g = fmaf(scale, base, shift);
     float c;
     if (align_corners) { c = (g + 1.f) * 0.5f * (float)(nsrc - 1); mult = 0.5f * (float)(nsrc - 1); }
-    else { c = ((g + 1.f) * (float)nsrc - 1.f) * 0.5f; mult = 0.5f * (float)nsrc; }
+    else { c = fmaf(g + 1.f, (float)nsrc, -1.f) * 0.5f; mult = 0.5f * (float)nsrc; }
     if (border) {
         const float hi = (float)(nsrc - 1);
         if (c <= 0.f) { c = 0.f; mult = 0.f; }

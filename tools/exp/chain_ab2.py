@@ -1,0 +1,8 @@
+import sys, os, torch
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/tests/golden')
+import test_chain_gpu as T
+from helpers import load_case
+z, case = load_case("ref_default_b2_step1001")
+a = T.run(case, z, flags=0); b = T.run(case, z, flags=1)
+print("fused", [float(v) for v in a["terms"][:3]], float(a["z_attr"].abs().sum()), float(a["recon"].sum()))
+print("perwf", [float(v) for v in b["terms"][:3]], float(b["z_attr"].abs().sum()), float(b["recon"].sum()))
