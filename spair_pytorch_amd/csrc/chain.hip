@@ -248,26 +248,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     // current one: thread -> (row, 4 features) and 2 x (row, noise slot)
     float4 pf_feat = make_float4(0.f, 0.f, 0.f, 0.f);
     float pf_noise[2] = {0.f, 0.f};
+    // per-thread constants of the prefetch (which feature quad / which noise slots this thread owns): computed ONCE -- the divisions and
+    // the four-way source select were ~40 instructions of every wavefront's first stage
+    const int pf_frow = min(tid0, MT * (F / 4) - 1) / (F / 4), pf_fc4 = (min(tid0, MT * (F / 4) - 1) - pf_frow * (F / 4)) * 4;
+    int pf_nrow[2];
+    const float* pf_nsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = min(tid0 + q * NTH, MT * REC - 1);
+        const int row = i / REC, j = i - row * REC;
+        pf_nrow[q] = row;
+        pf_nsrc[q] = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
+                     : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
+                     : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
+                                   : P.u_pres + (size_t)b * G * G;
+    }
     auto prefetch = [&](int tn, int tidv) {       // branch-free (clamped indices): conditional loads would make every later wait on the
                                                   // weight ring a vmcnt(0), i.e. a wait for THESE loads
+        (void)tidv;
         const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
         {
-            const int tf = min(tidv, MT * (F / 4) - 1);
-            const int row = tf / (F / 4), c4 = (tf - row * (F / 4)) * 4;
-            const int hw = cell_hw[c0n + min(row, ncn - 1)];
-            pf_feat = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + (hw >> 8)) * G + (hw & 255)) * P.ld_feat + c4);
+            const int hw = cell_hw[c0n + min(pf_frow, ncn - 1)];
+            pf_feat = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + (hw >> 8)) * G + (hw & 255)) * P.ld_feat + pf_fc4);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int i = min(tidv + q * NTH, MT * REC - 1);
-            const int row = i / REC, j = i - row * REC;
-            const int hw = cell_hw[c0n + min(row, ncn - 1)];
-            const size_t cell = (size_t)(hw >> 8) * G + (hw & 255);
-            const float* src = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
-                               : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
-                               : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
-                                             : P.u_pres + (size_t)b * G * G;
-            pf_noise[q] = src[cell];
+            const int hw = cell_hw[c0n + min(pf_nrow[q], ncn - 1)];
+            pf_noise[q] = pf_nsrc[q][(size_t)(hw >> 8) * G + (hw & 255)];
         }
     };
     auto park = [&](int tidv) {
@@ -1149,14 +1156,19 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
         if (wave == 7) copy_rows_b16<SP_H>(Aa, LD_H, P.dHb1, SP_LDH, row_r, nc, lane);      // BOX1's output
-        for (int idx = tid; idx < nc * (F + CTX); idx += NTH) {
-            const int row = idx / (F + CTX), n = idx - row * (F + CTX);
-            const float v = slot[row][n];
+        // four columns per thread (F and REC are multiples of 4: a quad never straddles the feature / neighbour-slot boundaries)
+        for (int idx = tid; idx < nc * ((F + CTX) / 4); idx += NTH) {
+            const int row = idx / ((F + CTX) / 4), n = (idx - row * ((F + CTX) / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(&slot[row][n]);
             if (n < F) {
-                reinterpret_cast<__bf16*>(P.dfeat16)[((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n] = (__bf16)v;   // read by the 1x1 stack
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dfeat16) + ((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n) =
+                    pack4(v.x, v.y, v.z, v.w);                                                          // read by the 1x1 stack
             } else {
                 const int s = (n - F) / REC;
-                if (nbr_row[row][s] < 0) atomicAdd(&edge_acc[(n - F) - s * REC], v);
+                if (nbr_row[row][s] < 0) {
+                    float* e = &edge_acc[(n - F) - s * REC];
+                    atomicAdd(e, v.x); atomicAdd(e + 1, v.y); atomicAdd(e + 2, v.z); atomicAdd(e + 3, v.w);
+                }
             }
         }
         bundle_park();                       // every reader of this wavefront's bundle is behind the BOX0 barrier
