@@ -180,6 +180,14 @@ int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const fl
 int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                      const float* aux, const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth,
                      int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
+/* the same with 16-bit sprites, as the bf16 training step runs them: sprites are FP16 (grey, alpha) pairs [N][ld_s] (post-sigmoid values
+ * in (0,1): 11 significant bits), d-logits come back as BF16 [N][ld_s] */
+int spair_render_fwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
+                       const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P,
+                       int align_corners, void* stream);
+int spair_render_bwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
+                       const float* aux, const float* grad_loss, void* dlogits_bf16, float* dnbox, float* dpres, float* ddepth,
+                       int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -503,3 +503,20 @@ extern "C" int spair_render_bwd(const float* sprites, int ld_s, const float* nbo
     return render_bwd(sprites, ld_s, nbox, pres, depth, 1, aux, grad_loss, dlogits, dnbox, dpres, ddepth, ld_s, B, HW, C, I, P,
                       align_corners, obj_scale, alpha_scale, 0, 0, (hipStream_t)stream);
 }
+
+// 16-bit sprite variants (what the bf16 training step runs): sprites are fp16 (grey, alpha) pairs [N][ld_s] (ld_s in elements), the
+// d-logits come back as bf16 [N][ld_s]
+extern "C" int spair_render_fwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
+                                  const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P,
+                                  int align_corners, void* stream) {
+    return render_fwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, x, recon, aux, bce_partial, B, HW, C, I, P,
+                      align_corners, 1, (hipStream_t)stream);
+}
+extern "C" int spair_render_bwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
+                                  const float* aux, const float* grad_loss, void* dlogits_bf16, float* dnbox, float* dpres,
+                                  float* ddepth, int B, int HW, int C, int I, int P, int align_corners, float obj_scale,
+                                  float alpha_scale, void* stream) {
+    return render_bwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, aux, grad_loss,
+                      reinterpret_cast<float*>(dlogits_bf16), dnbox, dpres, ddepth, ld_s, B, HW, C, I, P, align_corners, obj_scale,
+                      alpha_scale, 1, 1, (hipStream_t)stream);
+}

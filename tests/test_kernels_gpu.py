@@ -103,3 +103,52 @@ def test_render_fwd_bwd_vs_oracle(B, G, I, smin, srange):
 def ctypes_f(v):
     import ctypes
     return ctypes.c_float(v)
+
+
+@pytest.mark.parametrize("B,G,I,smin,srange", [(8, 4, 64, 0.08, 0.5), (4, 8, 128, 0.12, 0.12),      # the bench geometry's object sizes
+                                                (1, 2, 128, 0.7, 0.5),                                # magnified: several pixel chunks per object
+                                                (2, 4, 96, 0.02, 0.1)])                               # minified
+def test_render16_fwd_bwd_vs_oracle(B, G, I, smin, srange):
+    """The renderer kernels of the bf16 step (k_render_fwd3 on fp16 sprites, k_render_bwd2: one wave per object, sampling transpose on the
+    matrix cores) through spair_render_fwd16 / _bwd16 against the oracle evaluated on the SAME fp16-rounded sprites.  Forward: fp32 math,
+    2e-5.  Backward: the adjoints and hat weights enter the MFMAs as bf16 and the d-logits leave as bf16 -> 1e-2 relative to the largest
+    element, cosine >= 0.9999; d z_where is fp32 throughout (1e-3), d pres / d depth come from the bf16-product texel sums (1e-2)."""
+    L = _L()
+    P, HW = 28, G * G
+    N = B * HW
+    g = torch.Generator().manual_seed(B + G + I + 1)
+    logits = torch.randn(N, P, P, 2, generator=g)
+    logits[..., 1] += 1.0
+    S = torch.sigmoid(logits).half().float().requires_grad_(True)          # exactly fp16-representable sprites
+    nbox = torch.stack([torch.rand(N, generator=g) * 1.2 - 0.1, torch.rand(N, generator=g) * 1.2 - 0.1,
+                        torch.rand(N, generator=g) * srange + smin, torch.rand(N, generator=g) * srange + smin], 1).requires_grad_(True)
+    pres = torch.rand(N, generator=g).requires_grad_(True)
+    depth = (torch.rand(N, generator=g) * 4).requires_grad_(True)
+    x = (torch.rand(B, 1, I, I, generator=g) > 0.7).float() * torch.rand(B, 1, I, I, generator=g)
+    rec_o, bce_o = _render_oracle(S, nbox, pres, depth, x, B, HW, I, P)
+    bce_o.backward()
+
+    Sd = S.detach().reshape(N, -1).half().contiguous().cuda()
+    nb, pr, dp, xd = nbox.detach().cuda(), pres.detach().cuda(), depth.detach().cuda(), x.cuda()
+    recon = torch.zeros(B, 1, I, I, device="cuda")
+    aux = torch.zeros(B, I, I, 2, device="cuda")
+    part = torch.zeros(B * ((I + 15) // 16) ** 2, device="cuda")
+    ld = P * P * 2
+    L.check(L.lib().spair_render_fwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
+                                       B, HW, 1, I, P, 0, L.stream()), "render fwd16")
+    assert (recon.cpu() - rec_o.detach()).abs().max() < 2e-5
+    assert abs(part.sum().item() - bce_o.item()) <= 2e-5 * bce_o.item()
+    gl = torch.ones((), device="cuda")
+    dlog = torch.zeros(N, ld, device="cuda", dtype=torch.bfloat16)
+    dnb, dpr, ddp = torch.zeros(N, 4, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    L.check(L.lib().spair_render_bwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(aux), L.ptr(gl), L.ptr(dlog), L.ptr(dnb),
+                                       L.ptr(dpr), L.ptr(ddp), B, HW, 1, I, P, 0, ctypes_f(2.0), ctypes_f(0.1), L.stream()), "render bwd16")
+    s = S.detach()
+    ref_dlog = (S.grad * s * (1 - s) * torch.tensor([2.0, 0.1]).view(1, 1, 1, 2)).reshape(N, -1)
+    got = dlog.float().cpu()
+    assert (got - ref_dlog).abs().max().item() <= 1e-2 * ref_dlog.abs().max().item() + 1e-7
+    cos = float((got.double() * ref_dlog.double()).sum() / (got.double().norm() * ref_dlog.double().norm() + 1e-30))
+    assert cos >= 0.9999, cos
+    assert (dnb.cpu() - nbox.grad).abs().max().item() <= 1e-3 * nbox.grad.abs().max().item() + 1e-7
+    assert (dpr.cpu() - pres.grad).abs().max().item() <= 1e-2 * pres.grad.abs().max().item() + 1e-7
+    assert (ddp.cpu() - depth.grad).abs().max().item() <= 1e-2 * depth.grad.abs().max().item() + 1e-7
