@@ -96,6 +96,18 @@ __device__ __forceinline__ int nt16_swz(int row) { return BK == 64 ? (row & 7) :
 // ds_write pass; a wave-instruction writes 1 KiB = 8 (BK 64) or 16 (BK 32) whole unpadded tile rows at base + lane * 16, so the XOR
 // swizzle is applied on the SOURCE side: the lane that owns LDS chunk c of row r fetches global chunk c ^ swz(r)); masked lanes pass an
 // out-of-range offset and the range check writes zeros.
+#ifdef NT16_STAMP
+// diagnostic builds only (tools/build_variant.sh ... -DNT16_STAMP): cycles per K-loop phase, summed over K tiles, waves and workgroups
+__device__ unsigned long long g_nt16_st[8];
+extern "C" int spair_nt16_stamps(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_nt16_st), sizeof(g_nt16_st)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_nt16_st), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define NT16_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define NT16_T(var)
+#endif
 template <bool ACONV, bool C16, bool STEM, int BK, bool SWZ, bool GL>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT g) {
     static_assert(!GL || SWZ, "direct-to-LDS staging needs the unpadded swizzled tile");
@@ -109,8 +121,21 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #define NT16_RING64 0     // 1: the 3-deep ring at BK 64 too (96 KB of LDS: one workgroup per CU) -- A/B builds only
 #endif
     constexpr int NBUF = (GL && (BK == 32 || NT16_RING64)) ? 3 : 2;      // direct-to-LDS at BK 32: a 3-deep ring, two K tiles in flight behind a counted wait
-    __bf16* As0 = smem;                       // [NBUF][BM*LD]
-    __bf16* Bs0 = smem + NBUF * BM * LD;      // [NBUF][BN*LD]
+    // Two A/B build switches, both measured and left OFF (tools/build_variant.sh <name> gemm16.hip -DNT16_A3B2=1 / -DNT16_FRAG_AHEAD=1;
+    // conv_1 forward 0.230-0.236 ms with either or both against 0.233 ms without, every other launch of tools/bench_gemm16.py within
+    // the run-to-run spread too).  What the K loop costs, from builds that skip operand fetches after the third K tile
+    // (-DNT16_EXP_NO_A / _NO_B): conv_1 forward 0.222 ms = 0.147 ms with no fetches at all (1,055 TFLOP/s: LDS reads + MFMA + epilogue +
+    // a 4.5-round grid) + 0.053-0.060 for the gathered A tile + 0.015-0.022 for the L2-hot weight tile.
+#ifndef NT16_FRAG_AHEAD
+#define NT16_FRAG_AHEAD 0 // 1: all 16 fragment reads of a K tile (BK 64) are issued before its first MFMA
+#endif
+#ifndef NT16_A3B2
+#define NT16_A3B2 0       // 1: direct-to-LDS at BK 64 with three A buffers (fetched two tiles ahead), two B buffers: 80 KB, still two workgroups per CU
+#endif
+    constexpr bool A3B2 = GL && BK == 64 && NBUF == 2 && NT16_A3B2;
+    constexpr int NBUF_A = A3B2 ? 3 : NBUF;
+    __bf16* As0 = smem;                       // [NBUF_A][BM*LD]
+    __bf16* Bs0 = smem + NBUF_A * BM * LD;    // [NBUF][BN*LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -220,14 +245,18 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + (i * 256 + wave * 64) * 16), 16,
                                                  (int)byte_off, 0, 0, 0);
     };
-    auto glds_tiles = [&](int k0, int buf) {
-        __bf16* As = As0 + buf * BM * LD;
-        __bf16* Bs = Bs0 + buf * BN * LD;
+    auto glds_part = [&](int k0, int bufa, int bufb, bool doA, bool doB) {     // doA / doB: compile-time constants at every call site
+        __bf16* As = As0 + bufa * BM * LD;
+        __bf16* Bs = Bs0 + bufb * BN * LD;
         const int k = k0 + kq * 8;
         const bool kok = k < g.K;
         const bool live = k0 < g.K;                      // wave-uniform
         const unsigned kc = (unsigned)min(k, Klast);
-        if (ACONV) {
+#ifdef NT16_EXP_NO_A
+        if (k0 >= 3 * BK) goto b_only;
+#endif
+        if (!doA) {
+        } else if (ACONV) {
             int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
             if (BK == 64 && g.n_ktab > 0) {
                 const unsigned e = g.ktab[min(k0 >> 6, g.n_ktab - 1)];
@@ -252,9 +281,17 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #pragma unroll
             for (int i = 0; i < NA; ++i) glds16(rsA, (a_ok[i] && kok) ? (a_base[i] + kc) * 2u : BUF_OOB, As, i);
         }
+#ifdef NT16_EXP_NO_A
+    b_only:
+#endif
+#ifdef NT16_EXP_NO_B      // experiment: the weight tile is fetched for the first K tiles only (wrong results; what do the B loads cost?)
+        if (k0 >= 3 * BK) return;
+#endif
+        if (!doB) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) glds16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB, Bs, i);
     };
+    auto glds_tiles = [&](int k0, int buf) { glds_part(k0, buf, buf, true, true); };
     auto store_tiles = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
         __bf16* As = As0 + buf * BM * LD;
         __bf16* Bs = Bs0 + buf * BN * LD;
@@ -271,11 +308,34 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (g.K + BK - 1) / BK;
-    auto mfma_tile = [&](int buf) {
-        const __bf16* As = As0 + buf * BM * LD;
-        const __bf16* Bs = Bs0 + buf * BN * LD;
+    auto mfma_tile2 = [&](int bufa, int bufb) {
+        const __bf16* As = As0 + bufa * BM * LD;
+        const __bf16* Bs = Bs0 + bufb * BN * LD;
         const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15);
         const int sw = SWZ ? nt16_swz<BK>(lane & 15) : 0;       // the fragment rows differ from lane & 15 by multiples of 16
+#if NT16_FRAG_AHEAD
+        // every fragment of the K tile is requested before the first MFMA (16 ds_read_b128 at BK 64: 64 VGPRs): with one register set the
+        // second 32-deep slice's reads could only be issued once the first slice's MFMAs had consumed theirs, and each slice paid its
+        // own LDS latency (stamps: 927 cycles per K tile for 512 cycles of MFMA)
+        bf16x8 af[BK / 32][TM], bfr[BK / 32][TN];
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const int kg = ((ks * 4 + (lane >> 4)) ^ sw) * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + kg]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + kg]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8 * (BK / 32), 0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * (BK / 32), 0);
+#else
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
@@ -290,8 +350,34 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+#endif
     };
-    if constexpr (GL && NBUF == 3) {
+    auto mfma_tile = [&](int buf) { mfma_tile2(buf, buf); };
+    if constexpr (A3B2) {
+        // K tile 64: the gathered / streamed A tile is what the wait before the barrier was exposed to (with both operand fetches
+        // removed conv_1 forward ran 0.147 ms, with only A's removed 0.169, only B's 0.207, both present 0.222): A gets a third buffer and
+        // is fetched TWO tiles ahead, the L2-hot weight tile B stays double-buffered one tile ahead.  B(kt+1) is issued BEFORE A(kt+2), so
+        // the counted wait (all but the NA youngest) retires A(kt+1) and B(kt+1) and leaves A(kt+2) in flight across the barrier.
+        glds_part(0, 0, 0, true, false);
+        glds_part(0, 0, 0, false, true);
+        glds_part(BK, 1, 0, true, false);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int acur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int anext2 = acur == 0 ? 2 : acur - 1;       // (kt + 2) % 3
+            glds_part((kt + 1) * BK, 0, (kt + 1) & 1, false, true);
+            glds_part((kt + 2) * BK, anext2, 0, true, false);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile2(acur, kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            acur = acur == 2 ? 0 : acur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue re-uses the operand buffers
+        __syncthreads();
+    } else if constexpr (GL && NBUF == 3) {
         // ring of three: tile kt+2 is issued before the MFMAs of tile kt; the wait before the (raw) barrier only retires tile kt+1's
         // NA + NB loads -- tile kt+2 stays in flight across it (a __syncthreads() would drain it: it waits vmcnt(0) with LDS-DMA pending).
         // Buffer (kt+2) % 3 was last read in step kt-1, behind that step's barrier.
@@ -300,30 +386,64 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
         __builtin_amdgcn_s_barrier();
         int bcur = 0;
+#ifdef NT16_STAMP
+        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int bnext2 = bcur == 0 ? 2 : bcur - 1;       // (kt + 2) % 3
+            NT16_T(t0);
             glds_tiles((kt + 2) * BK, bnext2);
             __builtin_amdgcn_sched_barrier(0);
+            NT16_T(t1);
             mfma_tile(bcur);
             __builtin_amdgcn_sched_barrier(0);
+            NT16_T(t2);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+            NT16_T(t3);
             __builtin_amdgcn_s_barrier();
+            NT16_T(t4);
+#ifdef NT16_STAMP
+            st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_d += t4 - t3;
+#endif
             bcur = bcur == 2 ? 0 : bcur + 1;
         }
+#ifdef NT16_STAMP
+        if (lane == 0) {
+            atomicAdd(&g_nt16_st[0], st_a); atomicAdd(&g_nt16_st[1], st_b); atomicAdd(&g_nt16_st[2], st_c); atomicAdd(&g_nt16_st[3], st_d);
+            atomicAdd(&g_nt16_st[4], (unsigned long long)nk);
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue re-uses the operand buffers
         __syncthreads();
     } else if constexpr (GL) {
         glds_tiles(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef NT16_STAMP
+        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
+            NT16_T(t0);
             glds_tiles((kt + 1) * BK, (kt + 1) & 1);     // the other buffer: last read one iteration ago, behind the previous barrier
             __builtin_amdgcn_sched_barrier(0);
+            NT16_T(t1);
             mfma_tile(kt & 1);
             __builtin_amdgcn_sched_barrier(0);
+            NT16_T(t2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NT16_T(t3);
             __syncthreads();
+            NT16_T(t4);
+#ifdef NT16_STAMP
+            st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_d += t4 - t3;
+#endif
         }
+#ifdef NT16_STAMP
+        if (lane == 0) {
+            atomicAdd(&g_nt16_st[0], st_a); atomicAdd(&g_nt16_st[1], st_b); atomicAdd(&g_nt16_st[2], st_c); atomicAdd(&g_nt16_st[3], st_d);
+            atomicAdd(&g_nt16_st[4], (unsigned long long)nk);
+        }
+#endif
     } else {
     load_tiles(0, ra, rb);
     store_tiles(0, ra, rb);
@@ -634,7 +754,8 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     static const int swz = [] { const char* e = getenv("SPAIR_NT16_SWZ"); return e ? atoi(e) : 1; }();      // 0: padded rows (A/B timing)
     static const int glds = [] { const char* e = getenv("SPAIR_NT16_GLDS"); return e ? atoi(e) : 1; }();    // 0: operands staged through registers
     const int nbuf = (swz && glds && (bk == 32 || NT16_RING64)) ? 3 : 2;
-    size_t lds = std::max((size_t)nbuf * (128 + 128) * (bk + (swz ? 0 : 8)) * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
+    const int nbuf_a = (swz && glds && bk == 64 && nbuf == 2 && NT16_A3B2) ? 3 : nbuf;
+    size_t lds = std::max((size_t)(nbuf_a + nbuf) * 128 * (bk + (swz ? 0 : 8)) * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
     if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
