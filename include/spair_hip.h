@@ -180,6 +180,12 @@ int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const fl
 int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                      const float* aux, const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth,
                      int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
+/* Backbone stem alone: conv 1 -> Cout channels, 4x4, stride `stride`, no padding, + bias + relu, over the image zero-padded to Hin x Hin
+ * (pad_pre pixels before; modules.py:95-104 Backbone.padding + the first Conv2d/ReLU of Backbone.net).  x [B][I][I] fp32 (unpadded),
+ * w [Cout][16], out NHWC [B][Hout][Hout][Cout] fp32 or (out_bf16) bf16.  In bf16 mode with Cout = 128, stride 2 it runs on the matrix
+ * cores with split-bf16 operands (three products, fp32 accumulation): agrees with the fp32 result to < 2^-15 relative before the store. */
+int spair_stem_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int I, int pad_pre, int Hin, int Hout,
+                        int Cout, int stride, int out_bf16, void* stream);
 /* the same with 16-bit sprites, as the bf16 training step runs them: sprites are FP16 (grey, alpha) pairs [N][ld_s] (post-sigmoid values
  * in (0,1): 11 significant bits), d-logits come back as BF16 [N][ld_s] */
 int spair_render_fwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,

@@ -1,5 +1,6 @@
 // Small utility kernels: fused Adam (K9), counter-based noise, input padding, weight preparation,
 // per-row -> NCHW map export, and the direct first backbone layer (Cin = image channels).
+#include <cstdlib>
 #include "cells.h"
 #include "misc.h"
 
@@ -289,6 +290,114 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict_
     }
 }
 
+// The same stem on the matrix cores (bf16 mode, 128 output channels, stride 2).  As a GEMM the stem is [channels x 16 taps] . [16 taps x
+// pixels]: v_mfma_f32_16x16x16_bf16 with M = 16 channels, N = 16 consecutive output pixels of one row, K = the 16 taps (lane group q holds
+// the 4 taps of kernel row q: 4 consecutive input pixels).  fp32 operands are split x = xh + xl, w = wh + wl into bf16 pairs and three
+// products (xh.wh + xh.wl + xl.wh) accumulate in fp32 -- what is dropped is xl.wl, below 2^-16 of |x||w| -- so the result agrees with the
+// fp32 FMA kernel above to well inside the bf16 rounding of the stored activation.  24 MFMAs per 16 pixels x 128 channels replace 2,048
+// lane-FMAs per wave-instruction slot.
+// Channel order: row 4q + r of channel group g is channel 32q + 4g + r, so after the 8 groups lane (q, pixel) holds the 32 CONSECUTIVE
+// channels 32q .. 32q+31 of its pixel.  Stored straight from there every wave-instruction scatters 64 x 16 bytes at a 64-byte pitch
+// (measured: 122 us = 2.6 TB/s for the 321 MB of config 2, hardly better than the FMA kernel's 134 us with its 8-byte stores); through a
+// per-wave LDS tile (pixel pitch 272 B: conflict-free both ways) each store instruction writes 4 whole pixel rows = 1 KiB contiguous:
+// 74 us = 4.4 TB/s.
+typedef short c0_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int C0_TP = 272;           // output staging tile: bytes per pixel
+__device__ __forceinline__ void c0_split4(const float (&v)[4], c0_s16x4& hi, c0_s16x4& lo) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+    hi = __builtin_bit_cast(c0_s16x4, h);
+    lo = __builtin_bit_cast(c0_s16x4, l);
+}
+__host__ __device__ constexpr size_t c0_mfma_xs_bytes(int Hin) { return (((size_t)(2 * (C0_ROWS - 1) + 4) * (Hin + 2) * sizeof(float)) + 15) & ~(size_t)15; }
+__global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, __bf16* __restrict__ out, int Hin, int Hout,
+                                                             int I, int pre) {
+    extern __shared__ float xs[];    // [2 * (C0_ROWS - 1) + 4][Hin + 2]: the input rows of this workgroup's output rows; then 4 per-wave output tiles
+    char* tile = reinterpret_cast<char*>(xs) + c0_mfma_xs_bytes(Hin);
+    const int oy0 = blockIdx.x * C0_ROWS, b = blockIdx.y;
+    const int nrow = min(C0_ROWS, Hout - oy0), nin = 2 * (nrow - 1) + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LDX = Hin + 2;
+    {
+        const __amdgpu_buffer_rsrc_t rsx = buf_rsrc(x + (size_t)b * I * I);
+        const int total = nin * LDX;
+        for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+            unsigned v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256;
+                const int ky = i / LDX, xx = i - ky * LDX;
+                const int sy = oy0 * 2 + ky - pre, sx = xx - pre;
+                const bool in = i < total && (unsigned)sy < (unsigned)I && (unsigned)sx < (unsigned)I;
+                v[e] = __builtin_amdgcn_raw_buffer_load_b32(rsx, in ? (sy * I + sx) * 4 : (int)BUF_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (i0 + e * 256 < total) xs[i0 + e * 256] = __uint_as_float(v[e]);
+        }
+    }
+    // weights: lane (m = lane & 15, q = lane >> 4) holds taps (ky = q, kx = 0..3) of channel 32*(m >> 2) + 4g + (m & 3), g = 0..7
+    const int q = lane >> 4, m = lane & 15;
+    c0_s16x4 wh[8], wl[8];
+    f32x4 bv[8];                      // accumulator start = bias of the lane's OUTPUT channels 32q + 4g + r
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int ch = 32 * (m >> 2) + 4 * g + (m & 3);
+        const float4 t = *reinterpret_cast<const float4*>(w + (size_t)ch * 16 + q * 4);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+        c0_split4(tv, wh[g], wl[g]);
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 32 * q + 4 * g);
+        bv[g] = (f32x4){bq.x, bq.y, bq.z, bq.w};
+    }
+    __syncthreads();
+    const int nbx = (Hout + 15) >> 4, nblk = nrow * nbx;
+    char* tw = tile + wave * (16 * C0_TP);
+    for (int blk = wave; blk < nblk; blk += 4) {
+        const int r = blk / nbx, ox0 = (blk - r * nbx) * 16;
+        const int oxc = min(ox0 + m, Hout - 1);
+        const float* xr = xs + (r * 2 + q) * LDX + oxc * 2;            // 8-byte aligned (LDX even)
+        const float2 p0 = *reinterpret_cast<const float2*>(xr), p1 = *reinterpret_cast<const float2*>(xr + 2);
+        const float pv[4] = {p0.x, p0.y, p1.x, p1.y};
+        c0_s16x4 xh, xl;
+        c0_split4(pv, xh, xl);
+        f32x4 acc[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[g], xh, bv[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[g], xh, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[g], xl, acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (__bf16)fmaxf(acc[2 * j][e], 0.f);
+                o[4 + e] = (__bf16)fmaxf(acc[2 * j + 1][e], 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(tw + m * C0_TP + q * 64 + j * 16) = o;
+        }
+        // (a wave writes and reads only its own tile: program order and the compiler's lgkmcnt waits are enough)
+        __bf16* drow = out + (((size_t)b * Hout + oy0 + r) * Hout + ox0) * 128;
+        const int npx = min(16, Hout - ox0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = 4 * j + q;
+            const bf16x8 o = *reinterpret_cast<const bf16x8*>(tw + px * C0_TP + m * 16);
+#ifdef C0_NT_STORE
+            if (px < npx) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8));
+#else
+            if (px < npx) *reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8) = o;
+#endif
+        }
+    }
+}
+
 bool misc_conv0_reads_unpadded(int B, int Hin, int C, int k, int Cout) {
     return Cout % 4 == 0 && C == 1 && k == 4 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0 && B <= 65535 &&
            (size_t)(4 * (C0_ROWS - 1) + 4) * Hin * sizeof(float) <= 48 * 1024;     // stride <= 4
@@ -298,6 +407,13 @@ int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float*
     if (Cout % 4) return SPAIR_ERR_ALIGN;
     if (misc_conv0_reads_unpadded(B, Hin, C, k, Cout)) {
         if (s < 1 || s > 4) return SPAIR_ERR_UNSUPPORTED;
+        static const int no_mfma = [] { const char* e = getenv("SPAIR_CONV0_VALU"); return e ? atoi(e) : 0; }();     // 1: the FMA kernel (A/B timing)
+        if (out_bf16 && Cout == 128 && s == 2 && (Hin & 1) == 0 && !no_mfma) {
+            hipLaunchKernelGGL(k_conv0_fwd_c1k4_mfma, dim3((Hout + C0_ROWS - 1) / C0_ROWS, B), dim3(256), c0_mfma_xs_bytes(Hin) + 4 * 16 * C0_TP, st, x,
+                               w, bias, reinterpret_cast<__bf16*>(out), Hin, Hout, I, pre);
+            SPAIR_CHECK_LAUNCH();
+            return SPAIR_OK;
+        }
         hipLaunchKernelGGL(k_conv0_fwd_c1k4, dim3((Hout + C0_ROWS - 1) / C0_ROWS, B), dim3(256),
                            (size_t)(s * (C0_ROWS - 1) + 4) * Hin * sizeof(float), st, x, w, bias, out, Hin, s, Hout, Cout, out_bf16, I, pre);
         SPAIR_CHECK_LAUNCH();
@@ -310,6 +426,15 @@ int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float*
     hipLaunchKernelGGL(k_conv0_fwd, dim3(grid), dim3(256), lds, st, xp, w, bias, out, B, Hin, C, k, s, Hout, Cout, out_bf16);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
+}
+
+// the grey-scale 4x4 stem alone (parity tests): x [B][I][I] fp32 unpadded, zero outside [pre, pre + I) of the Hin x Hin padded frame
+extern "C" int spair_stem_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int I, int pad_pre, int Hin, int Hout,
+                                   int Cout, int stride, int out_bf16, void* stream) {
+    if (!x || !w || !bias || !out) return SPAIR_ERR_SHAPE;
+    if (B <= 0 || I <= 0 || stride < 1 || Hin < I + pad_pre || Hout != (Hin - 4) / stride + 1) return SPAIR_ERR_SHAPE;
+    if (!misc_conv0_reads_unpadded(B, Hin, 1, 4, Cout)) return SPAIR_ERR_UNSUPPORTED;
+    return misc_conv0_fwd(x, nullptr, w, bias, reinterpret_cast<float*>(out), B, I, pad_pre, Hin, 1, 4, stride, Hout, Cout, out_bf16, (hipStream_t)stream);
 }
 
 // weight gradient: dW[co][ci][ky][kx] += sum_m dOut[m][co] * patch(m)[(ky,kx,ci)]; thread = (co, k) pairs

@@ -152,3 +152,27 @@ def test_render16_fwd_bwd_vs_oracle(B, G, I, smin, srange):
     assert (dnb.cpu() - nbox.grad).abs().max().item() <= 1e-3 * nbox.grad.abs().max().item() + 1e-7
     assert (dpr.cpu() - pres.grad).abs().max().item() <= 1e-2 * pres.grad.abs().max().item() + 1e-7
     assert (ddp.cpu() - depth.grad).abs().max().item() <= 1e-2 * depth.grad.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("B,I,pre,post", [(3, 128, 7, 7), (2, 48, 3, 5), (1, 32, 0, 2)])
+def test_stem_conv_mfma_vs_torch(B, I, pre, post):
+    """The bf16-mode stem (k_conv0_fwd_c1k4_mfma: split-bf16 operands on the matrix cores) against torch's fp32 conv on the CPU: before
+    the bf16 store the two agree to ~2^-15, so after it every element is within ONE bf16 step (2^-8 relative) and all but a few per
+    thousand are identical to the rounded fp32 result; the fp32-output path of the same entry point (the FMA kernel) to 2e-6."""
+    L = _L()
+    Hin = I + pre + post
+    Hout = (Hin - 4) // 2 + 1
+    g = torch.Generator().manual_seed(I + pre)
+    x = torch.rand(B, 1, I, I, generator=g) * (torch.rand(B, 1, I, I, generator=g) > 0.5)
+    w = torch.randn(128, 1, 4, 4, generator=g) * 0.3
+    b = torch.randn(128, generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(x, (pre, post, pre, post)), w, b, stride=2)).permute(0, 2, 3, 1).contiguous()
+    xd, wd, bd = x.cuda().contiguous(), w.reshape(128, 16).cuda().contiguous(), b.cuda()
+    o16 = torch.zeros(B, Hout, Hout, 128, device="cuda", dtype=torch.bfloat16)
+    o32 = torch.zeros(B, Hout, Hout, 128, device="cuda")
+    L.check(L.lib().spair_stem_conv_fwd(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(o16), B, I, pre, Hin, Hout, 128, 2, 1, L.stream()), "stem bf16")
+    L.check(L.lib().spair_stem_conv_fwd(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(o32), B, I, pre, Hin, Hout, 128, 2, 0, L.stream()), "stem fp32")
+    assert (o32.cpu() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    got, want = o16.float().cpu(), ref.bfloat16().float()
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    assert (got != want).float().mean().item() < 5e-3
