@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     // the run-to-run spread too).  What the K loop costs, from builds that skip operand fetches after the third K tile
     // (-DNT16_EXP_NO_A / _NO_B): conv_1 forward 0.222 ms = 0.147 ms with no fetches at all (1,055 TFLOP/s: LDS reads + MFMA + epilogue +
     // a 4.5-round grid) + 0.053-0.060 for the gathered A tile + 0.015-0.022 for the L2-hot weight tile.
+#ifndef NT16_NT_STORE
+#define NT16_NT_STORE 0   // bit 0: sprites, bit 1: bf16 outputs leave through non-temporal stores
+#endif
 #ifndef NT16_FRAG_AHEAD
 #define NT16_FRAG_AHEAD 0 // 1: all 16 fragment reads of a K tile (BK 64) are issued before its first MFMA
 #endif
@@ -607,7 +610,11 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 h8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+#if NT16_NT_STORE & 1
+                __builtin_nontemporal_store(o, reinterpret_cast<h8*>(dst));
+#else
                 *reinterpret_cast<h8*>(dst) = o;
+#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -619,7 +626,11 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+#if NT16_NT_STORE & 2
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dst));
+#else
                 *reinterpret_cast<bf16x8*>(dst) = o;
+#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4(const float* __restrict_
 // channels 32q .. 32q+31 of its pixel.  Stored straight from there every wave-instruction scatters 64 x 16 bytes at a 64-byte pitch
 // (measured: 122 us = 2.6 TB/s for the 321 MB of config 2, hardly better than the FMA kernel's 134 us with its 8-byte stores); through a
 // per-wave LDS tile (pixel pitch 272 B: conflict-free both ways) each store instruction writes 4 whole pixel rows = 1 KiB contiguous:
-// 74 us = 4.4 TB/s.
+// 74 us = 4.4 TB/s, 66 us with non-temporal stores.
 typedef short c0_s16x4 __attribute__((ext_vector_type(4)));
 constexpr int C0_TP = 272;           // output staging tile: bytes per pixel
 __device__ __forceinline__ void c0_split4(const float (&v)[4], c0_s16x4& hi, c0_s16x4& lo) {
@@ -389,11 +389,9 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __rest
         for (int j = 0; j < 4; ++j) {
             const int px = 4 * j + q;
             const bf16x8 o = *reinterpret_cast<const bf16x8*>(tw + px * C0_TP + m * 16);
-#ifdef C0_NT_STORE
+            // non-temporal: the 321 MB stream past the L2 instead of evicting it (74 -> 66 us alone; in the step conv_1's forward, which
+            // reads this tensor next, went 0.231 -> 0.210 ms as well)
             if (px < npx) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8));
-#else
-            if (px < npx) *reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8) = o;
-#endif
         }
     }
 }
