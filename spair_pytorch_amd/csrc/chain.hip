@@ -60,6 +60,36 @@ constexpr int NTH = NW * 64;
 #define CHAIN_RD 12      // measured: 16 / 20 / 24 fragments in flight per wave change nothing (0.91 -> 0.93-0.95 ms)
 #endif
 constexpr int RD = CHAIN_RD;
+#ifndef CHAIN_NT
+#define CHAIN_NT 1        // the row-buffer stores are non-temporal: they stream past the L2 that holds the weights every workgroup re-reads each wavefront (chain fwd 0.854 -> 0.836 ms, bwd 0.861 -> 0.851)
+#endif
+#if CHAIN_NT
+template <typename T> __device__ __forceinline__ void ch_gstore_nt(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void ch_gstore_nt(float4* p, const float4& v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
+}
+#define CH_GSTORE(p, v) ch_gstore_nt((p), (v))
+#else
+#define CH_GSTORE(p, v) (*(p) = (v))
+#endif
+#ifndef CHAIN_NT_LD
+#define CHAIN_NT_LD 1     // the backward kernel's read-once row data (bundle, glimpse derivatives) is loaded non-temporally (chain bwd 0.852 -> 0.833 ms)
+#endif
+__device__ __forceinline__ uint4 ch_gload16(const void* p) {
+#if CHAIN_NT_LD
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+#define CH_GLOAD16(p) ch_gload16(p)
+__device__ __forceinline__ float4 ch_gloadf4(const float* p) {
+    const uint4 v = ch_gload16(p);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#define CH_GLOADF4(p) ch_gloadf4(p)
 struct WPipe { uint4 q[RD]; };
 
 template <int KT, int NT, int NT0>
@@ -133,8 +163,8 @@ __device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restri
         if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
         if (lds_f) lds_f[row * ld_f + n] = v;
         if (hbm && row < nc) {
-            if (hbm_b16) reinterpret_cast<__bf16*>(hbm)[(size_t)row_r[row] * ld_hbm + n] = (__bf16)v;
-            else hbm[(size_t)row_r[row] * ld_hbm + n] = v;
+            if (hbm_b16) CH_GSTORE(&reinterpret_cast<__bf16*>(hbm)[(size_t)row_r[row] * ld_hbm + n], (__bf16)v);
+            else CH_GSTORE(&hbm[(size_t)row_r[row] * ld_hbm + n], v);
         }
     }
 }
@@ -155,7 +185,7 @@ __device__ __forceinline__ void copy_rows_bf16(const __bf16* src, int lds_ld, fl
     for (int t = lane; t < nc * CH; t += 64) {
         const int row = t / CH, c = (t - row * CH) * 4;
         const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c);
-        *reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        CH_GSTORE(reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c), make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]));
     }
 }
 template <int NCOL>
@@ -164,7 +194,7 @@ __device__ __forceinline__ void copy_rows_b16(const __bf16* src, int lds_ld, flo
     __bf16* __restrict__ dst = reinterpret_cast<__bf16*>(dst_);
     for (int t = lane; t < nc * CH; t += 64) {
         const int row = t / CH, c = (t - row * CH) * 4;
-        *reinterpret_cast<bf16x4*>(dst + (size_t)row_r[row] * ldd + c) = *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c);
+        CH_GSTORE(reinterpret_cast<bf16x4*>(dst + (size_t)row_r[row] * ldd + c), *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c));
     }
 }
 template <int NCOL>
@@ -172,7 +202,7 @@ __device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, floa
     constexpr int CH = NCOL / 4;
     for (int t = lane; t < nc * CH; t += 64) {
         const int row = t / CH, c = (t - row * CH) * 4;
-        *reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c) = *reinterpret_cast<const float4*>(src + row * lds_ld + c);
+        CH_GSTORE(reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c), *reinterpret_cast<const float4*>(src + row * lds_ld + c));
     }
 }
 
@@ -490,8 +520,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             bf16x4 o;
             o[0] = (__bf16)out[0]; o[1] = (__bf16)out[1]; o[2] = (__bf16)out[2]; o[3] = (__bf16)out[3];
             *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)row_r[row] * L.ld_gl + e) = o;
-            *reinterpret_cast<uint4*>(P.gxy + (size_t)row_r[row] * L.ld_gl + e) = make_uint4(gxy[0], gxy[1], gxy[2], gxy[3]);
+            CH_GSTORE(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)row_r[row] * L.ld_gl + e), o);
+            CH_GSTORE(reinterpret_cast<u32x4_t*>(P.gxy + (size_t)row_r[row] * L.ld_gl + e), ((u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]}));
         }
         lds_barrier();
         CH_STAMP();
@@ -839,8 +869,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         const int k = min(brow, ncn - 1);
         const int cpn = c0n + k, h = hlo_of(tn) + k, w = tn - 2 * h;
         const size_t rn = (size_t)cpn * L.B + b, cell = (size_t)h * G + w;
-        pf_v0 = *reinterpret_cast<const float4*>(v0_base + rn * v0_ld);
-        pf_v1 = *reinterpret_cast<const float4*>(v1_base + (v1_cp ? (size_t)cpn : rn) * v1_ld);
+        pf_v0 = CH_GLOADF4(v0_base + rn * v0_ld);
+        pf_v1 = CH_GLOADF4(v1_base + (v1_cp ? (size_t)cpn : rn) * v1_ld);
         pf_s0 = s0_base[cell];
         pf_s1 = s1_base[(s1_row ? rn : cell) * s1_stride];
     };
@@ -902,7 +932,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int e0 = min((wave + NW * j) * 16 + (lane & 3) * 4, GLN - 4);
-                gxy_pf[j] = *reinterpret_cast<const uint4*>(P.gxy + grow + e0);
+                gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
             }
         }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
