@@ -264,13 +264,13 @@ def main():
     #  overlap and are not per-kernel durations -- see profiles/ for the rocprofv3 kernel stats)
     # HBM traffic per launch from the committed PMC passes of this same command (two separate rocprofv3 --pmc runs; FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload it was collected on.
-    pmc_path = os.path.join(ROOT, "profiles", "r02_c_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r02_d_pmc_traffic.json")
     if os.path.exists(pmc_path) and B == 256 and args.image == 128 and args.dtype == "bf16":
         pmc = json.load(open(pmc_path))
         for name, rec in kernels.items():
             if name in pmc:
                 rec["traffic"] = (pmc[name]["read_MB"] + pmc[name]["write_MB"]) * 1e6
-                rec["traffic_source"] = "profiles/r02_c_pmc_traffic.json"
+                rec["traffic_source"] = "profiles/r02_d_pmc_traffic.json"
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     roof = dict(kernels[dominant], kernel=dominant) if dominant else None
 
