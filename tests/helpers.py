@@ -31,3 +31,12 @@ def case_noise(z):
 
 
 KL_NAMES = ["cy_logit", "cx_logit", "height_logit", "width_logit", "attr", "depth_logit", "pres_dist"]
+
+
+def assert_adam_updates_close(pa, pb, lr, tight=2e-6, outlier_frac=1e-5):
+    """Parameters after Adam steps of two runs whose gradients agree to rounding (fp32 atomics in the bias / edge sums): Adam's update
+    lr * m / (sqrt(v) + eps) is sign-like, so a gradient that is itself rounding noise (|g| <~ eps) may move its parameter by up to
+    +-lr differently in the two runs.  All but a few elements in a million must agree to `tight`, none may differ by more than 2.2 lr."""
+    d = np.abs(np.asarray(pa, np.float64) - np.asarray(pb, np.float64))
+    assert d.max() <= 2.2 * lr, d.max()
+    assert (d > tight).mean() <= outlier_frac, ((d > tight).sum(), d.size)

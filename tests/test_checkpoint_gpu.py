@@ -5,6 +5,8 @@ import os
 import pytest
 import torch
 
+from helpers import assert_adam_updates_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -47,7 +49,7 @@ def test_resume_continues_the_run(tmp_path):
     l2 = _step(m2, o2, x, it, 102)
     assert l1 == l2                                                        # forward: bit-exact
     # backward: bias / edge gradients are summed with fp32 atomics, so two runs agree to rounding, not to the bit
-    assert (m1.flat_parameters() - m2.flat_parameters()).abs().max().item() <= 1e-6
+    assert_adam_updates_close(m1.flat_parameters().cpu().numpy(), m2.flat_parameters().cpu().numpy(), 1e-3, tight=1e-6)
     scale = o1.exp_avg.abs().max().item()
     assert (o1.exp_avg - o2.exp_avg).abs().max().item() <= 1e-5 * scale
     assert (o1.exp_avg_sq - o2.exp_avg_sq).abs().max().item() <= 1e-5 * o1.exp_avg_sq.abs().max().item()
