@@ -322,6 +322,10 @@ __device__ __forceinline__ uint4 rb2_ld16(const char* p) {
     return *reinterpret_cast<const uint4*>(p);
 #endif
 }
+#ifdef RF3_STAMP       // diagnostic builds only (tools/build_variant.sh rfst render2.hip -DRF3_STAMP; tools/exp/rf3_stamps.py)
+__device__ unsigned long long g_rf3_st[256 * 32];
+extern "C" int spair_rf3_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rf3_st), sizeof(g_rf3_st)) == hipSuccess ? 0 : -3; }
+#endif
 template <bool S16, int PT, int AC, int IP2>
 __global__ __launch_bounds__(256) void k_render_fwd3(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                      const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
@@ -451,9 +455,16 @@ __global__ __launch_bounds__(256) void k_render_fwd3(const float* __restrict__ S
             const unsigned sbase = pool_off + (unsigned)(cum - bytes) - (unsigned)(v0 * ROWB);     // + tabulated row * ROWB = first tap's row
             unsigned long long todo = __ballot(hs);
             int cbase = 0;
+#ifdef RF3_STAMP
+            unsigned long long st_issue = 0, st_wait = 0, st_comp = 0, st_n = 0, st_dma = 0;
+#endif
             while (todo) {
                 const bool fits = ((todo >> lane) & 1ull) && (cum - cbase) <= POOL;
                 const unsigned long long chunk = __ballot(fits);                     // a prefix of `todo`: cum is monotone
+#ifdef RF3_STAMP
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                st_dma += __popcll(chunk);
+#endif
                 // stage the chunk's sprite rows
                 for (unsigned long long m = chunk; m; m &= m - 1) {
                     const int c = __builtin_ctzll(m);
@@ -467,7 +478,13 @@ __global__ __launch_bounds__(256) void k_render_fwd3(const float* __restrict__ S
                         }
                     }
                 }
+#ifdef RF3_STAMP
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RF3_STAMP
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
                 // composite
                 for (unsigned long long m = chunk; m; m &= m - 1) {
                     const int c = __builtin_ctzll(m);
@@ -489,7 +506,16 @@ __global__ __launch_bounds__(256) void k_render_fwd3(const float* __restrict__ S
                 const int last = 63 - __builtin_clzll(chunk);
                 cbase = __builtin_amdgcn_readlane(cum, last);
                 todo &= ~chunk;
+#ifdef RF3_STAMP
+                { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); st_issue += t1 - t0; st_wait += t2 - t1; st_comp += t3 - t2; st_n += 1; }
+#endif
             }
+#ifdef RF3_STAMP
+            if (lane == 0 && (blockIdx.x & 63) == 5) {
+                unsigned long long* d = g_rf3_st + ((blockIdx.x >> 6) & 255) * 32 + wave * 8;
+                d[0] = st_issue; d[1] = st_wait; d[2] = st_comp; d[3] = st_n; d[4] = st_dma;
+            }
+#endif
             __syncthreads();
         }
         if (k0 + 256 < HW) __syncthreads();      // the next cull rewrites cnt[0..3] / tl

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Forward renderer: cycles a strip's wave spends issuing sprite DMA, waiting for it, compositing (diagnostic build -DRF3_STAMP)."""
+"""Forward renderer: cycles a strip's wave spends issuing sprite DMA, waiting for it, compositing.
+Needs the diagnostic build: tools/build_variant.sh rfst render2.hip -DRF3_STAMP; SPAIR_HIP_LIB=build/libspair_rfst.so python tools/exp/rf3_stamps.py"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
