@@ -104,6 +104,214 @@ def hbm_copy_rates(dev, mb=1024):
     return dict(copy_GBs=rate(lambda: b.copy_(a), 2 * n * 4), fill_GBs=rate(lambda: b.fill_(2.0), n * 4), unit="GB/s", bytes=n * 4)
 
 
+# fragment packs the chain kernels stream from L2 on EVERY wavefront (engine.hip carve(): tiles x k-steps x 1 KiB per layer)
+CHAIN_PACK_KIB = dict(fwd=sum(a * b for a, b in zip((7, 7, 7, 16, 8, 7, 7, 7, 7, 7, 7, 1), (11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4, 4))),
+                      bwd=sum(a * b for a, b in zip((21, 7, 7, 49, 16, 8, 30, 7, 7, 30, 7, 0), (4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0))))
+L2_GATHER_PEAK_TBS = 17.8      # MI355X_MICROARCH.md "Indexed rows: gather into LDS": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2
+
+
+def kernel_table(d, B, dtype, ms, cnt, n_sampled):
+    """Per-kernel roofline records from the engine's HIP-event slots.  Algorithmic work = SURVEY.md section 8(d)'s per-unit figures."""
+    nslots = len(SLOT_NAMES)
+    per_step_ms = {SLOT_NAMES[i]: ms[i] / n_sampled for i in range(nslots) if cnt[i] > 0}
+    avg = {SLOT_NAMES[i]: ms[i] / cnt[i] for i in range(nslots) if cnt[i] > 0}       # per launch / region
+    N = B * d.G * d.G
+    P2 = d.P * d.P
+    es = 2 if dtype == "bf16" else 4
+    sprite_b = N * P2 * 2 * es                                           # (grey, alpha) sprites: 16-bit pairs in the bf16 step
+    render_fwd_bytes = sprite_b + N * 6 * 4 + B * d.I * d.I * 4          # SURVEY 8(d) K6: 223.9 MB (bf16) at config 2
+    render_bwd_bytes = render_fwd_bytes + N * P2 * 2 * es                # + the d-logits write
+    peak_f = MFMA_PEAK_TFLOPS["bf16" if dtype == "bf16" else "f32"]
+    h0 = (d.I + d.pad_pre + d.pad_post - d.conv_k[0]) // d.conv_s[0] + 1
+    h1 = (h0 - d.conv_k[1]) // d.conv_s[1] + 1
+    conv1_flop = 2.0 * B * h1 * h1 * d.conv_c[1] * (d.conv_k[1] * d.conv_k[1] * d.conv_c[0])
+    dec_out_flop = 2.0 * N * 256 * (P2 * 2)
+    A, NPc, Fc = d.A, d.NP, d.F
+    REC = 4 + A + 2                                                        # record [box4 | attr A | depth | pres]
+    box_in = Fc + 4 * REC                                                  # features + 4 neighbour records
+    z_in, glim = box_in + NPc + 4 + A, P2
+    o_in = z_in + 1
+    # K2 per-cell chain: SURVEY 8(d) prices it as MFMA work, 2 * N * 425,472 flop ("latency-limited by the 3G-2 dependent diagonals")
+    chain_flop = 2.0 * N * (box_in * 100 + 100 * 100 + 100 * (8 + NPc) + glim * 256 + 256 * 128 + 128 * 2 * A
+                            + z_in * 100 + 100 * 100 + 100 * (2 + NPc) + o_in * 100 + 100 * 100 + 100)
+    # builder-side byte model of what the chain kernels must move through HBM per row (DESIGN.md section 4) -- reported as `hbm_row_model`,
+    # NOT the roofline: forward = every GEMM operand once as bf16 + glimpse derivative pairs + the fp32 bundle/record + sign bits + inputs;
+    # backward = bundle + derivative pairs + sign bits in, layer-output gradients and d feat out as bf16
+    hid = 2 * 100 + (256 + 128) + 2 * 100 + 2 * 100
+    outs = (100 + 100 + 8 + NPc) + (256 + 128 + 2 * A) + (100 + 100 + 2 + NPc) + (100 + 100 + 1)
+    if dtype == "bf16":
+        fwd_row = 2 * (o_in + glim + hid + A) + 4 * glim + 4 * (308 + REC) + 66 * 4 * 8 // 8 + 4 * (Fc + REC + 2)
+    else:
+        fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)
+    bwd_row = 4 * (308 + glim) + 66 * 4 * 8 // 8 + 2 * (outs + Fc)
+    T = 3 * d.G - 2
+    kernels = {}
+
+    def add(name, bound, work, unit_scale, peak, unit, slot=None, **extra):
+        slot = slot or name
+        if slot in avg and avg[slot] > 0:
+            ach = work / (avg[slot] * 1e-3) / unit_scale
+            kernels[name] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_ms=avg[slot], traffic=None, **extra)
+
+    def chain_extra(slot, pack_kib, row_bytes):
+        if slot not in avg or avg[slot] <= 0:
+            return {}
+        t = avg[slot] * 1e-3
+        l2_bytes = float(B) * T * pack_kib * 1024            # every workgroup (= sample) re-streams the whole pack on each of its T wavefronts
+        return dict(l2_stream=dict(bytes=l2_bytes, achieved_TBs=l2_bytes / t / 1e12, peak_TBs=L2_GATHER_PEAK_TBS,
+                                   frac=l2_bytes / t / 1e12 / L2_GATHER_PEAK_TBS,
+                                   note="weight fragments L2 -> registers: B workgroups x (3G-2) wavefronts x pack; the bound these kernels sit closest to"),
+                    hbm_row_model=dict(bytes=float(N) * row_bytes, achieved_GBs=N * row_bytes / t / 1e9, frac_of_8TBs=N * row_bytes / t / 1e9 / HBM_PEAK_GBS,
+                                       note="builder's byte model of the row buffers (DESIGN.md section 4), not SURVEY 8(d)'s figure"))
+
+    add("chain_bwd", "mfma", chain_flop, 1e12, peak_f, "TFLOP/s", slot="cells_bwd", **chain_extra("cells_bwd", CHAIN_PACK_KIB["bwd"], bwd_row))
+    add("chain_fwd", "mfma", chain_flop, 1e12, peak_f, "TFLOP/s", slot="cells_fwd", **chain_extra("cells_fwd", CHAIN_PACK_KIB["fwd"], fwd_row))
+    add("render_fwd", "hbm", render_fwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
+    add("render_bwd", "hbm", render_bwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
+    add("conv1_fwd", "mfma", conv1_flop, 1e12, peak_f, "TFLOP/s")
+    add("dec_out_fwd", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
+    add("decoder_fwd", "mfma", 2.0 * N * (A * 128 + 128 * 256 + 256 * P2 * 2), 1e12, peak_f, "TFLOP/s")      # K5 whole: 57.7 GFLOP
+    add("dec_out_dgrad", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
+    # (decoder / per-cell weight gradients run on the helper stream beside the chain: their event times include the
+    #  overlap and are not per-kernel durations -- see profiles/ for the rocprofv3 kernel stats)
+    return kernels, per_step_ms
+
+
+def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
+    """K4 = the glimpse stage of k_chain_fwd.  SpairStep.flags bit 1 makes sample 0's workgroup stamp s_memtime after every stage; the
+    stage's share of the stamped cycles x the kernel's event time = its duration (clock-free).  One extra, untimed step."""
+    if not chain_fwd_ms:
+        return None
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd import models
+    import numpy as np
+    T, NS, GL = 3 * d.G - 2, 20, 6                 # stamps per wavefront; stage 6 = glimpse sampling (tools/chain_stamps.py)
+    if T * NS > 2048:
+        return None
+    old = models.STEP_FLAGS
+    models.STEP_FLAGS = old | 2
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        models.STEP_FLAGS = old
+    e = model._last["engine"]
+    out = torch.zeros(4096, dtype=torch.int64, device=model.device)
+    L.check(L.lib().spair_chain_stamps(ctypes.byref(e["dims"]), L.ptr(e["workspace"]), L.ptr(out), T * NS, L.stream()), "stamps")
+    st = out.cpu().numpy()[:T * NS].reshape(T, NS).astype(np.float64)
+    span = st[-1, NS - 1] - st[0, 0]
+    if not span > 0:
+        return None
+    share = float(np.diff(st, axis=1)[:, GL].sum() / span)
+    ms_ = share * chain_fwd_ms
+    N, P2 = B * d.G * d.G, d.P * d.P
+    work = B * d.C * d.I * d.I * 4 + N * P2 * d.C * (2 if dtype == "bf16" else 4) + N * 4 * 4       # SURVEY 8(d) K4: 120.6 MB at config 2 (bf16)
+    ach = work / (ms_ * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, avg_ms=None, stage_ms=ms_, traffic=None,
+                share_of_chain_fwd=share,
+                note="fused stage of k_chain_fwd (no launch of its own): stage share from in-kernel s_memtime stamps of sample 0 x the kernel's "
+                     "event time; every workgroup runs this stage %d times, all %d workgroups concurrently" % (T, B))
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def attach_pmc_traffic(kernels, B, image, dtype):
+    """roofline.traffic = HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Attached only when the file was collected on
+    THESE kernels: every kernel name in it must exist in the built library and the sources it records must hash to the current ones."""
+    import glob
+    if not (B == 256 and image == 128 and dtype == "bf16"):
+        return
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return
+    path = files[-1]
+    rel = os.path.relpath(path, ROOT)
+    pmc = json.load(open(path))
+    lib_bytes = open(os.path.join(ROOT, "spair_pytorch_amd", "libspair_hip.so"), "rb").read()
+    import re
+    stale = None
+    for src, sha in (pmc.get("src_sha16") or {}).items():
+        cur = os.path.join(ROOT, src)
+        if not os.path.exists(cur) or _sha16(cur) != sha:
+            stale = "%s changed since %s was collected" % (src, rel)
+    if not pmc.get("src_sha16"):
+        stale = "%s records no source hashes" % rel
+    for name, rec in pmc.items():
+        if isinstance(rec, dict) and "kernel" in rec:
+            m = re.search(r"k_[A-Za-z0-9_]+", rec["kernel"])
+            if m and m.group(0).encode() not in lib_bytes:
+                stale = "kernel %s of %s is not in the built library" % (m.group(0), rel)
+    for name, rec in kernels.items():
+        if stale:
+            rec["traffic_source"] = "refused: " + stale
+        elif name in pmc:
+            rec["traffic"] = (pmc[name]["read_MB"] + pmc[name]["write_MB"]) * 1e6
+            rec["traffic_source"] = rel
+
+
+def config3_record(dev, args, strides):
+    """BASELINE configs[3]: 256x256 scenes, 32x32 grid, batch 64 (same N = B*G*G as configs[1]) -- ms per step and the chain / renderer
+    roofline fractions, bounded to a few seconds."""
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.data import scattered_digits
+    from spair_pytorch_amd.models import SPAIR
+    from spair_pytorch_amd.optim import FusedAdam
+    I, B = 256, 64
+    cfg.set_grid(I, strides)
+    torch.manual_seed(3)
+    model = SPAIR([1, I, I], None, dev, compute_dtype=args.dtype).to(dev)
+    opt = FusedAdam(model, lr=1e-4)
+    x = torch.from_numpy(scattered_digits(1234, B, I, 11)[0]).to(dev)
+    torch.manual_seed(7)
+    gs = [args.global_step]
+
+    def step():
+        opt.zero_grad()
+        loss = model(x, gs[0])[0]
+        loss.backward()
+        opt.step()
+        gs[0] += 1
+        return loss
+
+    for _ in range(5):
+        step()
+    lib = L.lib()
+    L.check(lib.spair_prof_enable(1), "prof_enable")
+    lib.spair_prof_enable(0)
+    torch.cuda.synchronize()
+    K, every = args.config3_steps, 2
+    t0 = time.perf_counter()
+    for i in range(K):
+        lib.spair_prof_enable(2 if i % every == 0 else 0)
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nslots = len(SLOT_NAMES)
+    ms = (ctypes.c_float * nslots)()
+    cnt = (ctypes.c_int * nslots)()
+    L.check(lib.spair_prof_read(ms, cnt, nslots), "prof_read")
+    lib.spair_prof_enable(0)
+    d = model._last["engine"]["dims"]
+    kernels, per_step = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, every)))
+    stn = stn_fwd_from_stamps(model, step, d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
+    if stn:
+        kernels["stn_fwd"] = stn
+    keep = ("chain_fwd", "chain_bwd", "render_fwd", "render_bwd", "stn_fwd")
+    rec = dict(workload="BASELINE configs[3]: 256x256 synthetic scattered digits (<=11), 32x32 grid, batch 64, fwd+bwd+Adam, global_step %d+"
+                        % args.global_step,
+               ms_per_step=dt / K * 1e3, images_per_sec=B * K / dt, steps=K, warmup=5, elbo=float(loss.item()),
+               kernels={k: {f: v for f, v in kernels[k].items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "stage_ms", "l2_stream")}
+                        for k in keep if k in kernels},
+               step_breakdown_ms=per_step)
+    cfg.set_grid(args.image, strides)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,9 +322,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-step", type=int, default=2000, help="global_step of the first timed step (count-prior / wheel schedules)")
-    ap.add_argument("--sweep", action="store_true",
-                    help="BASELINE configs[4]: after the main measurement, time the step at global_step in {0,2000,4000,6000,7000,8000,10000}")
-    ap.add_argument("--sweep-steps", type=int, default=15)
+    ap.add_argument("--sweep", action="store_true", help="(kept for compatibility: the sweep is part of the default single-GPU line)")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip BASELINE configs[4]: after the main measurement, the step at global_step in {0,2000,4000,6000,7000,8000,10000}")
+    ap.add_argument("--sweep-steps", type=int, default=10)
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the bounded BASELINE configs[3] sub-record (256x256, 32x32 grid, batch 64) of the default single-GPU line")
+    ap.add_argument("--config3-steps", type=int, default=20)
     ap.add_argument("--prof-every", type=int, default=4, help="record the per-kernel HIP event pairs on every n-th timed step")
     ap.add_argument("--prof-mask", type=lambda v: int(v, 0), default=-1, help="bit mask of the engine's event-pair slots to record (-1 = all)")
     args = ap.parse_args()
@@ -151,7 +363,8 @@ def main():
     cfg.set_grid(args.image, strides)
     torch.manual_seed(3)                                   # train.py:39
     model = SPAIR([1, args.image, args.image], None, dev, compute_dtype=args.dtype).to(dev)
-    ddp.attach(model, world)
+    # SPAIR_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of the three bucketed, overlapped ones
+    ddp.attach(model, world, overlap=os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0")
     if world > 1:
         ddp.broadcast_parameters(model.flat_parameters())
     opt = FusedAdam(model, lr=1e-4)
@@ -208,70 +421,16 @@ def main():
         return
 
     K = args.steps
-    Ks = len(range(0, K, args.prof_every))                                              # steps on which the event pairs were recorded
-    per_step_ms = {SLOT_NAMES[i]: ms[i] / Ks for i in range(nslots) if cnt[i] > 0}
-    avg = {SLOT_NAMES[i]: ms[i] / cnt[i] for i in range(nslots) if cnt[i] > 0}       # per launch / region
     d = model._last["engine"]["dims"]
-    N = B * d.G * d.G
-    P2 = d.P * d.P
-    sprite_b = N * P2 * 2 * (2 if args.dtype == "bf16" else 4)    # (grey, alpha) sprites: bf16 pairs in the bf16 step, fp32 otherwise
-    render_fwd_bytes = sprite_b + N * 6 * 4 + B * d.I * d.I * 4          # 429.4 MB at config 2
-    render_bwd_bytes = render_fwd_bytes + N * P2 * 2 * (2 if args.dtype == "bf16" else 4)   # + the d-logits write
-    peak_f = MFMA_PEAK_TFLOPS["bf16" if args.dtype == "bf16" else "f32"]
-    c1 = [c for c in [(d.conv_k[1], d.conv_s[1], d.conv_c[1])]][0]
-    h0 = (d.I + d.pad_pre + d.pad_post - d.conv_k[0]) // d.conv_s[0] + 1
-    h1 = (h0 - c1[0]) // c1[1] + 1
-    conv1_flop = 2.0 * B * h1 * h1 * c1[2] * (c1[0] * c1[0] * d.conv_c[0])
-    dec_out_flop = 2.0 * N * 256 * (P2 * 2)
-    # per-cell chain (k_chain_fwd / k_chain_bwd): arithmetic intensity ~50 flop/B, far left of the ridge (312 flop/B),
-    # so HBM is the roofline that bounds it.  Algorithmic bytes per row: what the kernel MUST move --
-    # forward: every layer input it has to keep for the weight-gradient GEMMs + latents/records + the glimpse derivative pairs.
-    A, NPc, Fc = d.A, d.NP, d.F
-    REC = 4 + A + 2                                                        # record [box4 | attr A | depth | pres]
-    box_in = Fc + 4 * REC                                                  # features + 4 neighbour records
-    z_in, glim = box_in + NPc + 4 + A, P2
-    o_in = z_in + 1
-    hid = 2 * 100 + (256 + 128) + 2 * 100 + 2 * 100                       # relu outputs of the four nets
-    if args.dtype == "bf16":
-        # the fused chain stores every GEMM operand as bf16, once: [features|context|box|attr|depth] (o_in columns, shared by the
-        # box/z/obj first layers), the glimpse, the relu outputs; the glimpse derivative pairs as bf16x2; fp32: the 308-float
-        # per-row bundle the elementwise backward reads and the record; relu sign bits; + (features, noise) loads
-        fwd_row = 2 * (o_in + glim + hid + A) + 4 * glim + 4 * (308 + REC) + 66 * 4 * 8 // 8 + 4 * (Fc + REC + 2)
-    else:
-        fwd_row = 4 * (box_in + glim + z_in + o_in + hid + REC + glim) + 4 * (Fc + REC + 2)    # fp32 stores + (features, noise) loads
-    outs = (100 + 100 + 8 + NPc) + (256 + 128 + 2 * A) + (100 + 100 + 2 + NPc) + (100 + 100 + 1)
-    # backward: the 308-float per-row bundle + the glimpse derivative pairs + relu sign bits (66 tiles x 4 x 8 B per <= 8 rows) in;
-    # layer-output gradients and d feat out as bf16
-    bwd_row = 4 * (308 + glim) + 66 * 4 * 8 // 8 + 2 * (outs + Fc)
-    chain_flop = 2.0 * N * (box_in * 100 + 100 * 100 + 100 * (8 + NPc) + glim * 256 + 256 * 128 + 128 * 2 * A
-                            + z_in * 100 + 100 * 100 + 100 * (2 + NPc) + o_in * 100 + 100 * 100 + 100)
-    kernels = {}
-
-    def add(name, bound, work, unit_scale, peak, unit, slot=None, **extra):
-        slot = slot or name
-        if slot in avg and avg[slot] > 0:
-            ach = work / (avg[slot] * 1e-3) / unit_scale
-            kernels[name] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_ms=avg[slot], traffic=None, **extra)
-
-    add("chain_bwd", "hbm", N * bwd_row, 1e9, HBM_PEAK_GBS, "GB/s", slot="cells_bwd", mfma_tflops=chain_flop / (avg.get("cells_bwd", 1) * 1e-3) / 1e12)
-    add("chain_fwd", "hbm", N * fwd_row, 1e9, HBM_PEAK_GBS, "GB/s", slot="cells_fwd", mfma_tflops=chain_flop / (avg.get("cells_fwd", 1) * 1e-3) / 1e12)
-    add("render_fwd", "hbm", render_fwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
-    add("render_bwd", "hbm", render_bwd_bytes, 1e9, HBM_PEAK_GBS, "GB/s")
-    add("conv1_fwd", "mfma", conv1_flop, 1e12, peak_f, "TFLOP/s")
-    add("dec_out_fwd", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
-    add("dec_out_dgrad", "mfma", dec_out_flop, 1e12, peak_f, "TFLOP/s")
-    # (decoder / per-cell weight gradients run on the helper stream beside the chain: their event times include the
-    #  overlap and are not per-kernel durations -- see profiles/ for the rocprofv3 kernel stats)
-    # HBM traffic per launch from the committed PMC passes of this same command (two separate rocprofv3 --pmc runs; FETCH_SIZE doubled
-    # as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload it was collected on.
-    pmc_path = os.path.join(ROOT, "profiles", "r02_d_pmc_traffic.json")
-    if os.path.exists(pmc_path) and B == 256 and args.image == 128 and args.dtype == "bf16":
-        pmc = json.load(open(pmc_path))
-        for name, rec in kernels.items():
-            if name in pmc:
-                rec["traffic"] = (pmc[name]["read_MB"] + pmc[name]["write_MB"]) * 1e6
-                rec["traffic_source"] = "profiles/r02_d_pmc_traffic.json"
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+    kernels, per_step_ms = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, args.prof_every)))
+    # K4 (the STN-forward gather is a stage of k_chain_fwd, not a launch): its share of the kernel from the in-kernel stage stamps of
+    # one extra step outside the timed region
+    stn = stn_fwd_from_stamps(model, step, d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
+    if stn:
+        kernels["stn_fwd"] = stn
+    attach_pmc_traffic(kernels, B, args.image, args.dtype)
+    timed = [k for k in kernels if kernels[k].get("avg_ms")]
+    dominant = max(timed, key=lambda k: kernels[k]["avg_ms"]) if timed else None
     roof = dict(kernels[dominant], kernel=dominant) if dominant else None
 
     if args.image == 128 and B == 256 and d.G == 16:
@@ -289,7 +448,8 @@ def main():
                            parallelism="dp%d" % world),
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
-    if args.sweep and world == 1:
+    default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16"
+    if world == 1 and not args.no_sweep and (args.sweep or default_workload):
         # BASELINE configs[4] on one GPU: the count-prior schedule (config.py:65-69, models.py:186-188) changes z_pres and with it the
         # renderer's active-cell density; same model state, only global_step differs between the points
         from spair_pytorch_amd.models import step_scalars
@@ -311,6 +471,10 @@ def main():
             sweep.append(dict(global_step=gs, count_prior_prob=float(st_.count_prior_prob), wheel=float(st_.wheel), ms_per_step=ms_s,
                               images_per_sec=B / ms_s * 1e3, mean_z_pres=float(last["z_pres"].mean().item())))
         out["sweep"] = sweep
+        out["sweep_note"] = "BASELINE configs[4] on ONE GPU (the 8-GPU form is the driver's): %d timed steps per point" % args.sweep_steps
+    if world == 1 and default_workload and not args.no_config3:
+        # BASELINE configs[3] (256x256, 32x32 grid, batch 64) as a bounded sub-record of the default line: its own model, a few steps
+        out["config3"] = config3_record(dev, args, strides)      # (the main model stays alive: two ~5 GB workspaces of 288 GB)
     out["hbm_measured"] = hbm_copy_rates(dev)      # what this box sustains, beside the vendor 8 TB/s the roofline divides by
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(strides)

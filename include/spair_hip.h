@@ -11,9 +11,11 @@
  *   - return 0 on success, a negative SPAIR_ERR_* code otherwise (shape / dtype / launch);
  *   - all step state lives in the buffers the caller passes.  The only library-owned objects are one low-priority helper HIP stream
  *     (+ 6 fork/join events) per device, created under a lock on first use or by spair_init(), and the opt-in profiling event pool
- *     (spair_prof_*, lock-protected, off by default).  Calls on different devices or different caller streams may run concurrently
- *     from different host threads as long as they use different workspaces; create the helper stream with spair_init() before
- *     capturing a step into a hipGraph.
+ *     (spair_prof_*, lock-protected, off by default).  Calls on different devices or different caller streams may be issued concurrently
+ *     from different host threads as long as they use different workspaces: the fork/join events are per device, so each
+ *     spair_forward / spair_backward holds that device's enqueue lock from its first fork to its last join (host-side only -- the
+ *     enqueued work of the two callers still overlaps on the GPU; tests/test_surface_gpu.py drives two models from two threads).
+ *     Create the helper stream with spair_init() before capturing a step into a hipGraph.
  */
 #pragma once
 #include <stddef.h>

@@ -793,7 +793,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Aa[MT * LD_H];
     __shared__ __attribute__((aligned(16))) __bf16 Ab[MT * LD_H];
     __shared__ float grec[MT][REC];
-    __shared__ float gnb[MT][4], nb_sh[MT][4];
+    __shared__ float gnbw[NW][MT][4], nb_sh[MT][4];      // gnbw: per-WAVE partial d nbox of the glimpse epilogue, summed in wave order (no atomics: run-to-run identical)
     __shared__ float dOo_sh[MT], zp_sh[MT];
     __shared__ float edge_acc[REC];
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
@@ -907,7 +907,6 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 cons_sh[tid][q] = ibundle_sh[tid][q];
                 nbr_row[tid][q] = ibundle_sh[tid][4 + q];
                 nb_sh[tid][q] = bundle_sh[tid][BD_NB + q];
-                gnb[tid][q] = 0.f;
             }
         }
         lds_barrier();
@@ -1122,10 +1121,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             wide_prefetch<4, 7>(a.wt[CW_BOXH], wave, lane, wpre);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { gs[k] = dpp_add_<0xB1>(gs[k]); gs[k] = dpp_add_<0x4E>(gs[k]); }      // the 4 lanes of a row
-            if ((lane & 3) == 0 && trow < nc) {
-                atomicAdd(&gnb[trow][0], 2.f * gs[0]); atomicAdd(&gnb[trow][1], 2.f * gs[1]);                   // tx = 2*xt - 1
-                atomicAdd(&gnb[trow][2], gs[2]); atomicAdd(&gnb[trow][3], gs[3]);
-            }
+            if ((lane & 3) == 0 && trow < nc)                                                                       // tx = 2*xt - 1
+                *reinterpret_cast<float4*>(&gnbw[wave][trow][0]) = make_float4(2.f * gs[0], 2.f * gs[1], gs[2], gs[3]);
         }
         lds_barrier();
         CB_STAMP();
@@ -1147,7 +1144,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const size_t r = row_r[row];
                 const float* bd = bundle_sh[row];
                 const float* st = bd + BD_ST;
-                const float gn = gnb[row][o] + bd[BD_GNB + o];
+                float gn = gnbw[0][row][o];
+#pragma unroll
+                for (int wv = 1; wv < NW; ++wv) gn += gnbw[wv][row][o];
+                gn += bd[BD_GNB + o];
                 const float gb = grec[row][o] + tailZ[row][NP + o] + tailO[row][NP + o];
                 const float mu = st[ST_MU_BOX + k], sd = st[ST_SD_BOX + k], eps = bd[BD_EB + k], lls = bd[BD_OBL + k], zp = zp_sh[row];
                 const float gq = k < 2 ? (gb + gn * H.cell_over_img) * (H.max_yx - H.min_yx) : (gb + gn * H.anchor / H.img) * (H.max_hw - H.min_hw);
@@ -1193,23 +1193,53 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             if (n < F) {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dfeat16) + ((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n) =
                     pack4(v.x, v.y, v.z, v.w);                                                          // read by the 1x1 stack
-            } else {
-                const int s = (n - F) / REC;
-                if (nbr_row[row][s] < 0) {
-                    float* e = &edge_acc[(n - F) - s * REC];
-                    atomicAdd(e, v.x); atomicAdd(e + 1, v.y); atomicAdd(e + 2, v.z); atomicAdd(e + 3, v.w);
-                }
             }
+        }
+        // out-of-grid context slots: element j of the edge record is owned by ONE thread, which adds the wavefront's (row, slot) terms
+        // in a fixed order (LDS atomics from the quad loop above gave sums that differed in the last bits from run to run)
+        if (tid >= NTH - 64 && tid < NTH - 64 + REC) {
+            const int j = tid - (NTH - 64);
+            float e = edge_acc[j];
+            for (int row = 0; row < nc; ++row) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (nbr_row[row][s] < 0) e += slot[row][F + s * REC + j];
+            }
+            edge_acc[j] = e;
         }
         bundle_park();                       // every reader of this wavefront's bundle is behind the BOX0 barrier
         lds_barrier();
         CB_STAMP();
     }
-    if (tid < REC) atomicAdd(&a.gedge[tid], edge_acc[tid]);
+    // per-sample partial of the edge element's gradient; chain_bwd's second launch adds the B partials in sample order
+    if (tid >= NTH - 64 && tid < NTH - 64 + REC) a.gedge_part[(size_t)b * REC + (tid - (NTH - 64))] = edge_acc[tid - (NTH - 64)];
+}
+
+// gedge[j] += sum_b part[b][j], samples in order (one thread per element, 8 loads in flight)
+__global__ __launch_bounds__(64) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge) {
+    const int j = threadIdx.x;
+    if (j >= REC) return;
+    float t = 0.f;
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(b + e) * REC + j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += v[e];
+    }
+    for (; b < B; ++b) t += part[(size_t)b * REC + j];
+    gedge[j] += t;
 }
 
 int chain_bwd(const ChainArgs& a, hipStream_t s) {
+    if (!a.gedge_part) return SPAIR_ERR_SHAPE;
     hipLaunchKernelGGL(k_chain_bwd, dim3(a.L.B), dim3(NTH), 0, s, a);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+int chain_edge_reduce(const ChainArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(64), 0, s, a.gedge_part, a.L.B, a.gedge);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

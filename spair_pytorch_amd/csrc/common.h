@@ -67,6 +67,14 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
 }
 
 #if defined(__HIPCC__)
+// Orders a wave's LDS writes before the LDS reads its OTHER lanes make afterwards, for data that never leaves the wave (wave-private
+// tiles / tables): the hardware already executes one wave's DS instructions in order; this states the ordering for the compiler, which
+// may otherwise move a load above a store it can prove distinct for the executing lane.  No instruction is emitted.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // 16-byte load through a buffer descriptor: an offset past num_records returns zeros, so a masked lane needs no select on the result
 // and -- what matters -- no branch around the load (hipcc turns `ok ? *p : 0` into a conditional load, and a conditional VM op makes
 // every later wait a vmcnt(0)).  The descriptor spans the whole 32-bit offset range; masked lanes pass BUF_OOB.

@@ -138,7 +138,7 @@ struct Ws {
     float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;     // Hd*, dLog, dHd*: bf16 in bf16 mode
     void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
     float *tn_part, *tn_part2;                          // split-K partial tiles of the weight-gradient GEMMs (caller's / helper stream)
-    float *aux, *bce_partial, *kl_partial, *klp;
+    float *aux, *bce_partial, *kl_partial, *klp, *gedge_part;
     unsigned long long* stamps;
     int ld_feat, ld_s;
     size_t total;
@@ -243,6 +243,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
+    w.gedge_part = c.take<float>((size_t)d.B * L.REC);
     w.stamps = c.take<unsigned long long>(4096);
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
@@ -340,10 +341,14 @@ struct Ctx {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[6];
+    std::mutex enq_mu;      // held for the whole enqueue of one spair_forward / spair_backward call that uses this helper stream
 };
 // One helper stream + its fork/join events PER DEVICE, created once under a lock (first use, or spair_init() ahead of a hipGraph
 // capture -- stream / event creation is not capturable).  They carry no data between calls: every call forks from and joins back
-// into the caller's stream, so concurrent steps on different caller streams of one device only share the helper queue's ordering.
+// into the caller's stream.  The six events are shared by every call on the device, so a call holds enq_mu from its first fork to its
+// last join: hipStreamWaitEvent binds to the record that precedes it at CALL time, hence two host threads driving two caller streams
+// of one device can never wait on each other's records (they only share the helper queue's ordering) -- without the lock thread A
+// could wait on the record thread B had just made on ITS stream and start its helper-stream weight gradients before its own producers.
 #define SP_MAX_DEVICES 64
 static SideStream g_side[SP_MAX_DEVICES];
 static std::mutex g_side_mu;
@@ -876,6 +881,8 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     P.z_where = z_where; P.z_pres = z_pres;
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));
+    std::unique_lock<std::mutex> enq_lock;
+    if (side) enq_lock = std::unique_lock<std::mutex>(side->enq_mu);
     {   // tables + per-step weight copies (helper stream) beside the input padding and the stem conv (caller's stream)
         hipStream_t const main_s = c.s;
         if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
@@ -1075,6 +1082,8 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     }
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));
+    std::unique_lock<std::mutex> enq_lock;
+    if (side) enq_lock = std::unique_lock<std::mutex>(side->enq_mu);
     hipStream_t const main_s = c.s;
     if (b16) {   // decoder, bf16-stored activations and gradients: the data-gradient chain stays on the caller's stream, the three
                  // weight gradients go to the helper stream and overlap with the (latency-bound) per-cell backward chain
@@ -1105,16 +1114,19 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     }
     // per-cell chain, reverse wavefront order
     const int ps_cells = prof_begin(PS_CELLS_BWD, c.s);
+    ChainArgs chain_args;
+    memset(&chain_args, 0, sizeof(chain_args));
     if (c.use_chain) {
         ChainArgs a;
         memset(&a, 0, sizeof(a));
         a.L = L; a.P = P; a.H = c.H;
         for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = reinterpret_cast<const uint4*>(c.w.chain_wt[i]);
         a.w_obj2 = params + PL.lin[LIN_OBJ2].w;
-        a.gedge = grads + PL.edge;
+        a.gedge = grads + PL.edge; a.gedge_part = c.w.gedge_part;
         a.x = x; a.I = d->I; a.Pp = d->P; a.ac = d->align_corners;
         a.stamps = (st->flags & 2) ? c.w.stamps : nullptr;
         TRY(chain_bwd(a, c.s));
+        chain_args = a;
     } else {
     for (int t = c.T - 1; t >= 0; --t) {
         const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
@@ -1147,6 +1159,7 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         if (side) c.tn_scratch = c.w.tn_part2;
         TRY(cells_wgrad_grouped(c, grads));
         c.tn_scratch = nullptr;
+        TRY(chain_edge_reduce(chain_args, c.s));       // the edge element's gradient: per-sample partials summed in sample order (off the critical path)
     } else {
     TRY(wgrad_lin(c, LIN_BOX0, P.dHb1, SP_LDH, P.Xb, L.ld_xb, grads, N));
     TRY(wgrad_lin(c, LIN_BOX1, P.dHb2, SP_LDH, P.Hb1, SP_LDH, grads, N));

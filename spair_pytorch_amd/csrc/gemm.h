@@ -43,6 +43,7 @@ struct GemmTN {
     // optional split-K scratch: each block stores its fp32 tile with plain coalesced stores to part[split][tile][128][128]
     // and a second kernel sums the splits and does C += sum (no atomics).  NULL / too small -> fp32 atomics into C.
     float* part; long long part_cap;    // capacity in floats
+    float* colpart;                     // filled by the gemm16.hip launcher: per-block column sums [split][tile][128] behind the partial tiles
     // gemm16.hip grouped launch: ngroup independent single-tile problems (M, N <= 128 each) over the same R rows in ONE launch +
     // ONE reduce pass -- per-layer launches of small weight gradients are pure overhead (the per-cell nets' 14 GEMMs = 36 tiles took
     // 0.74 ms, the backbone's four 1x1 layers 4 x 70 us).  Operand pointers are pre-offset to the tile's first column.  Requires `part`.

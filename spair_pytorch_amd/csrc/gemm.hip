@@ -624,9 +624,30 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTN g) {
 // Second stage of the split-K weight gradient: C[m][col(n)] += sum over splits of part[split][tile][m][n].
 // A workgroup owns 32 float4 elements; its 8 thread groups each sum every 8th split (coalesced 512 B rows), the
 // groups are combined through LDS and group 0 does the one read-modify-write of C.
-__global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
+__global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn, int n_main) {
     __shared__ float4 red[8][32];
     const int tiles = g.tiles_m * g.tiles_n, per = bm * bn / 4, bn4 = bn / 4;
+    if ((int)blockIdx.x >= n_main) {
+        // bias gradients: one workgroup per tile sums that tile's per-split column sums (g.colpart) in a fixed order
+        const int tile = blockIdx.x - n_main;
+        const int mt = tile % g.tiles_m, nt = tile / g.tiles_m;
+        const bool grouped = g.ngroup > 1;
+        const GemmTN::Tile& gt = g.tile[grouped ? nt : 0];
+        float* cs = grouped ? gt.colsum : (nt == 0 ? g.colsum_out : nullptr);
+        if (!cs) return;                                      // workgroup-uniform
+        const int Mst = grouped ? gt.Mstore : g.Mstore, mskip = grouped ? gt.m_skip : 0;
+        float* redc = reinterpret_cast<float*>(red);
+        const int col = threadIdx.x % bm, part = threadIdx.x / bm, np = 256 / bm;      // bm = 128: two partial sums per column
+        float t = 0.f;
+        for (int sp = part; sp < g.nsplit; sp += np) t += g.colpart[((size_t)sp * tiles + tile) * bm + col];
+        redc[part * bm + col] = t;
+        __syncthreads();
+        if (part != 0) return;
+        for (int q = 1; q < np; ++q) t += redc[q * bm + col];
+        const int m = mt * bm + col;
+        if (m >= mskip && m < mskip + Mst) cs[m - mskip] += t;
+        return;
+    }
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + el;
     const int tile = idx / per, e = idx - tile * per;
@@ -685,7 +706,13 @@ __global__ __launch_bounds__(256) void k_tn_reduce(GemmTN g, int bm, int bn) {
 }
 int spair_tn_reduce(const GemmTN& g, int bm, int bn, hipStream_t s) {
     const long long n4 = (long long)g.tiles_m * g.tiles_n * bm * bn / 4;
-    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, g, bm, bn);
+    const int n_main = (int)((n4 + 31) / 32);
+    bool any_colsum = false;
+    if (g.colpart && bm <= 256 && 256 % bm == 0) {
+        if (g.ngroup > 1) { for (int q = 0; q < g.ngroup; ++q) any_colsum = any_colsum || g.tile[q].colsum != nullptr; }
+        else any_colsum = g.colsum_out != nullptr;
+    }
+    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)(n_main + (any_colsum ? g.tiles_m * g.tiles_n : 0))), dim3(256), 0, s, g, bm, bn, n_main);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

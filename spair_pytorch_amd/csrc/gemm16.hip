@@ -1030,7 +1030,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(GemmTN g) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += scr[q * BM + m];
-            if (m0 + m >= g_mskip && m0 + m < g_mskip + g_Mstore) atomicAdd(&g_colsum[m0 + m - g_mskip], t);
+            // split-K partial path: this block's column sums go to colpart[split][tile][BM] and k_tn_reduce adds the splits in a fixed
+            // order (run-to-run identical bias gradients); without scratch, one atomic per column
+            if (g.colpart) g.colpart[((size_t)sp_ * (g.tiles_m * g.tiles_n) + (size_t)nt_ * g.tiles_m + mt_) * BM + m] = t;
+            else if (m0 + m >= g_mskip && m0 + m < g_mskip + g_Mstore) atomicAdd(&g_colsum[m0 + m - g_mskip], t);
         }
     }
     const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
@@ -1216,7 +1219,8 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
     if (ceil_div(g.R, rps) != nsplit) nsplit = ceil_div(g.R, rps);
     g.rows_per_split = rps; g.nsplit = nsplit; g.tiles_m = ceil_div(g.M, BM); g.tiles_n = g.ngroup > 1 ? g.ngroup : ceil_div(g.N, BN);
     dim3 grid(g.tiles_m * g.tiles_n * nsplit);
-    if (g.part && (long long)grid.x * BM * BN > g.part_cap) { if (g.ngroup > 1) return SPAIR_ERR_UNSUPPORTED; g.part = nullptr; }   // scratch too small: atomics
+    if (g.part && (long long)grid.x * (BM * BN + BM) > g.part_cap) { if (g.ngroup > 1) return SPAIR_ERR_UNSUPPORTED; g.part = nullptr; }   // scratch too small: atomics
+    g.colpart = g.part ? g.part + (size_t)grid.x * BM * BN : nullptr;     // per-block column sums (bias gradients) behind the partial tiles
     if (conv) {
         if (b_bf16) hipLaunchKernelGGL((gemm_tn16_kernel<true, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_tn16_kernel<true, false>), grid, dim3(256), 0, s, g);

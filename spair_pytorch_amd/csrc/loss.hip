@@ -7,12 +7,7 @@
 
 #define KL_MAXBINS 1025   // HW+1 for G <= 32
 
-// orders a wave's own LDS writes before its later reads of other lanes' values (no workgroup barrier: one wave per sample)
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wave_lds_fence(), common.h: orders a wave's own LDS writes before its later reads of other lanes' values -- one wave per sample here)
 // One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane), so a step is
 // register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
 // G = 32, where this kernel, not the decoder beside it, set the forward's length).

@@ -79,7 +79,9 @@ __global__ void k_metrics_final(const float* __restrict__ per_sample, int B, flo
         if (per_sample[2 * b] >= 0.f) { a += per_sample[2 * b]; ++nv; }
         c += per_sample[2 * b + 1];
     }
-    out[0] = a / (float)max(nv, 1);                                                            // == a / B when no scene is empty
+    // == a / B when no scene is empty; a batch of ONLY empty scenes has no mAP: NaN, as the reference's 0/0 gives (a caller can
+    // tell "no data" from an mAP of 0)
+    out[0] = nv > 0 ? a / (float)nv : __builtin_nanf("");
     out[1] = c / (float)B;
 }
 

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __rest
             }
             *reinterpret_cast<bf16x8*>(tw + m * C0_TP + q * 64 + j * 16) = o;
         }
-        // (a wave writes and reads only its own tile: program order and the compiler's lgkmcnt waits are enough)
+        wave_lds_fence();       // the tile is wave-private, but every lane reads what OTHER lanes wrote
         __bf16* drow = out + (((size_t)b * Hout + oy0 + r) * Hout + ox0) * 128;
         const int npx = min(16, Hout - ox0);
 #pragma unroll
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __rest
             // reads this tensor next, went 0.231 -> 0.210 ms as well)
             if (px < npx) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8));
         }
+        wave_lds_fence();       // ... and the next block's writes stay behind these reads
     }
 }
 

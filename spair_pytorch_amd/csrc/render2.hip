@@ -731,6 +731,9 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
         }
         for (int e = lane; e < RB2_ADJ_BYTES / 16; e += 64) reinterpret_cast<uint4*>(adjT)[e] = make_uint4(0u, 0u, 0u, 0u);
     }
+    // One wave per workgroup: every LDS hand-over below is between lanes of this wave.  wave_lds_fence() (common.h) states the order
+    // of each write phase and the reads that follow it for the compiler; it emits nothing.
+    wave_lds_fence();
     const int pw = PX1 - PX0 + 1;
     const int wsh = pw <= 16 ? 4 : 5, W = 1 << wsh, RPI = 64 >> wsh;
     const int col = lane & (W - 1), rsub = lane >> wsh;
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
             yt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
             sys[lane] = s;
         }
+        wave_lds_fence();
         for (int px0 = PX0; px0 <= PX1; px0 += W) {
             if (lane < 32) {
                 const int xx = px0 + lane;
@@ -773,6 +777,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 xt[lane] = make_float4(__int_as_float(off), f, gn, 0.f);
                 sxs[lane] = s;
             }
+            wave_lds_fence();
             // ---- pass A: adjoints of the chunk's pixels, two row groups per trip (A / B register sets: the loads of one are issued
             // before the arithmetic of the other)
             const int nit = (nrw + RPI - 1) >> (6 - wsh);
@@ -831,6 +836,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 inA = load_px(it + 2);
                 do_px(inB, it + 1);
             }
+            wave_lds_fence();          // pass A's adjoint tiles -> pass B's fragment reads
             // ---- pass B.  First product: T_c[py][u] = sum_px adj_c[py][px] * Wx[px][u] for this chunk (fresh accumulators: nothing of
             // pass B is live during pass A).  Second product right behind it: dS_c[v][u] += sum_py Wy[py][v] * T_c[py][u].  T's
             // accumulator tile is the B operand of v_mfma_f32_16x16x16_bf16 as it stands (lane group q holds K = 4q .. 4q+3 = the tile
@@ -853,6 +859,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                 dS[c][0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy0), __builtin_bit_cast(rb2_s16x4, tb1), dS[c][0][1], 0, 0, 0);
                 dS[c][1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(rb2_s16x4, wy1), __builtin_bit_cast(rb2_s16x4, tb1), dS[c][1][1], 0, 0, 0);
             }
+            wave_lds_fence();          // pass B's reads of the tiles / tables -> the next chunk's writes
         }
     }
     // ---- epilogue: per texel sigmoid' and logit scales (models.py:485-492), d pres / d depth; d-logits staged in LDS (over the adjoint tiles)
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
                     ost[v * P + u] = *reinterpret_cast<unsigned*>(ob);
                 }
             }
+    wave_lds_fence();                  // per-texel d-logit staging -> the 16-byte pieces read back below
     {
         char* dst = reinterpret_cast<char*>(dlogits + (size_t)r * ld_g);
         const int npieces = (P * P * 4) >> 4;

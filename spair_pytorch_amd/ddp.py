@@ -30,7 +30,7 @@ BUCKET_NAMES = ("decoder", "cell_nets", "backbone+edge")
 class GradBuckets:
     """The three readiness events + flat-buffer ranges of a model (created by ``attach``)."""
 
-    def __init__(self, model):
+    def __init__(self, model, timing=False):
         lib = L.lib()
         d = model._dims(1)
         lo, hi = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
@@ -38,7 +38,7 @@ class GradBuckets:
         self.ranges = [(int(lo[i]), int(hi[i])) for i in range(3)]
         dev = model.device
         with torch.cuda.device(dev):
-            self.events = [torch.cuda.Event(enable_timing=False) for _ in range(3)]
+            self.events = [torch.cuda.Event(enable_timing=bool(timing)) for _ in range(3)]      # timing: the overlap-window measurement only
             for e in self.events:
                 e.record()                 # materialises the hipEvent_t behind the torch object
             self.comm = torch.cuda.Stream(device=dev)
@@ -48,11 +48,12 @@ class GradBuckets:
         return [ctypes.c_void_p(e.cuda_event) for e in self.events]
 
 
-def attach(model, world_size=None, overlap=True):
+def attach(model, world_size=None, overlap=True, timing=False):
     """Marks ``model`` as one of ``world_size`` replicas (sharded-loss scaling) and, with ``overlap``,
-    arms the bucket events its backward records."""
+    arms the bucket events its backward records.  ``overlap=False`` (bench.py: SPAIR_DDP_OVERLAP=0) keeps the
+    plain path: one all-reduce of the whole flat gradient on the caller's stream after the backward."""
     model.world_size = int(world_size if world_size is not None else dist.get_world_size())
-    model._grad_buckets = GradBuckets(model) if (overlap and model.device.type == "cuda" and model.world_size > 1) else None
+    model._grad_buckets = GradBuckets(model, timing) if (overlap and model.device.type == "cuda" and model.world_size > 1) else None
     return model
 
 

@@ -31,7 +31,8 @@ def _both(z_where, z_pres, ground_truth_bbox, truth_bbox_digit_count, image_side
 
 
 def mAP(z_where, z_pres, ground_truth_bbox, truth_bbox_digit_count, image_side=None):
-    """Mean average precision @ IoU [0.1:0.1:0.9] of the best predicted box per label box (metric.py:5-47)."""
+    """Mean average precision @ IoU [0.1:0.1:0.9] of the best predicted box per label box (metric.py:5-47).  Scenes without objects
+    (0/0 in the reference) are left out of the batch mean; a batch of only such scenes returns NaN."""
     return _both(z_where, z_pres, ground_truth_bbox, truth_bbox_digit_count, image_side)[0]
 
 

@@ -16,6 +16,7 @@ step, train.py:64-67) runs unchanged.  All arithmetic of the step is in libspair
 import ctypes
 import os
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -94,6 +95,11 @@ class _NullWriter:
         return lambda *a, **k: None
 
 
+class _Engine(dict):
+    """One batch size's workspace + noise maps + dims (a dict that can be weakly referenced)."""
+    __slots__ = ("__weakref__",)
+
+
 class _StepFn(torch.autograd.Function):
     """Ties the hand-written backward into autograd.  ``anchor`` is a dummy differentiable leaf:
     the parameter gradients are accumulated straight into the flat gradient buffer (the views
@@ -103,10 +109,11 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, x, step, noise):
         loss_terms, recon, z_where, z_pres = model._run_forward(x, step, noise, train=True)
         ctx.model, ctx.x, ctx.step, ctx.noise = model, x, step, noise
-        # the saved activations live in the engine's workspace, not in autograd: remember WHICH forward filled it (and keep the
-        # engine alive), so a backward through a workspace that a later forward has overwritten raises instead of being silently wrong
-        ctx.engine = model._last["engine"]
-        ctx.generation = ctx.engine["generation"]
+        # the saved activations live in the engine's workspace, not in autograd: remember WHICH forward filled it, so a backward through
+        # a workspace that a later forward has overwritten (or that the engine cache has dropped) raises instead of being silently wrong.
+        # A weak reference: the graph must not keep a multi-GB workspace alive after the cache evicted it.
+        ctx.engine_ref = weakref.ref(model._last["engine"])
+        ctx.generation = model._last["engine"]["generation"]
         ctx.mark_non_differentiable(recon, z_where, z_pres)
         ctx.set_materialize_grads(False)     # otherwise autograd zero-fills a gradient for each non-differentiable output (17 MB per step)
         model._loss_terms = loss_terms
@@ -116,11 +123,13 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, g_loss, g_recon, g_zw, g_zp):
         if g_loss is None:
             return None, None, None, None, None
-        if ctx.engine["generation"] != ctx.generation:
+        engine = ctx.engine_ref()
+        if engine is None or engine["generation"] != ctx.generation:
             raise L.SpairHipError(
-                "backward() of a SPAIR forward whose saved activations were overwritten by a later forward of the same batch size "
-                "(the engine keeps ONE set of activations per batch size; call backward before the next forward of that size)")
-        ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float(), ctx.engine)
+                "backward() of a SPAIR forward whose saved activations were overwritten by a later forward of the same batch size, or "
+                "whose workspace the engine cache has dropped (the engine keeps ONE set of activations per batch size and "
+                "`max_engines` batch sizes; call backward before the next forward of that size)")
+        ctx.model._run_backward(ctx.x, ctx.step, ctx.noise, g_loss.contiguous().float(), engine)
         return None, None, None, None, None      # the parameter gradients went straight into the flat buffer
 
 
@@ -143,7 +152,10 @@ class SPAIR(nn.Module):
         self._flat = None
         self._flat_grad = None
         self._engines = {}
-        self.max_engines = 2         # workspaces kept alive (one per batch size, least recently used dropped): train + eval / last partial batch
+        # workspaces kept alive (one per batch size, least recently used dropped).  None = automatic: a second one (eval batch / last
+        # partial batch beside the training batch) only while all live workspaces together stay under a quarter of the device's
+        # memory, otherwise exactly one (they are ~5 GB each at B=256 / 128x128)
+        self.max_engines = None
         self._grad_buckets = None    # set by spair_pytorch_amd.ddp.attach: readiness events for the overlapped all-reduce
         self._anchor = None
         self._loss_terms = None
@@ -284,12 +296,16 @@ class SPAIR(nn.Module):
                                       (batch, self.image_shape, self.backbone.topology))
             G, A = d.G, d.A
             dev = self.device
-            e = dict(dims=d, generation=0,
+            limit = self.max_engines
+            if limit is None:
+                live = sum(int(v["workspace"].numel()) for v in self._engines.values())
+                limit = 2 if (live + nbytes) <= torch.cuda.get_device_properties(dev).total_memory // 4 else 1
+            while len(self._engines) >= max(1, limit):      # evict BEFORE allocating: two multi-GB workspaces never coexist needlessly
+                self._engines.pop(next(iter(self._engines)))
+            e = _Engine(dims=d, generation=0,
                      workspace=torch.zeros(nbytes, dtype=torch.uint8, device=dev),   # zero-initialised ONCE
                      noise=dict(eps_box=torch.empty(batch, 4, G, G, device=dev), eps_attr=torch.empty(batch, A, G, G, device=dev),
                                 eps_depth=torch.empty(batch, 1, G, G, device=dev), u_pres=torch.empty(batch, 1, G, G, device=dev)))
-            while len(self._engines) >= max(1, self.max_engines):      # workspaces are GBs at B=256: keep the most recent few
-                self._engines.pop(next(iter(self._engines)))
         else:
             self._engines.pop(batch)
         self._engines[batch] = e         # most recently used last

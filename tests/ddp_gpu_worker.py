@@ -20,14 +20,21 @@ def main():
     from spair_pytorch_amd import config as cfg, ddp
     from spair_pytorch_amd.models import SPAIR
     from spair_pytorch_amd.optim import FusedAdam
-    torch.cuda.set_device(0)
-    dist.init_process_group(os.environ.get("SPAIR_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+    backend = os.environ.get("SPAIR_DIST_BACKEND", "gloo")
+    # gloo: every rank on cuda:0 (one-GPU box); nccl (= RCCL): one GPU per rank, only where the box has that many
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     z, case = load_case(case_name)
     cfg.set_grid(case["I"], case["strides"])
     m = SPAIR([1, case["I"], case["I"]], None, torch.device("cuda"), compute_dtype=dtype).to("cuda")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in gi.make_weights(case["wseed"], case["wscale"]).items()})
-    ddp.attach(m, world)                       # sharded-loss scaling + bucket events
-    assert m._grad_buckets is not None
+    overlap = os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0"
+    ddp.attach(m, world, overlap=overlap)      # sharded-loss scaling + bucket events
+    assert (m._grad_buckets is not None) == overlap
     ddp.broadcast_parameters(m.flat_parameters())
     B = z["x"].shape[0]
     lo, hi = rank * B // world, (rank + 1) * B // world
@@ -37,15 +44,15 @@ def main():
     opt.zero_grad()
     loss = m(x, int(z["global_step"]), noise=noise)[0]
     loss.backward()
-    assert m._grad_buckets.pending
-    ddp.allreduce_gradients(m)                 # three buckets, each behind its readiness event, on the communication stream
+    assert not overlap or m._grad_buckets.pending
+    ddp.allreduce_gradients(m)                 # three buckets, each behind its readiness event, on the communication stream (or one, plain)
     terms = ddp.global_loss(m.loss_terms().clone())
     grads = m.flat_gradients().clone()
     opt.step()
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(out_path, grads=grads.cpu().numpy(), terms=terms.cpu().numpy(), params=m.flat_parameters().cpu().numpy(),
-                 ranges=np.array(m._grad_buckets.ranges))
+                 ranges=np.array(ddp.GradBuckets(m).ranges))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -25,15 +25,24 @@ def _free_port():
     return p
 
 
+# (backend, overlapped buckets): gloo with both ranks on the box's one GPU always; RCCL ("nccl") only where the box has two GPUs -- the
+# collective then runs on RCCL's internal stream behind the communication stream's events; the plain single-bucket path is the fallback
+# bench.py selects with SPAIR_DDP_OVERLAP=0
+_MODES = [("gloo", "1"), ("gloo", "0")] + ([("nccl", "1"), ("nccl", "0")] if torch.cuda.device_count() >= 2 else [])
+
+
+@pytest.mark.parametrize("backend,overlap", _MODES)
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2)])
-def test_two_ranks_overlapped_allreduce_equals_global_batch(tmp_path, dtype, tol):
+def test_two_ranks_overlapped_allreduce_equals_global_batch(tmp_path, dtype, tol, backend, overlap):
+    if backend == "gloo" and overlap == "0" and dtype == "f32":
+        pytest.skip("covered by the bf16 case")
     name = "c1_b8_step1001"
     out = str(tmp_path / "rank0.npz")
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPAIR_DIST_BACKEND="gloo",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPAIR_DIST_BACKEND=backend,
+                   SPAIR_DDP_OVERLAP=overlap, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out, name, dtype], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []

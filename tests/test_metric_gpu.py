@@ -80,3 +80,6 @@ def test_map_skips_empty_scenes_and_accepts_flat_counts():
     assert abs(m.item() - ref.item()) <= 5e-6 * max(1.0, abs(ref.item()))
     m2 = metric.mAP(zw.cuda(), zp.cuda(), bb.cuda(), cnt.view(-1, 1).cuda(), image_side=I)
     assert m2.item() == m.item()
+    # a batch of ONLY empty scenes has no mAP: NaN, as the reference's 0/0 (metric.py:45) -- distinguishable from a true 0
+    none = metric.mAP(zw[:2].cuda(), zp[:2].cuda(), torch.zeros(2, K, 4).cuda(), torch.zeros(2).cuda(), image_side=I)
+    assert torch.isnan(none).item()

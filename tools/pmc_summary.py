@@ -32,6 +32,12 @@ if len(sys.argv) > 3:      # optional: the four kernels bench.py prices, as JSON
     names = {"chain_bwd": "k_chain_bwd", "chain_fwd": "k_chain_fwd", "render_fwd": "k_render_fwd", "render_bwd": "k_render_bwd"}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1`; "
                      "FETCH_SIZE doubled (gfx950), per launch"}
+    # hashes of the kernel sources this was collected on: bench.py refuses to quote the traffic once they change
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out["src_sha16"] = {}
+    for src in ("spair_pytorch_amd/csrc/chain.hip", "spair_pytorch_amd/csrc/render2.hip"):
+        out["src_sha16"][src] = hashlib.sha256(open(os.path.join(root, src), "rb").read()).hexdigest()[:16]
     for key, kn in names.items():
         for tot, k, calls, rd, wr in rows:
             if kn in k:
