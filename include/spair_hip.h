@@ -51,7 +51,8 @@ typedef struct SpairStep {
     int train;                 /* 1: keep what backward needs */
     int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps;
                                 * bit 2: no helper stream (every kernel on the caller's stream);
-                                * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient) */
+                                * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient);
+                                * bit 4: decoder forward as three GEMM launches instead of the fused activation-stationary kernel */
     int draw_noise;            /* spair_forward only: 1 = fill eps_box/eps_attr/eps_depth/u_pres from noise_seed first (what spair_noise_fill
                                 * does, but on the helper stream beside the backbone); the buffers must be writable */
     unsigned long long noise_seed;
@@ -188,6 +189,14 @@ int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const fl
  * cores with split-bf16 operands (three products, fp32 accumulation): agrees with the fp32 result to < 2^-15 relative before the store. */
 int spair_stem_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int I, int pad_pre, int Hin, int Hout,
                         int Cout, int stride, int out_bf16, void* stream);
+/* The bf16 step's object-decoder FORWARD (reference models.py:474-492: Linear 50->128, ReLU, Linear 128->256, ReLU, Linear 256->P*P*2, the sprite
+ * scales and analytic sigmoid) as one activation-stationary kernel (csrc/dec_fused.hip).  z_attr16: bf16 [N][ld_za] (columns >= A ignored);
+ * W*, b*: the fp32 parameters, row-major [out][in]; H1 / H2: bf16 [N][128] / [N][256] hidden activations (stored for the backward);
+ * sprites: fp16 [N][ld_s] (grey, alpha) pairs; stream_buf: spair_decoder_fwd16_scratch_bytes(n_out) bytes of scratch (the packed weights). */
+int64_t spair_decoder_fwd16_scratch_bytes(int n_out);
+int spair_decoder_fwd16(const void* z_attr16, int ld_za, const float* W0, const float* b0, const float* W1, const float* b1,
+                        const float* W2, const float* b2, void* H1, void* H2, void* sprites, int ld_s, long long N, int A, int n_out,
+                        float obj_scale, float alpha_scale, float alpha_bias, void* stream_buf, void* stream);
 /* the same with 16-bit sprites, as the bf16 training step runs them: sprites are FP16 (grey, alpha) pairs [N][ld_s] (post-sigmoid values
  * in (0,1): 11 significant bits), d-logits come back as BF16 [N][ld_s] */
 int spair_render_fwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,

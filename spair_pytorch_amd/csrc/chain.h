@@ -12,7 +12,7 @@ struct ChainArgs {
     const uint4* wt[CW_COUNT];    // data-gradient packs (k_prep mode 5): B[k=out][n=in]
     const float* w_obj2;          // obj_network.out.weight [1,100] fp32 (rank-1 data-gradient)
     float* gedge;                 // gradient of virtual_edge_element
-    float* gedge_part;            // [B][REC] per-sample partials of it (k_chain_bwd writes, chain_edge_reduce sums them in sample order)
+    float* gedge_part;            // [B][4][REC] per-(sample, neighbour slot) partials of it (k_chain_bwd writes, chain_edge_reduce sums them in sample order)
     unsigned long long* stamps;   // diagnostic: s_memtime after every stage of sample 0 (null in production)
     const float* x;
     int I, Pp, ac;

@@ -795,7 +795,6 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ float grec[MT][REC];
     __shared__ float gnbw[NW][MT][4], nb_sh[MT][4];      // gnbw: per-WAVE partial d nbox of the glimpse epilogue, summed in wave order (no atomics: run-to-run identical)
     __shared__ float dOo_sh[MT], zp_sh[MT];
-    __shared__ float edge_acc[REC];
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
     __shared__ float gtile[NW][16][17];       // wave-private transpose tile of the glimpse-gradient epilogue
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
@@ -832,7 +831,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     for (int i = tid; i < 4 * MT * LD_R; i += NTH) (&ring[0][0][0])[i] = 0.f;
     for (int i = tid; i < MT * KX; i += NTH) { (&tailO[0][0])[i] = 0.f; (&tailZ[0][0])[i] = 0.f; }
     for (int i = tid; i <= T; i += NTH) dstart_sh[i] = P.diag_start[i];
-    if (tid < REC) edge_acc[tid] = 0.f;
+    float edge_reg = 0.f;                    // threads NTH/2 .. NTH/2 + 4*REC: running sum of one (neighbour slot, record element) of the edge gradient
     __syncthreads();
 
     // ---- bundle prefetch: thread (row = tid>>5, l = tid&31) owns two 16-byte and two 4-byte items of that row.  Bases, strides
@@ -1195,40 +1194,41 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                     pack4(v.x, v.y, v.z, v.w);                                                          // read by the 1x1 stack
             }
         }
-        // out-of-grid context slots: element j of the edge record is owned by ONE thread, which adds the wavefront's (row, slot) terms
-        // in a fixed order (LDS atomics from the quad loop above gave sums that differed in the last bits from run to run)
-        if (tid >= NTH - 64 && tid < NTH - 64 + REC) {
-            const int j = tid - (NTH - 64);
-            float e = edge_acc[j];
+        // out-of-grid context slots feed the edge element: thread (s, j) owns element j of neighbour slot s and adds the wavefront's rows
+        // in row order into a REGISTER that lives across the wavefronts (LDS atomics from the quad loop above gave sums that differed in
+        // the last bits from run to run; a single owner thread walking all (row, slot) pairs cost ~1 us per wavefront)
+        if (tid >= NTH / 2 && tid < NTH / 2 + 4 * REC) {
+            const int es = (tid - NTH / 2) / REC, ej = (tid - NTH / 2) - es * REC;
+            float add = 0.f;
             for (int row = 0; row < nc; ++row) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (nbr_row[row][s] < 0) e += slot[row][F + s * REC + j];
+                const float v = slot[row][F + es * REC + ej];
+                add += nbr_row[row][es] < 0 ? v : 0.f;
             }
-            edge_acc[j] = e;
+            edge_reg += add;
         }
         bundle_park();                       // every reader of this wavefront's bundle is behind the BOX0 barrier
         lds_barrier();
         CB_STAMP();
     }
-    // per-sample partial of the edge element's gradient; chain_bwd's second launch adds the B partials in sample order
-    if (tid >= NTH - 64 && tid < NTH - 64 + REC) a.gedge_part[(size_t)b * REC + (tid - (NTH - 64))] = edge_acc[tid - (NTH - 64)];
+    // per-(sample, neighbour slot) partials of the edge element's gradient; chain_edge_reduce adds them in a fixed order
+    if (tid >= NTH / 2 && tid < NTH / 2 + 4 * REC) a.gedge_part[(size_t)b * 4 * REC + (tid - NTH / 2)] = edge_reg;
 }
 
-// gedge[j] += sum_b part[b][j], samples in order (one thread per element, 8 loads in flight)
+// gedge[j] += sum_b sum_s part[b][s][j], in (sample, slot) order (one thread per element, 8 loads in flight)
 __global__ __launch_bounds__(64) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge) {
     const int j = threadIdx.x;
     if (j >= REC) return;
     float t = 0.f;
-    int b = 0;
-    for (; b + 8 <= B; b += 8) {
+    const int n = 4 * B;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(b + e) * REC + j];
+        for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(i + e) * REC + j];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t += v[e];
     }
-    for (; b < B; ++b) t += part[(size_t)b * REC + j];
+    for (; i < n; ++i) t += part[(size_t)i * REC + j];
     gedge[j] += t;
 }
 

@@ -13,6 +13,7 @@
 #include "gemm.h"
 #include "misc.h"
 #include "chain.h"
+#include "dec_fused.h"
 
 // kernels in other translation units
 int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, int px16, hipStream_t s);
@@ -131,6 +132,7 @@ struct Ws {
     float *bias_boxh, *bias_zh;
     void* chain_w[CW_COUNT];      // fragment-packed weights for the fused chain (bf16)
     void* chain_wt[CW_COUNT];     // ... and their data-gradient packs
+    void* dec_stream;             // fused decoder forward: fragment stream of its three weight matrices (bf16 mode)
     float* xpad;
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
     float *feat, *dfeat;
@@ -198,6 +200,7 @@ static Ws carve(const SpairDims& d, void* base) {
         const int ktb[CW_COUNT] = {4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0};
         for (int i = 0; i < CW_COUNT; ++i) w.chain_wt[i] = ntb[i] ? c.take_bytes((size_t)ntb[i] * ktb[i] * 1024) : nullptr;
     }
+    w.dec_stream = d.dtype == SPAIR_BF16 ? c.take_bytes(dec_fused_stream_bytes(d.P * d.P * (d.C + 1))) : nullptr;
     // backbone
     const int Ip = d.I + d.pad_pre + d.pad_post;
     w.xpad = c.take<float>((size_t)d.B * Ip * Ip * d.C);
@@ -243,7 +246,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
-    w.gedge_part = c.take<float>((size_t)d.B * L.REC);
+    w.gedge_part = c.take<float>((size_t)d.B * 4 * L.REC);
     w.stamps = c.take<unsigned long long>(4096);
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
@@ -328,6 +331,7 @@ struct Ctx {
     hipStream_t s;
     int T;                 // number of wavefront diagonals
     int use_chain;         // fused persistent per-cell kernels (bf16, reference network sizes)
+    int use_dec_fused;     // the decoder forward as one activation-stationary kernel (bf16; SpairStep.flags bit 4 turns it off)
     float* tn_scratch = nullptr;   // split-K scratch override while work is being issued on the helper stream
     std::vector<int> dstart;
 };
@@ -418,6 +422,8 @@ static int make_ctx(Ctx& c, const SpairDims* d, const SpairStep* st, const float
     c.w.cb.eps_box = eps_box; c.w.cb.eps_attr = eps_attr; c.w.cb.eps_depth = eps_depth; c.w.cb.u_pres = u_pres;
     fill_diag(c);
     c.use_chain = chain_fwd_supported(*d) && !(st->flags & 1);
+    c.use_dec_fused = d->dtype == SPAIR_BF16 && !(st->flags & 16) && c.PL.lin[LIN_DEC0].out == SP_DEC_H1 && c.PL.lin[LIN_DEC1].out == SP_DEC_H2 &&
+                      dec_fused_supported(d->A, d->P * d->P * (d->C + 1), c.L.ld_rec, c.L.N, c.w.ld_s) && d->C == 1;
     return SPAIR_OK;
 }
 
@@ -566,6 +572,9 @@ static int prep_weights(Ctx& c, bool need_dgrad, int part) {
             packt(CW_OBJ0, LIN_OBJ0, 4, 0); packt(CW_OBJ1, LIN_OBJ1, 4, 0);
         }
     }
+    if (part == 1 && c.use_dec_fused)
+        TRY(dec_fused_pack(c.params + c.PL.lin[LIN_DEC0].w, c.params + c.PL.lin[LIN_DEC1].w, c.params + c.PL.lin[LIN_DEC2].w, c.d.A,
+                           c.d.P * c.d.P * (c.d.C + 1), c.w.dec_stream, c.s));
     if (part == 1) {
         push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
         push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
@@ -926,8 +935,14 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         ProfScope ps(PS_DECODER_FWD, c.s);
         const int b16 = d->dtype == SPAIR_BF16;
         const int K0 = round_up(PL.lin[LIN_DEC0].in, 8), K2 = round_up(PL.lin[LIN_DEC2].in, 8);
+        if (b16 && !c.use_chain) TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));     // the fused chain writes bf16 itself
+        if (c.use_dec_fused) {
+            // all three layers + the sprite epilogue in one activation-stationary launch (dec_fused.hip)
+            ProfScope p2(PS_DEC2_FWD, c.s);
+            TRY(dec_fused_fwd(c.w.Za16, L.ld_rec, c.w.dec_stream, params + PL.lin[LIN_DEC0].b, params + PL.lin[LIN_DEC1].b, params + PL.lin[LIN_DEC2].b,
+                              c.w.Hd1, c.w.Hd2, c.w.S, c.w.ld_s, N, d->A, per, d->obj_logit_scale, d->alpha_logit_scale, d->alpha_logit_bias, c.s));
+        } else {
         if (b16) {   // hidden activations stored as bf16
-            if (!c.use_chain) TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));     // the fused chain writes bf16 itself
             TRY(nt16(c, c.w.Za16, L.ld_rec, c.w.lin_wf[LIN_DEC0], K0, c.w.Hd1, SP_DEC_H1, 1, N, SP_DEC_H1, K0, params + PL.lin[LIN_DEC0].b, nullptr, 0, 1));
             TRY(nt16(c, c.w.Hd1, SP_DEC_H1, c.w.lin_wf[LIN_DEC1], SP_DEC_H1, c.w.Hd2, SP_DEC_H2, 1, N, SP_DEC_H2, SP_DEC_H1,
                      params + PL.lin[LIN_DEC1].b, nullptr, 0, 1));
@@ -945,6 +960,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             g.obj_scale = d->obj_logit_scale; g.alpha_scale = d->alpha_logit_scale; g.alpha_bias = d->alpha_logit_bias;
             if (b16) TRY(spair_gemm_nt16_impl(g, false, c.s));
             else TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
+        }
         }
     }
     // KL + render + loss

@@ -176,3 +176,45 @@ def test_stem_conv_mfma_vs_torch(B, I, pre, post):
     got, want = o16.float().cpu(), ref.bfloat16().float()
     assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
     assert (got != want).float().mean().item() < 5e-3
+
+
+@pytest.mark.parametrize("N", [72, 1000, 8192])
+def test_decoder_fused_fwd_vs_torch(N):
+    """dec_fused.hip (the bf16 step's decoder forward, models.py:474-492, as ONE activation-stationary kernel) through its C-ABI entry
+    point against torch fp32 on the same bf16-rounded weights: the stored hidden activations (what the weight gradients / relu gates
+    read) to one bf16 step, the fp16 sprites to the rounding of a bf16-operand product.  N = 72 / 1000: partial 256-row blocks."""
+    import ctypes
+    L = _L()
+    A, LDZ, H1, H2, NO, LDS_ = 50, 56, 128, 256, 1568, 1568
+    g = torch.Generator().manual_seed(N)
+    za = torch.randn(N, LDZ, generator=g)
+    za[:, A:] = 3.0                                   # pad columns: finite garbage, must not matter
+    W0, b0 = torch.randn(H1, A, generator=g) * 0.2, torch.randn(H1, generator=g) * 0.1
+    W1, b1 = torch.randn(H2, H1, generator=g) * 0.1, torch.randn(H2, generator=g) * 0.1
+    W2, b2 = torch.randn(NO, H2, generator=g) * 0.08, torch.randn(NO, generator=g) * 0.1
+    obj_s, al_s, al_b = 2.0, 0.1, 5.0
+    rb = lambda t: t.to(torch.bfloat16).float()
+    za16 = za.to(torch.bfloat16)
+    h1 = rb(torch.relu(za16.float()[:, :A] @ rb(W0).t() + b0))
+    h2 = rb(torch.relu(h1 @ rb(W1).t() + b1))
+    lg = (h2 @ rb(W2).t() + b2).view(N, NO // 2, 2)
+    ref = torch.stack([torch.sigmoid(lg[..., 0] * obj_s), torch.sigmoid(lg[..., 1] * al_s + al_b)], -1).view(N, NO)
+    lib = L.lib()
+    lib.spair_decoder_fwd16_scratch_bytes.restype = ctypes.c_int64
+    scratch = torch.zeros(int(lib.spair_decoder_fwd16_scratch_bytes(NO)), dtype=torch.uint8, device="cuda")
+    H1d = torch.full((N, H1), -7.0, dtype=torch.bfloat16, device="cuda")
+    H2d = torch.full((N, H2), -7.0, dtype=torch.bfloat16, device="cuda")
+    S = torch.full((N + 1, LDS_), -7.0, dtype=torch.float16, device="cuda")       # one guard row behind the last
+    dv = [t.cuda().contiguous() for t in (W0, b0, W1, b1, W2, b2)]
+    L.check(lib.spair_decoder_fwd16(L.ptr(za16.cuda()), LDZ, L.ptr(dv[0]), L.ptr(dv[1]), L.ptr(dv[2]), L.ptr(dv[3]), L.ptr(dv[4]), L.ptr(dv[5]),
+                                    L.ptr(H1d), L.ptr(H2d), L.ptr(S), LDS_, ctypes.c_longlong(N), A, NO, ctypes.c_float(obj_s),
+                                    ctypes.c_float(al_s), ctypes.c_float(al_b), L.ptr(scratch), L.stream()), "decoder fwd16")
+    torch.cuda.synchronize()
+    assert (S[N] == -7.0).all().item()                                            # nothing written past the last row
+    for got, want, name in ((H1d, h1, "h1"), (H2d, h2, "h2")):
+        d = (got.float().cpu() - want).abs()
+        assert (d <= 0.0079 * want.abs() + 1e-6).all().item(), (name, float(d.max()))     # one bf16 step (2^-7)
+        assert (d > 0).float().mean().item() < 0.02, name                           # ... and only where a rounding boundary was crossed
+    ds = (S[:N].float().cpu() - ref).abs()
+    assert ds.max().item() < 4e-3, float(ds.max())
+    assert ds.mean().item() < 2e-4
