@@ -211,10 +211,18 @@ def test_decoder_fused_fwd_vs_torch(N):
                                     ctypes.c_float(al_s), ctypes.c_float(al_b), L.ptr(scratch), L.stream()), "decoder fwd16")
     torch.cuda.synchronize()
     assert (S[N] == -7.0).all().item()                                            # nothing written past the last row
-    for got, want, name in ((H1d, h1, "h1"), (H2d, h2, "h2")):
-        d = (got.float().cpu() - want).abs()
-        assert (d <= 0.0079 * want.abs() + 1e-6).all().item(), (name, float(d.max()))     # one bf16 step (2^-7)
-        assert (d > 0).float().mean().item() < 0.02, name                           # ... and only where a rounding boundary was crossed
-    ds = (S[:N].float().cpu() - ref).abs()
-    assert ds.max().item() < 4e-3, float(ds.max())
-    assert ds.mean().item() < 2e-4
+    # layer by layer, each against torch on the kernel's OWN stored input of that layer (a flipped bf16 rounding of h1 would otherwise
+    # propagate into h2 as an absolute error unrelated to h2's magnitude): one bf16 step (2^-7) where the fp32 sums differ in the last bits
+    H1c, H2c = H1d.float().cpu(), H2d.float().cpu()
+    h2_own = rb(torch.relu(H1c @ rb(W1).t() + b1))
+    lg_own = (H2c @ rb(W2).t() + b2).view(N, NO // 2, 2)
+    ref_own = torch.stack([torch.sigmoid(lg_own[..., 0] * obj_s), torch.sigmoid(lg_own[..., 1] * al_s + al_b)], -1).view(N, NO)
+    for got, want, name in ((H1c, h1, "h1"), (H2c, h2_own, "h2")):
+        d = (got - want).abs()
+        assert (d <= 0.0079 * want.abs() + 1e-6).all().item(), (name, float(d.max()))
+        assert (d > 0).float().mean().item() < 0.02, name                            # ... and only where a rounding boundary was crossed
+    ds = (S[:N].float().cpu() - ref_own).abs()
+    assert ds.max().item() < 1.5e-3, float(ds.max())                                 # fp16 store of a value in (0, 1) + fp32 summation order
+    assert ds.mean().item() < 2e-4                                                   # fp16 rounding of values in (0.5, 1): 2^-12 on average
+    # end to end against the all-torch chain: the same up to the propagated rounding flips
+    assert (H2c - h2).abs().mean().item() < 2e-4 and (S[:N].float().cpu() - ref).abs().max().item() < 6e-3
