@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"].split("(")[0].replace("void ", "")
             data[n + " grid=" + r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("nt16", "tn16", "chain", "render", "pw_stack", "conv0", "count_kl")
+keep = ("nt16", "tn16", "chain", "render", "pw_stack", "conv0", "count_kl", "k_dec", "k_conv")
 print("%-58s %9s %9s %9s %9s %9s %9s %9s" % ("kernel", "mfma_util", "lds_busy", "bank_conf", "wait_any", "wait_inst", "issue", "valu"))
 for k in sorted(data):
     if not any(t in k for t in keep):
