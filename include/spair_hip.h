@@ -52,7 +52,8 @@ typedef struct SpairStep {
     int flags;                 /* bit 0: disable the fused persistent per-cell kernels (A/B testing); bit 1: record stage stamps;
                                 * bit 2: no helper stream (every kernel on the caller's stream);
                                 * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient);
-                                * bit 4: decoder forward as three GEMM launches instead of the fused activation-stationary kernel */
+                                * bit 4: decoder forward as three GEMM launches instead of the fused activation-stationary kernel;
+                                * bit 5: strided backbone convs through the implicit-GEMM kernel instead of the patch-resident one */
     int draw_noise;            /* spair_forward only: 1 = fill eps_box/eps_attr/eps_depth/u_pres from noise_seed first (what spair_noise_fill
                                 * does, but on the helper stream beside the backbone); the buffers must be writable */
     unsigned long long noise_seed;
@@ -189,6 +190,11 @@ int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const fl
  * cores with split-bf16 operands (three products, fp32 accumulation): agrees with the fp32 result to < 2^-15 relative before the store. */
 int spair_stem_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int I, int pad_pre, int Hin, int Hout,
                         int Cout, int stride, int out_bf16, void* stream);
+/* Patch-resident forward of the backbone's 128 -> 128 channel, 4x4, stride-2 convolutions + bias + ReLU (reference modules.py:59-64), bf16 NHWC in / out
+ * (csrc/conv_s2.hip).  in16 [B][Hin][Hin][128] with Hin = 2 * Hout + 2 (the input is pre-padded); wf16 [128][2048] bf16 in tap-parity K order:
+ * column ((class * 2 + half) * 4 + tap) * 64 + c holds W[o][ci = half * 64 + c][ky = py + 2 dy][kx = px + 2 dx], class = 2 py + px, tap = 2 dy + dx;
+ * out16 [B * Hout * Hout][128].  Returns SPAIR_ERR_UNSUPPORTED when a 256-row tile's input patch exceeds the kernel's LDS buffer. */
+int spair_conv_s2k4_fwd16(const void* in16, const void* wf16, const float* bias, void* out16, int B, int Hin, int Hout, void* stream);
 /* The bf16 step's object-decoder FORWARD (reference models.py:474-492: Linear 50->128, ReLU, Linear 128->256, ReLU, Linear 256->P*P*2, the sprite
  * scales and analytic sigmoid) as one activation-stationary kernel (csrc/dec_fused.hip).  z_attr16: bf16 [N][ld_za] (columns >= A ignored);
  * W*, b*: the fp32 parameters, row-major [out][in]; H1 / H2: bf16 [N][128] / [N][256] hidden activations (stored for the backward);

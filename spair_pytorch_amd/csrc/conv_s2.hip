@@ -1,0 +1,224 @@
+// Patch-resident forward of the backbone's strided convolutions in the bf16 step (reference: modules.py:59-64 -- Conv2d(128, 128, 4, stride 2)
+// + ReLU): conv_1 and conv_2 at 128 -> 128 channels, 4x4 kernel, stride 2, NHWC bf16 in / out.
+//
+// Why another conv kernel.  As an implicit GEMM (gemm16.hip) conv_1 moves, per 128-row tile and K step, 16 KB of gathered input and 16 KB of
+// weights from L2 into LDS: 2.4 GB per launch, and the launch takes exactly what 2.4 GB take at the ~11.5 TB/s the chip's L2 -> LDS paths
+// deliver to this access pattern (0.21 ms) -- the kernel is bound by operand bytes, not by the matrix cores.  Two changes cut the bytes 2.3x:
+//   * PATCH-RESIDENT input.  The 16 taps of a 4x4 / stride-2 kernel fall into 4 parity classes (ky % 2, kx % 2); the 4 taps of a class read
+//     the same input SUB-LATTICE S[yy][xx] = in[2 yy + py][2 xx + px] at (y + dy, x + dx), dy, dx in {0, 1}.  A workgroup stages, per (class,
+//     64-channel half), the sub-lattice patch its 256 output pixels touch ONCE (<= 11 rows x 35 pixels x 128 B at conv_1) and reads the A
+//     fragments of all 4 taps out of it: 45 KB per 4 K steps instead of 4 x 32 KB.
+//   * 256-row tiles on 8 waves (4 x 2, 64 x 64 per wave): the weight tile of a K step is shared by twice the rows.
+// K runs in the tap-parity order the prepared weights already have (gemm.h, GemmNT::ktab: class, half, tap).
+// Pipeline: weight tiles through a ring of 3 x 16 KB, three K steps ahead; the next stage's patch into the other of two patch buffers; everything
+// by LDS-DMA (buffer_load ... lds, XOR swizzle applied on the source side) behind counted s_waitcnt vmcnt; the two wave groups of a workgroup
+// alternate between a fragment-load phase and an MFMA phase (ping-pong, see the kernel).
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int CP_BM = 256, CP_C = 128;           // rows per workgroup, channels (in = out)
+constexpr int CP_PPX = 392;                      // patch capacity in pixels (49 DMA pieces of 8 pixels x 128 B)
+constexpr int CP_PATCH_B = CP_PPX * 128;         // 50,176 B per patch buffer
+constexpr int CP_BT_B = 128 * 128;               // weight tile [128 n][64 k] bf16
+constexpr int CP_NPIECE_W = 5;                   // patch pieces per GB wave per C phase (3 phases x 4 waves x 5 >= 49)
+constexpr int CP_LDS = 3 * CP_BT_B + 2 * CP_PATCH_B + 1024;      // + 1 KiB that the surplus (out-of-range) patch pieces are pointed at
+constexpr int CP_LDC = CP_C + 8;                 // epilogue staging row (bf16 elements)
+
+struct ConvPatchArgs {
+    const u16* in; const u16* wf; const float* bias; u16* out;
+    int B, Hin, Hout, M, K;                      // M = B * Hout * Hout, K = 16 * 128
+};
+
+template <int W>
+__device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory"); }
+
+__global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char cp_sm[];
+    char* bt = cp_sm;                            // [3][128][64] bf16, chunk ^ (row & 7)
+    char* patch = cp_sm + 3 * CP_BT_B;           // [2][CP_PPX][64] bf16, chunk ^ (pixel & 7)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Hout = a.Hout, Ws = Hout + 1, Hs = Hout + 1;
+    const int m0 = blockIdx.x * CP_BM;
+    const int mlast = min(m0 + CP_BM, a.M) - 1;
+    // extended sub-lattice row of output row g = (b, y): E = g + b (every image owns Hout + 1 sub-lattice rows); the tile needs E0 .. E1
+    const int g0 = m0 / Hout, g1 = mlast / Hout;
+    const int E0 = g0 + g0 / Hout, E1 = g1 + g1 / Hout + 1;
+    const int npx = (E1 - E0 + 1) * Ws;          // <= CP_PPX (checked by the launcher)
+
+    // ---- per-lane geometry of the A fragments: patch pixel of (row tile i, row r16) at tap (0, 0)
+    int pbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
+        const int g = m / Hout, x = m - g * Hout;
+        pbase[i] = (g + g / Hout - E0) * Ws + x;
+    }
+    const int bn_row = wn * 64 + r16;            // + j * 16: weight-tile row of column tile j
+
+    // ---- PING-PONG schedule.  The 8 waves form two groups, GA = waves 0..3 and GB = waves 4..7 (one of each per SIMD).  Every K step has a
+    // LOAD phase L (the 16 fragment reads of the step, into registers) and a COMPUTE phase C (its 32 MFMAs), separated by workgroup barriers;
+    // GB runs one barrier behind GA, so while one group computes the other loads and the matrix pipe of a SIMD always has one wave in a C phase:
+    //     GA:  L0 | C0 | L1 | C1 | L2 ...          (| = s_barrier; GB executes one extra barrier up front)
+    //     GB:     | L0 | C0 | L1 | C1 ...
+    // All DMA is issued by the GB waves inside their C phases, where the issue cost hides behind the MFMAs: the weight tile of step kt + 3 into
+    // ring slot kt % 3 (both groups hold step kt's fragments in registers by then) and one third of the NEXT stage's patch (nothing in the last
+    // C phase before a stage boundary, so that the counted wait in front of it retires every patch piece).
+    const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.in), rwf = buf_rsrc(a.wf);
+    const bool gb = wave >= 4;
+    const int lw = wave & 3;                     // DMA lane group inside GB
+    auto glds = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, char* dst) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)byte_off, 0, 0, 0);
+    };
+    auto issue_b = [&](int kt) {                 // GB: weight tile of K step kt -> ring slot kt % 3; four 1-KiB pieces (8 rows each) per wave
+        const bool live = kt < (a.K >> 6);
+        char* dst = bt + (kt % 3) * CP_BT_B;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = lw * 4 + p, n = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (n & 7);
+            glds(rwf, live ? ((unsigned)n * (unsigned)a.K + (unsigned)kt * 64u + (unsigned)c * 8u) * 2u : BUF_OOB, dst + piece * 1024);
+        }
+    };
+    auto issue_patch = [&](int st, int part) {   // GB: pieces (part * 4 + lw) * 5 .. + 4 of stage st's sub-lattice patch -> patch buffer st & 1
+        const int cls = st >> 1, half = st & 1, py = cls >> 1, px = cls & 1;
+        char* dst = patch + (st & 1) * CP_PATCH_B;
+#pragma unroll
+        for (int e = 0; e < CP_NPIECE_W; ++e) {
+            const int piece = (part * 4 + lw) * CP_NPIECE_W + e;       // 0 .. 59, the patch has <= 49
+            const int pp = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (pp & 7);
+            const int er = pp / Ws, xx = pp - er * Ws, E = E0 + er;
+            const int b = E / Hs, yy = E - b * Hs;
+            const bool ok = st < 8 && pp < npx && b < a.B;
+            const unsigned off = (((unsigned)(b * a.Hin + 2 * yy + py) * (unsigned)a.Hin + (unsigned)(2 * xx + px)) * CP_C + half * 64 + c * 8) * 2u;
+            // surplus pieces are issued too (same instruction count in every wave and phase), always out of range, into a dump KiB
+            glds(rin, ok ? off : BUF_OOB, piece < CP_PPX / 8 ? dst + piece * 1024 : cp_sm + 3 * CP_BT_B + 2 * CP_PATCH_B);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (gb) {                                    // prologue: stage 0's patch, the first third of stage 1's, three weight tiles
+#pragma unroll
+        for (int part = 0; part < 3; ++part) issue_patch(0, part);
+        issue_patch(1, 0);
+        issue_b(0); issue_b(1); issue_b(2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (gb) __builtin_amdgcn_s_barrier();         // GB runs one barrier behind GA from here on
+    asm volatile("" ::: "memory");
+    for (int st = 0; st < 8; ++st) {
+        const char* pb = patch + (st & 1) * CP_PATCH_B;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            const int kt = st * 4 + j4;
+            // ---- L(kt): the step's fragments -> registers
+            const char* bs = bt + (kt % 3) * CP_BT_B;
+            const int tap = (j4 >> 1) * Ws + (j4 & 1);
+            bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ks * 4 + q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pp = pbase[i] + tap;
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = bn_row + j * 16;
+                    bfr[ks][j] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ (n & 7)) << 4));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are done before the barrier: the slot / patch may be refilled behind it
+            // GB: weight tile kt + 1 (issued in C(kt - 2), behind that phase's patch pieces) has landed; younger than it: C(kt - 1)'s
+            // pieces = 4 + (5 unless kt - 1 is the last step before a stage boundary... of the NEXT stage's patch, i.e. (kt % 4) == 3)
+            if (gb) { if (j4 == 3) cp_wait<4>(); else cp_wait<4 + CP_NPIECE_W>(); }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- C(kt)
+            if (gb) {
+                if (j4 != 2) issue_patch(st + 1 + (j4 == 3), j4 == 3 ? 0 : j4 + 1);        // (kt + 1) % 4 = part, 3 = none; stage (kt + 1) / 4 + 1
+                issue_b(kt + 3);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (!gb) __builtin_amdgcn_s_barrier();        // GA catches up with GB's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the dummy tail DMAs target this workgroup's LDS
+    __syncthreads();
+
+    // ---- epilogue: bias + relu -> bf16 rows staged in LDS (over the patch buffers), then whole 256-byte output rows, 16 bytes per lane
+    __bf16* cs = reinterpret_cast<__bf16*>(patch);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + r16;
+        const float bv = a.bias[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(wm * 64 + i * 16 + q * 4 + r) * CP_LDC + n] = (__bf16)fmaxf(acc[i][j][r] + bv, 0.f);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rout = buf_rsrc(a.out);
+#pragma unroll
+    for (int it = 0; it < CP_BM / 32; ++it) {
+        const int row = it * 32 + (tid >> 4), ch = (tid & 15) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
+        buf_store16(rout, (m0 + row) < a.M ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
+    }
+}
+
+}  // namespace
+
+// in: bf16 NHWC [B][Hin][Hin][128]; wf: bf16 [128][2048] in tap-parity K order (engine.hip fill_ktab / k_prep mode 2 with T, s set);
+// out: bf16 [B*Hout*Hout][128] = relu(conv + bias).  SPAIR_ERR_UNSUPPORTED: the caller keeps the implicit-GEMM kernel.
+int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
+                          hipStream_t s) {
+    if (cin != CP_C || cout != CP_C || k != 4 || s_ != 2 || Hin != 2 * Hout + 2 || B <= 0 || Hout <= 0) return SPAIR_ERR_UNSUPPORTED;
+    const long long M = (long long)B * Hout * Hout;
+    if (M * CP_C >= (1ll << 31) || (long long)B * Hin * Hin * CP_C >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+    // the largest patch of any tile must fit the buffer (tiles start at multiples of 256 rows; the pattern repeats with lcm(256, Hout * Hout))
+    const int tiles = (int)((M + CP_BM - 1) / CP_BM);
+    int worst = 0;
+    for (int t = 0; t < tiles && t < 4096; ++t) {
+        const long long m0 = (long long)t * CP_BM, ml = std::min<long long>(m0 + CP_BM, M) - 1;
+        const int g0 = (int)(m0 / Hout), g1 = (int)(ml / Hout);
+        worst = std::max(worst, ((g1 + g1 / Hout + 1) - (g0 + g0 / Hout) + 1) * (Hout + 1));
+    }
+    if (worst > CP_PPX) return SPAIR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_s2k4_patch), hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS) != hipSuccess)
+            return SPAIR_ERR_LAUNCH;
+        attr_set = true;
+    }
+    ConvPatchArgs a;
+    a.in = reinterpret_cast<const u16*>(in); a.wf = reinterpret_cast<const u16*>(wf); a.bias = bias; a.out = reinterpret_cast<u16*>(out);
+    a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C;
+    hipLaunchKernelGGL(k_conv_s2k4_patch, dim3(tiles), dim3(512), CP_LDS, s, a);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+// unit-level C ABI: in16 NHWC bf16 [B][Hin][Hin][128], wf16 bf16 [128][2048] with K = ((class * 2 + half) * 4 + tap) * 64 + c for
+// (ky, kx, ci) = (py + 2 dy, px + 2 dx, half * 64 + c), class = py * 2 + px, tap = dy * 2 + dx; out16 bf16 [B*Hout*Hout][128]
+extern "C" int spair_conv_s2k4_fwd16(const void* in16, const void* wf16, const float* bias, void* out16, int B, int Hin, int Hout, void* stream) {
+    return conv_s2k4_patch_fwd16(in16, wf16, bias, out16, B, Hin, Hout, 128, 128, 4, 2, (hipStream_t)stream);
+}

@@ -74,3 +74,7 @@ int spair_pw_stack_fwd16(const void* X, const void* const* W, const int* ldw, co
 int spair_pw_stack_bwd16(const void* dY, int ldd, int kd, const void* const* Wd, const int* ldw, const int* cout, const void* const* gate,
                          void* const* dX, int M, int L, hipStream_t s);
 int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows, int cols, hipStream_t s);
+// conv_s2.hip: patch-resident forward of a 128 -> 128 channel 4x4 / stride-2 convolution (+ bias + relu), bf16 NHWC in / out, weights in
+// tap-parity K order; SPAIR_ERR_UNSUPPORTED when the geometry does not fit (the caller keeps the implicit-GEMM kernel)
+int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
+                          hipStream_t s);

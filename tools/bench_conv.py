@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""conv_1 / conv_2 forward of BASELINE config 2 (128 -> 128 channels, 4x4, stride 2, bf16 NHWC): the patch-resident kernel (conv_s2.hip)
+against the implicit-GEMM kernel (gemm16.hip) through their C-ABI entry points (GPU box only; developer tool)."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spair_pytorch_amd import _lib as L
+lib = L.lib()
+bf = torch.bfloat16
+
+
+def timeit(fn, n=20):
+    fn(); fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for name, B, Hout in (("conv_1", 256, 34), ("conv_2", 256, 16)):
+    Hin, C = 2 * Hout + 2, 128
+    x = torch.randn(B, Hin, Hin, C, device="cuda").to(bf)
+    wf = (torch.randn(C, 2048, device="cuda") / 45).to(bf)
+    bias = torch.zeros(C, device="cuda")
+    M = B * Hout * Hout
+    out = torch.empty(M, C, device="cuda", dtype=bf)
+    t_new = timeit(lambda: L.check(lib.spair_conv_s2k4_fwd16(L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(out), B, Hin, Hout, L.stream()), name))
+    conv13 = (ctypes.c_int * 13)(Hin, Hin, C, Hout, Hout, 4, 4, 2, 2, 1, 1, 0, 0)
+    out2 = torch.empty(M, C, device="cuda", dtype=bf)
+    t_old = timeit(lambda: L.check(lib.spair_gemm_nt16(L.ptr(x), 0, L.ptr(wf), 2048, L.ptr(out2), C, M, C, 2048, L.ptr(bias), None, 0, 1, 1, 1, conv13, None,
+                                                       L.stream()), name))
+    fl = 2.0 * M * C * 2048
+    print("%s: patch-resident %.3f ms (%.0f TFLOP/s) | implicit GEMM (natural K order) %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
