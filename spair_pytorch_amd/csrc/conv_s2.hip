@@ -8,7 +8,7 @@
 //     the same input SUB-LATTICE S[yy][xx] = in[2 yy + py][2 xx + px] at (y + dy, x + dx), dy, dx in {0, 1}.  A workgroup stages, per (class,
 //     64-channel half), the sub-lattice patch its 256 output pixels touch ONCE (<= 11 rows x 35 pixels x 128 B at conv_1) and reads the A
 //     fragments of all 4 taps out of it: 45 KB per 4 K steps instead of 4 x 32 KB.
-//   * 256-row tiles on 8 waves (4 x 2, 64 x 64 per wave): the weight tile of a K step is shared by twice the rows.
+//   * 256-row tiles (8 computing waves, 4 x 2, 64 x 64 each, + 4 loader waves): the weight tile of a K step is shared by twice the rows.
 // K runs in the tap-parity order the prepared weights already have (gemm.h, GemmNT::ktab: class, half, tap).
 // Pipeline: weight tiles through a ring of 3 x 16 KB, three K steps ahead; the next stage's patch into the other of two patch buffers; everything
 // by LDS-DMA (buffer_load ... lds, XOR swizzle applied on the source side) behind counted s_waitcnt vmcnt; the two wave groups of a workgroup
@@ -31,16 +31,22 @@ struct ConvPatchArgs {
     int B, Hin, Hout, M, K;                      // M = B * Hout * Hout, K = 16 * 128
 };
 
+#ifdef CP_STAMP
+__device__ unsigned long long g_cp_st[2 * 8 * 128];
+extern "C" int spair_cp_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_st), sizeof(g_cp_st)) == hipSuccess ? 0 : -3; }
+#define CP_T(i) do { if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 600)) g_cp_st[((blockIdx.x != 3) * 8 + wave) * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CP_T(i)
+#endif
 template <int W>
 __device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory"); }
 
-__global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
+__global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char cp_sm[];
     char* bt = cp_sm;                            // [3][128][64] bf16, chunk ^ (row & 7)
     char* patch = cp_sm + 3 * CP_BT_B;           // [2][CP_PPX][64] bf16, chunk ^ (pixel & 7)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r16 = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
     const int Hout = a.Hout, Ws = Hout + 1, Hs = Hout + 1;
     const int m0 = blockIdx.x * CP_BM;
     const int mlast = min(m0 + CP_BM, a.M) - 1;
@@ -49,31 +55,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
     const int E0 = g0 + g0 / Hout, E1 = g1 + g1 / Hout + 1;
     const int npx = (E1 - E0 + 1) * Ws;          // <= CP_PPX (checked by the launcher)
 
-    // ---- per-lane geometry of the A fragments: patch pixel of (row tile i, row r16) at tap (0, 0)
-    int pbase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
-        const int g = m / Hout, x = m - g * Hout;
-        pbase[i] = (g + g / Hout - E0) * Ws + x;
-    }
-    const int bn_row = wn * 64 + r16;            // + j * 16: weight-tile row of column tile j
-
-    // ---- PING-PONG schedule.  The 8 waves form two groups, GA = waves 0..3 and GB = waves 4..7 (one of each per SIMD).  Every K step has a
-    // LOAD phase L (the 16 fragment reads of the step, into registers) and a COMPUTE phase C (its 32 MFMAs), separated by workgroup barriers;
-    // GB runs one barrier behind GA, so while one group computes the other loads and the matrix pipe of a SIMD always has one wave in a C phase:
-    //     GA:  L0 | C0 | L1 | C1 | L2 ...          (| = s_barrier; GB executes one extra barrier up front)
-    //     GB:     | L0 | C0 | L1 | C1 ...
-    // All DMA is issued by the GB waves inside their C phases, where the issue cost hides behind the MFMAs: the weight tile of step kt + 3 into
-    // ring slot kt % 3 (both groups hold step kt's fragments in registers by then) and one third of the NEXT stage's patch (nothing in the last
-    // C phase before a stage boundary, so that the counted wait in front of it retires every patch piece).
+    // ---- roles.  Waves 0..7 are CONSUMERS (4 x 2, a 64 x 64 output tile each; two per SIMD, so that one's LDS round trip at the top of a K step
+    // meets the other's MFMAs), waves 8..11 are LOADERS (one per SIMD): they issue every LDS-DMA of the workgroup and nothing else.  A DMA instruction costs its issuing wave ~100-200 cycles of queue back-pressure (the CU takes in
+    // ~30 B/clk when every CU streams); on a computing wave that time is lost to the matrix pipe (measured: all 8 waves loading + computing
+    // 0.196 ms, a ping-pong schedule with the DMA inside the MFMA phases of half the waves 0.235 ms).  One workgroup barrier per K step:
+    //     consumers:  barrier(kt) | fragments + 32 MFMAs of step kt
+    //     loaders:    barrier(kt) | issue [patch part][weight tile kt + 2] | wait until tile kt + 1 (and everything older) has landed
+    const bool loader = wave >= 8;
+    const int lw = wave & 3;
+    const int wm = (wave >> 1) & 3, wn = wave & 1;
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.in), rwf = buf_rsrc(a.wf);
-    const bool gb = wave >= 4;
-    const int lw = wave & 3;                     // DMA lane group inside GB
     auto glds = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, char* dst) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)byte_off, 0, 0, 0);
     };
-    auto issue_b = [&](int kt) {                 // GB: weight tile of K step kt -> ring slot kt % 3; four 1-KiB pieces (8 rows each) per wave
+    auto issue_b = [&](int kt) {                 // weight tile of K step kt -> ring slot kt % 3; four 1-KiB pieces (8 rows each) per loader wave
         const bool live = kt < (a.K >> 6);
         char* dst = bt + (kt % 3) * CP_BT_B;
 #pragma unroll
@@ -82,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
             glds(rwf, live ? ((unsigned)n * (unsigned)a.K + (unsigned)kt * 64u + (unsigned)c * 8u) * 2u : BUF_OOB, dst + piece * 1024);
         }
     };
-    auto issue_patch = [&](int st, int part) {   // GB: pieces (part * 4 + lw) * 5 .. + 4 of stage st's sub-lattice patch -> patch buffer st & 1
+    auto issue_patch = [&](int st, int part) {   // pieces (part * 4 + lw) * 5 .. + 4 of stage st's sub-lattice patch -> patch buffer st & 1
         const int cls = st >> 1, half = st & 1, py = cls >> 1, px = cls & 1;
         char* dst = patch + (st & 1) * CP_PATCH_B;
 #pragma unroll
@@ -93,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
             const int b = E / Hs, yy = E - b * Hs;
             const bool ok = st < 8 && pp < npx && b < a.B;
             const unsigned off = (((unsigned)(b * a.Hin + 2 * yy + py) * (unsigned)a.Hin + (unsigned)(2 * xx + px)) * CP_C + half * 64 + c * 8) * 2u;
-            // surplus pieces are issued too (same instruction count in every wave and phase), always out of range, into a dump KiB
+            // surplus pieces are issued too (same instruction count in every wave and step), always out of range, into a dump KiB
             glds(rin, ok ? off : BUF_OOB, piece < CP_PPX / 8 ? dst + piece * 1024 : cp_sm + 3 * CP_BT_B + 2 * CP_PATCH_B);
         }
     };
@@ -104,84 +99,104 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_patch(ConvPatchArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (gb) {                                    // prologue: stage 0's patch, the first third of stage 1's, three weight tiles
+    if (loader) {
 #pragma unroll
         for (int part = 0; part < 3; ++part) issue_patch(0, part);
-        issue_patch(1, 0);
-        issue_b(0); issue_b(1); issue_b(2);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (gb) __builtin_amdgcn_s_barrier();         // GB runs one barrier behind GA from here on
-    asm volatile("" ::: "memory");
-    for (int st = 0; st < 8; ++st) {
-        const char* pb = patch + (st & 1) * CP_PATCH_B;
+        issue_b(0);
+        issue_b(1);
+        cp_wait<4>();                              // everything but tile 1
+        for (int st = 0; st < 8; ++st) {
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-            const int kt = st * 4 + j4;
-            // ---- L(kt): the step's fragments -> registers
-            const char* bs = bt + (kt % 3) * CP_BT_B;
-            const int tap = (j4 >> 1) * Ws + (j4 & 1);
-            bf16x8 af[2][4], bfr[2][4];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int c = ks * 4 + q;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pp = pbase[i] + tap;
-                    af[ks][i] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = bn_row + j * 16;
-                    bfr[ks][j] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ (n & 7)) << 4));
-                }
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int kt = st * 4 + j4;
+                CP_T(3 * kt);
+                __builtin_amdgcn_s_barrier();          // barrier(kt): the consumers are done with step kt - 1 (slot (kt + 2) % 3, and at j4 = 0 the other patch buffer)
+                asm volatile("" ::: "memory");
+                CP_T(3 * kt + 1);
+#ifndef CP_EXP_NOPATCH
+                if (j4 != 3) issue_patch(st + 1, j4);
+#else
+                if (j4 != 3) issue_patch(9, j4);       // experiment: only out-of-range pieces (zero fill, no memory traffic)
+#endif
+#ifndef CP_EXP_NOB
+                issue_b(kt + 2);
+#else
+                issue_b(1000);
+#endif
+                CP_T(3 * kt + 2);
+                // tile kt + 1 = the last 4 operations of the previous batch; younger: this batch
+                if (j4 == 3) cp_wait<4>(); else cp_wait<4 + CP_NPIECE_W>();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are done before the barrier: the slot / patch may be refilled behind it
-            // GB: weight tile kt + 1 (issued in C(kt - 2), behind that phase's patch pieces) has landed; younger than it: C(kt - 1)'s
-            // pieces = 4 + (5 unless kt - 1 is the last step before a stage boundary... of the NEXT stage's patch, i.e. (kt % 4) == 3)
-            if (gb) { if (j4 == 3) cp_wait<4>(); else cp_wait<4 + CP_NPIECE_W>(); }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // ---- C(kt)
-            if (gb) {
-                if (j4 != 2) issue_patch(st + 1 + (j4 == 3), j4 == 3 ? 0 : j4 + 1);        // (kt + 1) % 4 = part, 3 = none; stage (kt + 1) / 4 + 1
-                issue_b(kt + 3);
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();              // barrier(32): pairs with the consumers' final one
+    } else {
+        // ---- per-lane geometry of the A fragments: patch pixel of (row tile i, row r16) at tap (0, 0)
+        int pbase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
+            const int g = m / Hout, x = m - g * Hout;
+            pbase[i] = (g + g / Hout - E0) * Ws + x;
+        }
+        for (int st = 0; st < 8; ++st) {
+            const char* pb = patch + (st & 1) * CP_PATCH_B;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int kt = st * 4 + j4;
+                CP_T(3 * kt);
+                __builtin_amdgcn_s_barrier();          // barrier(kt): tile kt (and at j4 = 0 this stage's patch) has landed for every loader
+                asm volatile("" ::: "memory");
+                CP_T(3 * kt + 1);
+                const char* bs = bt + (kt % 3) * CP_BT_B;
+                const int tap = (j4 >> 1) * Ws + (j4 & 1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 af[4], bfr[4];
+                    const int c = ks * 4 + q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pp = pbase[i] + tap;
+                        af[i] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = wn * 64 + j * 16 + r16;
+                        bfr[j] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ (n & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();              // barrier(32)
     }
-    if (!gb) __builtin_amdgcn_s_barrier();        // GA catches up with GB's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the dummy tail DMAs target this workgroup's LDS
     __syncthreads();
 
     // ---- epilogue: bias + relu -> bf16 rows staged in LDS (over the patch buffers), then whole 256-byte output rows, 16 bytes per lane
     __bf16* cs = reinterpret_cast<__bf16*>(patch);
+    if (!loader) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wn * 64 + j * 16 + r16;
-        const float bv = a.bias[n];
+        for (int j = 0; j < 4; ++j) {
+            const int n = wn * 64 + j * 16 + r16;
+            const float bv = a.bias[n];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cs[(wm * 64 + i * 16 + q * 4 + r) * CP_LDC + n] = (__bf16)fmaxf(acc[i][j][r] + bv, 0.f);
+                for (int r = 0; r < 4; ++r) cs[(wm * 64 + i * 16 + q * 4 + r) * CP_LDC + n] = (__bf16)fmaxf(acc[i][j][r] + bv, 0.f);
+        }
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rout = buf_rsrc(a.out);
+    if (tid < 512) {
 #pragma unroll
-    for (int it = 0; it < CP_BM / 32; ++it) {
-        const int row = it * 32 + (tid >> 4), ch = (tid & 15) * 8;
-        const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
-        buf_store16(rout, (m0 + row) < a.M ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
+        for (int it = 0; it < CP_BM / 32; ++it) {
+            const int row = it * 32 + (tid >> 4), ch = (tid & 15) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
+            buf_store16(rout, (m0 + row) < a.M ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
+        }
     }
 }
 
@@ -212,7 +227,7 @@ int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, voi
     ConvPatchArgs a;
     a.in = reinterpret_cast<const u16*>(in); a.wf = reinterpret_cast<const u16*>(wf); a.bias = bias; a.out = reinterpret_cast<u16*>(out);
     a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C;
-    hipLaunchKernelGGL(k_conv_s2k4_patch, dim3(tiles), dim3(512), CP_LDS, s, a);
+    hipLaunchKernelGGL(k_conv_s2k4_patch, dim3(tiles), dim3(768), CP_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
