@@ -195,6 +195,11 @@ int spair_stem_conv_fwd(const float* x, const float* w, const float* bias, void*
  * column ((class * 2 + half) * 4 + tap) * 64 + c holds W[o][ci = half * 64 + c][ky = py + 2 dy][kx = px + 2 dx], class = 2 py + px, tap = 2 dy + dx;
  * out16 [B * Hout * Hout][128].  Returns SPAIR_ERR_UNSUPPORTED when a 256-row tile's input patch exceeds the kernel's LDS buffer. */
 int spair_conv_s2k4_fwd16(const void* in16, const void* wf16, const float* bias, void* out16, int B, int Hin, int Hout, void* stream);
+/* Patch-resident DATA GRADIENT of the same layers (csrc/conv_s2_dgrad.hip): dout16 bf16 NHWC [B][Ho][Ho][128]; wdq: bf16 [128 ci][4 * 128], column
+ * (ty * 2 + tx) * 128 + co = W[co][ci][py + 2 ty][px + 2 tx] for output-parity class q = 2 py + px; gate16: the stored activation of the layer
+ * below, bf16 NHWC [B][2 (Ho + 1)][2 (Ho + 1)][128]; out16 (same shape) = conv2d_backward_input(dout, W) where gate16 > 0, else 0. */
+int spair_conv_s2k4_dgrad16(const void* dout16, const void* wd0, const void* wd1, const void* wd2, const void* wd3, const void* gate16,
+                            void* out16, int B, int Ho, void* stream);
 /* The bf16 step's object-decoder FORWARD (reference models.py:474-492: Linear 50->128, ReLU, Linear 128->256, ReLU, Linear 256->P*P*2, the sprite
  * scales and analytic sigmoid) as one activation-stationary kernel (csrc/dec_fused.hip).  z_attr16: bf16 [N][ld_za] (columns >= A ignored);
  * W*, b*: the fp32 parameters, row-major [out][in]; H1 / H2: bf16 [N][128] / [N][256] hidden activations (stored for the backward);

@@ -1,0 +1,342 @@
+// Patch-resident DATA GRADIENT of the backbone's strided convolutions in the bf16 step (the backward of modules.py:59-64's Conv2d(128, 128, 4,
+// stride 2) + the ReLU gate of the layer below), optionally with the stem's weight gradient taken from the gated tile (conv_1: d act0 is never
+// written to HBM, as in gemm16.hip's STEM path).
+//
+// The data gradient of a 4x4 / stride-2 convolution splits into 4 output-parity classes (py, px): the pixels (2y + py, 2x + px) of the layer's
+// input receive  sum over the 2x2 taps (ty, tx) and co of  d_out[y - ty][x - tx][co] . W[co][ci][py + 2 ty][px + 2 tx]  -- a 2x2, stride-1
+// convolution of d_out per class.  All 4 classes x 4 taps read the SAME d_out neighbourhood, so a workgroup stages the zero-bordered d_out
+// patch of its 128 class pixels ONCE (both 64-channel halves, <= 7 rows x 36 pixels x 256 B at conv_1) and runs the 16 (class, tap) products
+// -- 32 K steps of 64 -- out of it: the gathered operand costs 64 KB per tile instead of 4 x 128 KB through the implicit-GEMM kernel, which was
+// bound by exactly those bytes (conv_1's data gradient: 0.31 ms for 155 GFLOP).  Only the 16 KB weight tile of each K step streams (ring of 3).
+// Wave roles as in conv_s2.hip: 4 computing waves (2 x 2, 64 x 64 each) + 4 loader waves that issue every LDS-DMA behind counted waits.
+// Per class an epilogue on the computing waves: accumulators -> bf16 tile in LDS -> whole 256-byte rows: ReLU gate (the stored activation of the
+// layer below > 0), then either the row-mapped store of d act or (STEM) the gated tile x the 4x4 input patches on the matrix cores, summed
+// over the tile's 4 classes and left as ONE [128][17] partial per workgroup.
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int DG_BM = 128, DG_C = 128;
+constexpr int DG_PPX = 256;                      // patch capacity in pixels per 64-channel half (32 DMA pieces of 8 pixels x 128 B)
+constexpr int DG_PATCH_B = DG_PPX * 128;         // 32 KB
+constexpr int DG_BT_B = 128 * 128;               // weight tile [128 ci][64 k] bf16
+constexpr int DG_LDG = DG_C + 8, DG_LDP = 32 + 8;
+constexpr int DG_OFF_PATCH = 3 * DG_BT_B;
+constexpr int DG_OFF_G = DG_OFF_PATCH + 2 * DG_PATCH_B;            // gated / staged tile [128][136] bf16
+constexpr int DG_OFF_P = DG_OFF_G + DG_BM * DG_LDG * 2;            // stem patches [128][40] bf16
+constexpr int DG_OFF_DUMP = DG_OFF_P + DG_BM * DG_LDP * 2;
+constexpr int DG_LDS = DG_OFF_DUMP + 1024;                         // 160,768 B
+constexpr int DG_STEM_FLOATS = 128 * 17;
+
+struct ConvDgradArgs {
+    const u16* dout; const u16* Bz[4]; const u16* gate; u16* out;
+    int B, Ho, Hc, Hi, M;                        // d_out side, class-grid side Ho + 1, input side 2 Hc, M = B * Hc * Hc
+    // STEM (conv_1): xp = zero-padded fp32 stem input [B][stem_hin][stem_hin], stride stem_s; one [128][17] partial per workgroup
+    const float* stem_xp; float* stem_part; int stem_hin, stem_s;
+};
+
+template <int W>
+__device__ __forceinline__ void dg_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory"); }
+
+typedef short dg_v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 dg_tr_frag16(const __bf16* tile, int ld, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const __bf16* a0 = tile + (8 * g + q) * ld + c0 + 4 * p;
+    const __bf16* a1 = a0 + 4 * ld;
+    const dg_v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dg_v4s16*)(a0));
+    const dg_v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dg_v4s16*)(a1));
+    union { struct { dg_v4s16 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+template <bool STEM>
+__global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dg_sm[];
+    char* bt = dg_sm;                            // [3][128 ci][64 k] bf16, chunk ^ (row & 7)
+    char* patch = dg_sm + DG_OFF_PATCH;          // [2 halves][DG_PPX][64 ch] bf16, chunk ^ (pixel & 7)
+    __bf16* Gs = reinterpret_cast<__bf16*>(dg_sm + DG_OFF_G);
+    __bf16* Ps = reinterpret_cast<__bf16*>(dg_sm + DG_OFF_P);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const int Ho = a.Ho, Hc = a.Hc, Wp = Ho + 2, Hp = Ho + 2;
+    const int m0 = blockIdx.x * DG_BM, mlast = min(m0 + DG_BM, a.M) - 1;
+    // class pixel m = (b, y, x) on the Hc x Hc class grid; g = b * Hc + y.  d_out rows with a zero border: extended row E = b * Hp + yd + 1;
+    // tap ty of class row g reads E = g + b + 1 - ty.  The tile needs E0 .. E1, every row Wp = Ho + 2 pixels (xd + 1 = x + 1 - tx).
+    const int g0 = m0 / Hc, g1 = mlast / Hc;
+    const int E0 = g0 + g0 / Hc, E1 = g1 + g1 / Hc + 1;
+    const int npx = (E1 - E0 + 1) * Wp;          // <= DG_PPX (checked by the launcher)
+    const bool loader = wave >= 4;
+    const int lw = wave & 3;
+
+    if (loader) {
+        const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.dout);
+        auto glds = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, char* dst) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)byte_off, 0, 0, 0);
+        };
+        auto issue_b = [&](int kt) {             // K step kt = (class, half, tap): weight tile -> ring slot kt % 3; 4 pieces (8 rows each) per loader
+            const int cls = (kt >> 3) & 3, half = (kt >> 2) & 1, tap = kt & 3;
+            const bool live = kt < 32;
+            const __amdgpu_buffer_rsrc_t rw = buf_rsrc(a.Bz[cls]);
+            char* dst = bt + (kt % 3) * DG_BT_B;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int piece = lw * 4 + p, n = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (n & 7);
+                glds(rw, live ? ((unsigned)n * 512u + (unsigned)(tap * 128 + half * 64 + c * 8)) * 2u : BUF_OOB, dst + piece * 1024);
+            }
+        };
+        auto issue_patch = [&](int half, int part, int npieces) {      // pieces (part * 4 + lw) * npieces .. of the d_out patch's channel half
+            char* dst = patch + half * DG_PATCH_B;
+            for (int e = 0; e < npieces; ++e) {
+                const int piece = (part * 4 + lw) * npieces + e;
+                const int pp = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (pp & 7);
+                const int er = pp / Wp, xp = pp - er * Wp, E = E0 + er;
+                const int b = E / Hp, yd = E - b * Hp - 1, xd = xp - 1;
+                const bool ok = pp < npx && b < a.B && yd >= 0 && yd < Ho && xd >= 0 && xd < Ho;
+                const unsigned off = (((unsigned)(b * Ho + yd) * (unsigned)Ho + (unsigned)xd) * DG_C + half * 64 + c * 8) * 2u;
+                glds(rin, ok ? off : BUF_OOB, piece < DG_PPX / 8 ? dst + piece * 1024 : dg_sm + DG_OFF_DUMP);
+            }
+        };
+        issue_patch(0, 0, 8);                    // half 0: 32 pieces = 4 loaders x 8
+        issue_b(0);
+        issue_b(1);
+        dg_wait<4>();                            // everything but tile 1
+#pragma unroll 1
+        for (int kt = 0; kt < 32; ++kt) {
+            __builtin_amdgcn_s_barrier();        // barrier(kt): the computing waves are done with step kt - 1 (ring slot (kt + 2) % 3)
+            asm volatile("" ::: "memory");
+            if (kt < 2) {                        // half 1 (first read at step 4): 2 x 4 pieces per loader, in front of the weight tile
+                issue_patch(1, kt, 4);
+                issue_b(kt + 2);
+                dg_wait<8>();                    // tile kt + 1 = the last 4 operations of the previous batch; younger: this batch (4 + 4)
+            } else {
+                issue_b(kt + 2);
+                dg_wait<4>();
+            }
+            if ((kt & 7) == 7) {                 // the class epilogue's barriers (see below): E1, and E2 with the stem product
+                __builtin_amdgcn_s_barrier();
+                if (STEM) __builtin_amdgcn_s_barrier();
+            }
+        }
+        __builtin_amdgcn_s_barrier();            // barrier(32)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target this workgroup's LDS
+        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+        return;
+    }
+
+    // ---------------------------------------------------------------- computing waves (tid 0 .. 255)
+    const int wm = wave >> 1, wn = wave & 1;
+    int pbase[4];                                // patch pixel of (row tile i, row r16) at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
+        const int g = m / Hc, x = m - g * Hc;
+        pbase[i] = (g + g / Hc + 1 - E0) * Wp + x + 1;
+    }
+    // epilogue geometry of this thread: rows (tid >> 4) + 16 it, 8 channels at (tid & 15) * 8; output pixel of class (0, 0)
+    const int c8 = (tid & 15) * 8;
+    unsigned orow[8];
+    bool ook[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int m = m0 + (tid >> 4) + it * 16;
+        ook[it] = m < a.M;
+        const int mc = min(m, a.M - 1);
+        const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
+        orow[it] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
+    }
+    const __amdgpu_buffer_rsrc_t rgate = buf_rsrc(a.gate), rout = buf_rsrc(a.out);
+    f32x4 sacc[2][2];                            // STEM: this wave's 32 channels x (16 taps | bias | 0 ...), over the tile's 4 classes
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // gate rows of this class (and the stem patches) are requested at the top of the class: their latency hides behind its 8 K steps
+        uint4 gate[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            gate[it] = buf_load16(rgate, ook[it] ? ((orow[it] + (unsigned)(py * a.Hi + px)) * DG_C + c8) * 2u : BUF_OOB);
+        float2 sp[4];
+        bool sp_ok = false;
+        if (STEM) {
+            const int prow = tid >> 1, hf = tid & 1;
+            const int m = m0 + prow;
+            sp_ok = m < a.M;
+            const int mc = min(m, a.M - 1);
+            const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
+            const int yy = 2 * y + py, xx = 2 * x + px;
+            const float* src = a.stem_xp + ((size_t)b * a.stem_hin + yy * a.stem_s + 2 * hf) * a.stem_hin + xx * a.stem_s;
+            sp[0] = *reinterpret_cast<const float2*>(src);
+            sp[1] = *reinterpret_cast<const float2*>(src + 2);
+            sp[2] = *reinterpret_cast<const float2*>(src + a.stem_hin);
+            sp[3] = *reinterpret_cast<const float2*>(src + a.stem_hin + 2);
+        }
+#pragma unroll
+        for (int h4 = 0; h4 < 8; ++h4) {
+            const int half = h4 >> 2, tap = h4 & 3, kt = cls * 8 + h4;
+            __builtin_amdgcn_s_barrier();        // barrier(kt): tile kt (and, from step 4 on, the second patch half) has landed
+            asm volatile("" ::: "memory");
+            const char* bs = bt + (kt % 3) * DG_BT_B;
+            const char* pb = patch + half * DG_PATCH_B;
+            const int toff = -((tap >> 1) * Wp + (tap & 1));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[4];
+                const int c = ks * 4 + q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pp = pbase[i] + toff;
+                    af[i] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = wn * 64 + j * 16 + r16;
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ (n & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- class epilogue.  (1) accumulators -> bf16 tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = wn * 64 + j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gs[(wm * 64 + i * 16 + q * 4 + r) * DG_LDG + n] = (__bf16)acc[i][j][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is written
+        __builtin_amdgcn_s_barrier();            // E1
+        asm volatile("" ::: "memory");
+        // (2) whole rows: gate = stored activation of the layer below > 0 (bf16 sign / zero test), 16 bytes per thread and row
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (tid >> 4) + it * 16;
+            const uint4 v = *reinterpret_cast<const uint4*>(Gs + row * DG_LDG + c8);
+            const unsigned vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gate[it].x, gate[it].y, gate[it].z, gate[it].w};
+            unsigned ow[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned glo = gw[e] & 0xffffu, ghi = gw[e] >> 16;
+                const unsigned mlo = ((glo & 0x8000u) == 0 && (glo & 0x7fffu) != 0) ? 0xffffu : 0u;
+                const unsigned mhi = ((ghi & 0x8000u) == 0 && (ghi & 0x7fffu) != 0) ? 0xffff0000u : 0u;
+                ow[e] = vw[e] & (mlo | mhi);
+            }
+            const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if (STEM) *reinterpret_cast<uint4*>(Gs + row * DG_LDG + c8) = ook[it] ? o : make_uint4(0u, 0u, 0u, 0u);       // in place: same thread, same 16 bytes
+            else buf_store16(rout, ook[it] ? ((orow[it] + (unsigned)(py * a.Hi + px)) * DG_C + c8) * 2u : BUF_OOB, o);
+        }
+        if (STEM) {
+            const int prow = tid >> 1, hf = tid & 1;
+            bf16x8 o, one;
+            const float pv[8] = {sp[0].x, sp[0].y, sp[1].x, sp[1].y, sp[2].x, sp[2].y, sp[3].x, sp[3].y};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = (__bf16)(sp_ok ? pv[e] : 0.f); one[e] = (__bf16)0.f; }
+            one[0] = (__bf16)((sp_ok && hf == 0) ? 1.f : 0.f);
+            *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + hf * 8]) = o;
+            *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + 16 + hf * 8]) = one;
+        }
+        // (plain: the next write of the tile is 8 K-step barriers away -- no barrier needed behind these reads)
+        if (STEM) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // E2: the tile is gated in place and the patches are written
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < DG_BM / 32; ++ks) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = dg_tr_frag16(Gs + ks * 32 * DG_LDG, DG_LDG, wave * 32 + i * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[j] = dg_tr_frag16(Ps + ks * 32 * DG_LDP, DG_LDP, j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], sacc[i][j], 0, 0, 0);
+            }
+            // (the next class overwrites the tile / patches only behind its 8 K-step barriers)
+        }
+    }
+    __builtin_amdgcn_s_barrier();                // barrier(32)
+    if (STEM) {
+        float* Ws = reinterpret_cast<float*>(Gs);            // [128 ch][17]
+        const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = wave * 32 + i * 16 + rgrp + r;
+                Ws[ch * 17 + col_l] = sacc[i][0][r];
+                if (col_l == 0) Ws[ch * 17 + 16] = sacc[i][1][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float4* pt = reinterpret_cast<float4*>(a.stem_part + (size_t)blockIdx.x * DG_STEM_FLOATS);
+        for (int qq = tid; qq < DG_STEM_FLOATS / 4; qq += 256) pt[qq] = reinterpret_cast<const float4*>(Ws)[qq];
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+}  // namespace
+
+int spair_stem_fused_reduce(float* part, int nblk, float* dw, float* db, hipStream_t s);      // gemm16.hip
+
+// dout: bf16 NHWC [B][Ho][Ho][128]; wd[q]: bf16 [128 ci][4 taps * 128 co] of output-parity class q = py * 2 + px (k_prep mode 3); gate: the
+// stored activation of the layer below, bf16 NHWC [B][2 (Ho + 1)][2 (Ho + 1)][128]; out: d of that activation (same layout), or -- when
+// stem_part != nullptr -- nothing: the stem's weight / bias gradient is accumulated into stem_dw [128][16] / stem_db [128] instead.
+// SPAIR_ERR_UNSUPPORTED: the caller keeps the implicit-GEMM kernel.
+int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void* gate, void* out, int B, int Ho, int hin, int cin, int cout, int k,
+                            int s_, const float* stem_xp, int stem_hin, int stem_s, float* stem_part, long long stem_part_cap, float* stem_dw,
+                            float* stem_db, hipStream_t s) {
+    const int Hc = Ho + 1;
+    if (cin != DG_C || cout != DG_C || k != 4 || s_ != 2 || hin != 2 * Hc || B <= 0 || Ho <= 0) return SPAIR_ERR_UNSUPPORTED;
+    const long long M = (long long)B * Hc * Hc;
+    if ((long long)B * hin * hin * DG_C >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
+    const int tiles = (int)((M + DG_BM - 1) / DG_BM);
+    int worst = 0;
+    for (int t = 0; t < tiles && t < 8192; ++t) {
+        const long long m0 = (long long)t * DG_BM, ml = std::min<long long>(m0 + DG_BM, M) - 1;
+        const int g0 = (int)(m0 / Hc), g1 = (int)(ml / Hc);
+        worst = std::max(worst, ((g1 + g1 / Hc + 1) - (g0 + g0 / Hc) + 1) * (Ho + 2));
+    }
+    if (worst > DG_PPX) return SPAIR_ERR_UNSUPPORTED;
+    const bool stem = stem_part != nullptr;
+    if (stem && (!stem_xp || !stem_dw || (long long)(tiles + 64) * DG_STEM_FLOATS > stem_part_cap || (stem_hin & 1) || (stem_s & 1))) return SPAIR_ERR_UNSUPPORTED;
+    ConvDgradArgs a;
+    a.dout = reinterpret_cast<const u16*>(dout);
+    for (int q = 0; q < 4; ++q) a.Bz[q] = reinterpret_cast<const u16*>(wd[q]);
+    a.gate = reinterpret_cast<const u16*>(gate); a.out = reinterpret_cast<u16*>(out);
+    a.B = B; a.Ho = Ho; a.Hc = Hc; a.Hi = hin; a.M = (int)M;
+    a.stem_xp = stem_xp; a.stem_part = stem_part; a.stem_hin = stem_hin; a.stem_s = stem_s;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[stem]) {
+        const void* fn = stem ? reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true>) : reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        attr_set[stem] = true;
+    }
+    if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(tiles), dim3(512), DG_LDS, s, a);
+    else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(tiles), dim3(512), DG_LDS, s, a);
+    SPAIR_CHECK_LAUNCH();
+    if (stem) return spair_stem_fused_reduce(stem_part, tiles, stem_dw, stem_db, s);
+    return SPAIR_OK;
+}
+
+// unit-level C ABI (tests): wd4 = 4 device pointers, one per output-parity class
+extern "C" int spair_conv_s2k4_dgrad16(const void* dout16, const void* wd0, const void* wd1, const void* wd2, const void* wd3, const void* gate16,
+                                       void* out16, int B, int Ho, void* stream) {
+    const void* wd[4] = {wd0, wd1, wd2, wd3};
+    return conv_s2k4_patch_dgrad16(dout16, wd, gate16, out16, B, Ho, 2 * (Ho + 1), 128, 128, 4, 2, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                   (hipStream_t)stream);
+}

@@ -722,6 +722,17 @@ static int backbone_bwd16(Ctx& c, float* grads) {
             const int K = cs.k * cs.k * cs.cin;
             TRY(tn16(c, dout, ldd, cs.cout, in, 0, K, true, grads + cs.w, K, M, grads + cs.b, &cd, cs.cin, cs.k * cs.k));
             const int T = cs.k / cs.s;
+            if (cs.k == 4 && cs.s == 2 && cs.cin == 128 && cs.cout == 128 && cs.hin == 2 * (cs.hout + 1) && !(c.st.flags & 32)) {
+                // patch-resident data gradient (conv_s2_dgrad.hip): the d-out neighbourhood of a tile is staged once for all 4 parity classes x 4 taps
+                const ConvSpec& c0 = c.PL.conv[0];
+                const bool want_stem = i == 1 && c0.cin == 1 && c0.k == 4 && c0.cout == 128 && c0.hout == cs.hin && !(c.st.flags & 8);
+                const void* wd4[4] = {c.w.conv_wd[i][0], c.w.conv_wd[i][1], c.w.conv_wd[i][2], c.w.conv_wd[i][3]};
+                const int rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s,
+                                                       want_stem ? c.w.xpad : nullptr, c0.hin, c0.s, want_stem ? c.w.tn_part : nullptr,
+                                                       SPAIR_TN_PART_FLOATS, grads + c0.w, grads + c0.b, c.s);
+                if (rc == SPAIR_OK) { if (want_stem) stem_fused = true; continue; }
+                if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
+            }
             if (cs.hin % cs.s == 0 && cs.s * cs.s <= 4) {
                 // all output-parity classes have the same size: one launch, blockIdx.z = class (4 launches of 1.1 rounds of
                 // resident blocks each ran as 2 rounds: conv2's data-gradient took 0.37 ms for 34 GFLOP)

@@ -78,3 +78,8 @@ int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows
 // tap-parity K order; SPAIR_ERR_UNSUPPORTED when the geometry does not fit (the caller keeps the implicit-GEMM kernel)
 int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
                           hipStream_t s);
+// conv_s2_dgrad.hip: patch-resident data gradient of the same layers (all 4 output-parity classes per workgroup), ReLU gate of the layer below,
+// optionally with the stem's weight gradient fused (stem_part != nullptr: nothing is stored to `out`)
+int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void* gate, void* out, int B, int Ho, int hin, int cin, int cout, int k,
+                            int s_, const float* stem_xp, int stem_hin, int stem_s, float* stem_part, long long stem_part_cap, float* stem_dw,
+                            float* stem_db, hipStream_t s);

@@ -734,6 +734,16 @@ __global__ __launch_bounds__(256) void k_stem_fused_reduce2(const float* __restr
     if (n < 16) dW[ch * 16 + n] += t;
     else if (db) db[ch] += t;
 }
+// part[nblk][128*17] (+ 64 * 128*17 floats of scratch behind it) -> dw [128][16] += , db [128] +=   (two small deterministic passes)
+int spair_stem_fused_reduce(float* part, int nblk, float* dw, float* db, hipStream_t s) {
+    const int S = 64, per = ceil_div(nblk, S);
+    float* part2 = part + (size_t)nblk * STEM_PART_FLOATS;
+    hipLaunchKernelGGL(k_stem_fused_reduce1, dim3(ceil_div(STEM_PART_FLOATS, 256), S), dim3(256), 0, s, part, nblk, per, part2);
+    SPAIR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_stem_fused_reduce2, dim3(ceil_div(STEM_PART_FLOATS, 256)), dim3(256), 0, s, part2, S, dw, db);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
 bool spair_nt16_stem_fusable(const GemmNT& g, long long part_cap) {
     const long long tiles = (long long)ceil_div(g.M, 128) * (g.nz > 1 ? g.nz : 1);
     return g.N == 128 && g.use_cmap && g.c_bf16 && (g.stem_hin % 2) == 0 && (g.stem_s % 2) == 0 &&
@@ -799,13 +809,7 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
         if (!conv || !g.stem_xp || !g.stem_dw || !spair_nt16_stem_fusable(g, g.stem_part_cap)) return SPAIR_ERR_UNSUPPORTED;
         NT16_LAUNCH(true, true, true);
         SPAIR_CHECK_LAUNCH();
-        const int nblk = ceil_div(g.M, 128) * (g.nz > 1 ? g.nz : 1), S = 64, per = ceil_div(nblk, S);
-        float* part2 = g.stem_part + (size_t)nblk * STEM_PART_FLOATS;
-        hipLaunchKernelGGL(k_stem_fused_reduce1, dim3(ceil_div(STEM_PART_FLOATS, 256), S), dim3(256), 0, s, g.stem_part, nblk, per, part2);
-        SPAIR_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_stem_fused_reduce2, dim3(ceil_div(STEM_PART_FLOATS, 256)), dim3(256), 0, s, part2, S, g.stem_dw, g.stem_db);
-        SPAIR_CHECK_LAUNCH();
-        return SPAIR_OK;
+        return spair_stem_fused_reduce(g.stem_part, ceil_div(g.M, 128) * (g.nz > 1 ? g.nz : 1), g.stem_dw, g.stem_db, s);
     }
     if (conv) { if (g.c_bf16) NT16_LAUNCH(true, true, false); else NT16_LAUNCH(true, false, false); }
     else { if (g.c_bf16) NT16_LAUNCH(false, true, false); else NT16_LAUNCH(false, false, false); }

@@ -264,3 +264,36 @@ def test_conv_s2k4_patch_fwd_vs_torch(B, Hout):
     d = (got - ref).abs()
     assert (d <= 0.0079 * ref.abs() + 2e-3).all().item(), float(d.max())       # one bf16 step of the stored value + fp32 summation order
     assert d.mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("B,Ho", [(3, 34), (2, 16), (5, 7), (1, 14)])
+def test_conv_s2k4_patch_dgrad_vs_torch(B, Ho):
+    """conv_s2_dgrad.hip (data gradient of conv_1 / conv_2 in the bf16 step + the ReLU gate of the layer below) against torch autograd on the
+    same bf16-rounded operands: d x = conv2d_backward_input(d out, W) * (x > 0), all four output-parity classes from one staged d-out patch."""
+    L = _L()
+    Hi, C = 2 * (Ho + 1), 128
+    g = torch.Generator().manual_seed(Ho * 7 + B)
+    x = torch.randn(B, C, Hi, Hi, generator=g).to(torch.bfloat16)                      # the stored activation of the layer below (its sign gates)
+    w = (torch.randn(C, C, 4, 4, generator=g) / 45.0).to(torch.bfloat16)             # [co][ci][ky][kx]
+    dout = torch.randn(B, C, Ho, Ho, generator=g).to(torch.bfloat16)
+    ref = torch.nn.grad.conv2d_input((B, C, Hi, Hi), w.float(), dout.float(), stride=2) * (x.float() > 0)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * Hi * Hi, C)
+    wd = []
+    for py in range(2):
+        for px in range(2):
+            m = torch.empty(C, 4 * C, dtype=torch.bfloat16)                          # [ci][(ty * 2 + tx) * 128 + co]
+            for ty in range(2):
+                for tx in range(2):
+                    m[:, (ty * 2 + tx) * C:(ty * 2 + tx + 1) * C] = w[:, :, py + 2 * ty, px + 2 * tx].t()
+            wd.append(m.cuda())
+    dd = dout.permute(0, 2, 3, 1).contiguous().cuda()
+    gate = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((B * Hi * Hi + 1, C), -3.0, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().spair_conv_s2k4_dgrad16(L.ptr(dd), L.ptr(wd[0]), L.ptr(wd[1]), L.ptr(wd[2]), L.ptr(wd[3]), L.ptr(gate), L.ptr(out), B, Ho,
+                                            L.stream()), "conv_s2k4 dgrad")
+    torch.cuda.synchronize()
+    assert (out[-1] == -3.0).all().item()
+    got = out[:-1].float().cpu()
+    d = (got - ref).abs()
+    assert (d <= 0.0079 * ref.abs() + 2e-3).all().item(), float(d.max())
+    assert ((got == 0) == (ref == 0)).float().mean().item() > 0.999                  # the gate
