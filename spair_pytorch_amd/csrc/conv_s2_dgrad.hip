@@ -36,6 +36,17 @@ struct ConvDgradArgs {
     const float* stem_xp; float* stem_part; int stem_hin, stem_s;
 };
 
+#ifdef DG_STAMP
+__device__ unsigned long long g_dg_st[2 * 8 * 256];
+extern "C" int spair_dg_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dg_st), sizeof(g_dg_st)) == hipSuccess ? 0 : -3; }
+#define DG_T(i) do { if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 1200)) g_dg_st[((blockIdx.x != 3) * 8 + wave) * 256 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DG_T(i)
+#endif
+// Swizzle key of weight-tile row n (16-byte chunk c of the row sits at position c ^ key): the computing waves read the rows in the PERMUTED
+// order n(T, m) = 32 (T >> 1) + 8 (m >> 2) + 4 (T & 1) + (m & 3) (so that a lane ends up with 8 consecutive output channels, see the kernel);
+// with the usual key n & 7 the 16 rows of a fragment would only produce 4 distinct keys.  This one gives 8, conflict-free for ds_read_b128.
+__device__ __forceinline__ int dg_wkey(int n) { return (n & 3) | (((n >> 3) & 1) << 2); }
 template <int W>
 __device__ __forceinline__ void dg_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory"); }
 
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             char* dst = bt + (kt % 3) * DG_BT_B;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int piece = lw * 4 + p, n = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (n & 7);
+                const int piece = lw * 4 + p, n = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ dg_wkey(n);
                 glds(rw, live ? ((unsigned)n * 512u + (unsigned)(tap * 128 + half * 64 + c * 8)) * 2u : BUF_OOB, dst + piece * 1024);
             }
         };
@@ -104,8 +115,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         dg_wait<4>();                            // everything but tile 1
 #pragma unroll 1
         for (int kt = 0; kt < 32; ++kt) {
+            DG_T(4 * kt);
             __builtin_amdgcn_s_barrier();        // barrier(kt): the computing waves are done with step kt - 1 (ring slot (kt + 2) % 3)
             asm volatile("" ::: "memory");
+            DG_T(4 * kt + 1);
             if (kt < 2) {                        // half 1 (first read at step 4): 2 x 4 pieces per loader, in front of the weight tile
                 issue_patch(1, kt, 4);
                 issue_b(kt + 2);
@@ -114,10 +127,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                 issue_b(kt + 2);
                 dg_wait<4>();
             }
-            if ((kt & 7) == 7) {                 // the class epilogue's barriers (see below): E1, and E2 with the stem product
-                __builtin_amdgcn_s_barrier();
-                if (STEM) __builtin_amdgcn_s_barrier();
-            }
+            if (STEM && (kt & 7) == 7) __builtin_amdgcn_s_barrier();       // the class epilogue's barrier E (stem product only)
         }
         __builtin_amdgcn_s_barrier();            // barrier(32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target this workgroup's LDS
@@ -126,26 +136,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     }
 
     // ---------------------------------------------------------------- computing waves (tid 0 .. 255)
+    // The products are computed TRANSPOSED, C'[ci][pixel] = sum_k W[ci][k] . patch[pixel][k] (weights = A operand, patch = B operand): a lane of the
+    // accumulator then holds 4 consecutive channels of ONE pixel, and with the weight rows of a tile pair read in the order n(T, m) above 8
+    // consecutive ones -- exactly a 16-byte piece of the pixel's NHWC row.  The ReLU gate and the store (or the write of the gated tile for the
+    // stem product) work on registers: no staging of the accumulators through LDS, no epilogue barrier in the plain kernel (staged through a
+    // bf16 tile with 2-byte LDS writes the epilogue of a class took 4,500 cycles, as long as 4 of its 8 K steps, and stalled the loaders).
     const int wm = wave >> 1, wn = wave & 1;
-    int pbase[4];                                // patch pixel of (row tile i, row r16) at tap (0, 0)
+    int pbase[4];                                // patch pixel of (pixel tile j, pixel r16) at tap (0, 0)
+    unsigned orow[4];                            // its output pixel of class (0, 0)
+    bool ook[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
-        const int g = m / Hc, x = m - g * Hc;
-        pbase[i] = (g + g / Hc + 1 - E0) * Wp + x + 1;
-    }
-    // epilogue geometry of this thread: rows (tid >> 4) + 16 it, 8 channels at (tid & 15) * 8; output pixel of class (0, 0)
-    const int c8 = (tid & 15) * 8;
-    unsigned orow[8];
-    bool ook[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int m = m0 + (tid >> 4) + it * 16;
-        ook[it] = m < a.M;
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + r16;
+        ook[j] = m < a.M;
         const int mc = min(m, a.M - 1);
         const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
-        orow[it] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
+        pbase[j] = (g + b + 1 - E0) * Wp + x + 1;
+        orow[j] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
     }
+    // weight-tile rows of this lane: tile t of the wave's 64 channels, lane row m = r16
+    const int wkey = (r16 & 3) | (((r16 >> 2) & 1) << 2);
+    const int wrow0 = wn * 64 + (r16 >> 2) * 8 + (r16 & 3);          // + 32 (t >> 1) + 4 (t & 1)
+    const int ch0 = wn * 64 + q * 8;                                  // + 32 p: the 8 channels this lane owns after tile pair p
     const __amdgpu_buffer_rsrc_t rgate = buf_rsrc(a.gate), rout = buf_rsrc(a.out);
     f32x4 sacc[2][2];                            // STEM: this wave's 32 channels x (16 taps | bias | 0 ...), over the tile's 4 classes
 #pragma unroll
@@ -155,16 +167,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 
     for (int cls = 0; cls < 4; ++cls) {
         const int py = cls >> 1, px = cls & 1;
-        f32x4 acc[4][4];
+        f32x4 acc[4][4];                         // [channel tile t][pixel tile j]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // gate rows of this class (and the stem patches) are requested at the top of the class: their latency hides behind its 8 K steps
-        uint4 gate[8];
+            for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // gate pieces of this class (and the stem patches) are requested at the top of the class: their latency hides behind its 8 K steps
+        uint4 gate[4][2];
 #pragma unroll
-        for (int it = 0; it < 8; ++it)
-            gate[it] = buf_load16(rgate, ook[it] ? ((orow[it] + (unsigned)(py * a.Hi + px)) * DG_C + c8) * 2u : BUF_OOB);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                gate[j][p] = buf_load16(rgate, ook[j] ? ((orow[j] + (unsigned)(py * a.Hi + px)) * DG_C + ch0 + p * 32) * 2u : BUF_OOB);
         float2 sp[4];
         bool sp_ok = false;
         if (STEM) {
@@ -183,61 +197,57 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
         for (int h4 = 0; h4 < 8; ++h4) {
             const int half = h4 >> 2, tap = h4 & 3, kt = cls * 8 + h4;
+            DG_T(4 * kt);
             __builtin_amdgcn_s_barrier();        // barrier(kt): tile kt (and, from step 4 on, the second patch half) has landed
             asm volatile("" ::: "memory");
+            DG_T(4 * kt + 1);
             const char* bs = bt + (kt % 3) * DG_BT_B;
             const char* pb = patch + half * DG_PATCH_B;
             const int toff = -((tap >> 1) * Wp + (tap & 1));
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[4], bfr[4];
+                bf16x8 wf[4], pf[4];
                 const int c = ks * 4 + q;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pp = pbase[i] + toff;
-                    af[i] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
+                for (int t = 0; t < 4; ++t) {
+                    const int n = wrow0 + (t >> 1) * 32 + (t & 1) * 4;
+                    wf[t] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ wkey) << 4));
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = wn * 64 + j * 16 + r16;
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ (n & 7)) << 4));
+                    const int pp = pbase[j] + toff;
+                    pf[j] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
             }
         }
-        // ---- class epilogue.  (1) accumulators -> bf16 tile
+        // ---- class epilogue on registers: gate = stored activation of the layer below > 0 (bf16 sign / zero test), 8 channels of one pixel per lane
+        DG_T(4 * (cls * 8 + 7) + 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = wn * 64 + j * 16 + r16;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int p = 0; p < 2; ++p) {
+                bf16x8 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Gs[(wm * 64 + i * 16 + q * 4 + r) * DG_LDG + n] = (__bf16)acc[i][j][r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is written
-        __builtin_amdgcn_s_barrier();            // E1
-        asm volatile("" ::: "memory");
-        // (2) whole rows: gate = stored activation of the layer below > 0 (bf16 sign / zero test), 16 bytes per thread and row
+                for (int e = 0; e < 4; ++e) { v[e] = (__bf16)acc[2 * p][j][e]; v[4 + e] = (__bf16)acc[2 * p + 1][j][e]; }
+                uint4 vv;
+                __builtin_memcpy(&vv, &v, 16);
+                const unsigned vw[4] = {vv.x, vv.y, vv.z, vv.w}, gw[4] = {gate[j][p].x, gate[j][p].y, gate[j][p].z, gate[j][p].w};
+                unsigned ow[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = (tid >> 4) + it * 16;
-            const uint4 v = *reinterpret_cast<const uint4*>(Gs + row * DG_LDG + c8);
-            const unsigned vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gate[it].x, gate[it].y, gate[it].z, gate[it].w};
-            unsigned ow[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned glo = gw[e] & 0xffffu, ghi = gw[e] >> 16;
-                const unsigned mlo = ((glo & 0x8000u) == 0 && (glo & 0x7fffu) != 0) ? 0xffffu : 0u;
-                const unsigned mhi = ((ghi & 0x8000u) == 0 && (ghi & 0x7fffu) != 0) ? 0xffff0000u : 0u;
-                ow[e] = vw[e] & (mlo | mhi);
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned glo = gw[e] & 0xffffu, ghi = gw[e] >> 16;
+                    const unsigned mlo = ((glo & 0x8000u) == 0 && (glo & 0x7fffu) != 0) ? 0xffffu : 0u;
+                    const unsigned mhi = ((ghi & 0x8000u) == 0 && (ghi & 0x7fffu) != 0) ? 0xffff0000u : 0u;
+                    ow[e] = vw[e] & (mlo | mhi);
+                }
+                const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (STEM) *reinterpret_cast<uint4*>(Gs + (wm * 64 + j * 16 + r16) * DG_LDG + ch0 + p * 32) = ook[j] ? o : make_uint4(0u, 0u, 0u, 0u);
+                else buf_store16(rout, ook[j] ? ((orow[j] + (unsigned)(py * a.Hi + px)) * DG_C + ch0 + p * 32) * 2u : BUF_OOB, o);
             }
-            const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-            if (STEM) *reinterpret_cast<uint4*>(Gs + row * DG_LDG + c8) = ook[it] ? o : make_uint4(0u, 0u, 0u, 0u);       // in place: same thread, same 16 bytes
-            else buf_store16(rout, ook[it] ? ((orow[it] + (unsigned)(py * a.Hi + px)) * DG_C + c8) * 2u : BUF_OOB, o);
-        }
         if (STEM) {
             const int prow = tid >> 1, hf = tid & 1;
             bf16x8 o, one;
@@ -247,11 +257,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             one[0] = (__bf16)((sp_ok && hf == 0) ? 1.f : 0.f);
             *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + hf * 8]) = o;
             *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + 16 + hf * 8]) = one;
-        }
-        // (plain: the next write of the tile is 8 K-step barriers away -- no barrier needed behind these reads)
-        if (STEM) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();        // E2: the tile is gated in place and the patches are written
+            __builtin_amdgcn_s_barrier();        // E: the gated tile and the patches are written
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < DG_BM / 32; ++ks) {

@@ -33,3 +33,24 @@ for name, B, Hout in (("conv_1", 256, 34), ("conv_2", 256, 16)):
                                                        L.stream()), name))
     fl = 2.0 * M * C * 2048
     print("%s: patch-resident %.3f ms (%.0f TFLOP/s) | implicit GEMM (natural K order) %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
+
+# data gradients of the same layers: patch-resident kernel (plain, no stem fusion) vs the implicit-GEMM kernel (4 parity classes, one launch each here)
+for name, B, Ho in (("conv_1 dgrad", 256, 34), ("conv_2 dgrad", 256, 16)):
+    Hc, C = Ho + 1, 128
+    Hi = 2 * Hc
+    dout = torch.randn(B, Ho, Ho, C, device="cuda").to(bf)
+    gate = torch.randn(B, Hi, Hi, C, device="cuda").to(bf)
+    wd = [(torch.randn(C, 512, device="cuda") / 22).to(bf) for _ in range(4)]
+    out = torch.empty(B * Hi * Hi, C, device="cuda", dtype=bf)
+    t_new = timeit(lambda: L.check(lib.spair_conv_s2k4_dgrad16(L.ptr(dout), L.ptr(wd[0]), L.ptr(wd[1]), L.ptr(wd[2]), L.ptr(wd[3]), L.ptr(gate),
+                                                               L.ptr(out), B, Ho, L.stream()), name))
+    M = B * Hc * Hc
+    conv13 = (ctypes.c_int * 13)(Ho, Ho, C, Hc, Hc, 2, 2, 1, 1, -1, -1, 0, 0)
+    def old():
+        for qq in range(4):
+            cmap = (ctypes.c_int * 8)(Hc, Hc, Hi, Hi, 2, 2, qq // 2, qq % 2)
+            L.check(lib.spair_gemm_nt16(L.ptr(dout), 0, L.ptr(wd[qq]), 512, L.ptr(out), C, M, C, 512, None, L.ptr(gate), C, 1, 0, 1, conv13, cmap,
+                                        L.stream()), name)
+    t_old = timeit(old)
+    fl = 2.0 * M * C * 512 * 4
+    print("%s: patch-resident %.3f ms (%.0f TFLOP/s) | implicit GEMM, 4 launches %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
