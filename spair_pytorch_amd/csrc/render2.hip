@@ -549,7 +549,7 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
     const int t = (I + RT - 1) / RT;
     const dim3 grid(B * t * t), block(256);
     float2* aux2 = reinterpret_cast<float2*>(aux);
-    if (gen == 3 && P <= RF3_ROWS) {
+    if (gen != 2 && P <= RF3_ROWS) {
         const size_t lds3 = (size_t)rf3_shared_bytes() + 4 * (size_t)rf3_wave_bytes(P, texb);
         if (lds3 > 160 * 1024) return SPAIR_ERR_UNSUPPORTED;
         const bool ip2 = (I & (I - 1)) == 0;
