@@ -1214,22 +1214,33 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     if (tid >= NTH / 2 && tid < NTH / 2 + 4 * REC) a.gedge_part[(size_t)b * 4 * REC + (tid - NTH / 2)] = edge_reg;
 }
 
-// gedge[j] += sum_b sum_s part[b][s][j], in (sample, slot) order (one thread per element, 8 loads in flight)
-__global__ __launch_bounds__(64) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge) {
-    const int j = threadIdx.x;
-    if (j >= REC) return;
+// gedge[j] += sum_b sum_s part[b][s][j]: 16 row groups of one workgroup sum contiguous chunks in row order (8 loads in flight each), then the
+// 16 group sums are added in group order -- the same association on every run
+__global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge) {
+    __shared__ float grp[16][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = 4 * B, per = (n + 15) / 16;
+    const int lo = g * per, hi = min(n, lo + per);
     float t = 0.f;
-    const int n = 4 * B;
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        float v[8];
+    if (j < REC) {
+        int i = lo;
+        for (; i + 8 <= hi; i += 8) {
+            float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(i + e) * REC + j];
+            for (int e = 0; e < 8; ++e) v[e] = part[(size_t)(i + e) * REC + j];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t += v[e];
+            for (int e = 0; e < 8; ++e) t += v[e];
+        }
+        for (; i < hi; ++i) t += part[(size_t)i * REC + j];
     }
-    for (; i < n; ++i) t += part[(size_t)i * REC + j];
-    gedge[j] += t;
+    grp[g][j] = t;
+    __syncthreads();
+    if (g == 0 && j < REC) {
+        float r = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += grp[e][j];
+        gedge[j] += r;
+    }
 }
 
 int chain_bwd(const ChainArgs& a, hipStream_t s) {
@@ -1239,7 +1250,7 @@ int chain_bwd(const ChainArgs& a, hipStream_t s) {
     return SPAIR_OK;
 }
 int chain_edge_reduce(const ChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(64), 0, s, a.gedge_part, a.L.B, a.gedge);
+    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(1024), 0, s, a.gedge_part, a.L.B, a.gedge);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

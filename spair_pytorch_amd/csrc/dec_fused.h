@@ -4,6 +4,8 @@
 bool dec_fused_supported(int A, int n_out, int ld_za, long long N, int ld_s);
 size_t dec_fused_stream_bytes(int n_out);
 // packs the three weight matrices (fp32 parameters, row-major [out][in]) into the kernel's fragment stream
-int dec_fused_pack(const float* W0, const float* W1, const float* W2, int A, int n_out, void* stream_buf, hipStream_t s);
+// (decoder.out's rows pre-multiplied by -scale * log2 e: the kernel's accumulator is the exp2 argument of the sprite sigmoid)
+int dec_fused_pack(const float* W0, const float* W1, const float* W2, int A, int n_out, float obj_scale, float alpha_scale, void* stream_buf,
+                   hipStream_t s);
 int dec_fused_fwd(const void* Za16, int ld_za, const void* stream_buf, const float* b0, const float* b1, const float* b2, void* H1, void* H2,
                   void* S, int ld_s, long long N, int A, int n_out, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);

@@ -25,6 +25,7 @@
 #include "dec_fused.h"
 
 namespace {
+constexpr float DF_L2E = 1.4426950408889634f;
 
 constexpr int DF_WAVES = 4, DF_RT = 4;                 // waves per workgroup, 16-row tiles per wave
 constexpr int DF_ROWS_W = 16 * DF_RT, DF_ROWS = DF_ROWS_W * DF_WAVES;
@@ -117,7 +118,12 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
     }
     for (int i = tid; i < DF_H1; i += DF_WAVES * 64) bias_sh[i] = a.b0[i];
     for (int i = tid; i < DF_H2; i += DF_WAVES * 64) bias_sh[DF_H1 + i] = a.b1[i];
-    for (int i = tid; i < npairs * 32; i += DF_WAVES * 64) bias_sh[DF_H1 + DF_H2 + i] = (pair0 * 32 + i) < a.n_out ? a.b2[pair0 * 32 + i] : 0.f;
+    // decoder.out's weights arrive pre-multiplied by -scale * log2(e) (k_dec_pack), so the bias is folded the same way and the accumulator
+    // is directly the exp2 argument of the analytic sigmoid: even columns grey (obj scale), odd alpha (alpha scale and bias)
+    for (int i = tid; i < npairs * 32; i += DF_WAVES * 64) {
+        const float bv = (pair0 * 32 + i) < a.n_out ? a.b2[pair0 * 32 + i] : 0.f;
+        bias_sh[DF_H1 + DF_H2 + i] = (i & 1) ? -(bv * a.alpha_scale + a.alpha_bias) * DF_L2E : -(bv * a.obj_scale) * DF_L2E;
+    }
     // "use" the loaded fragments here, where nothing else is in flight: the compiler's own wait for them then sits in front of the first DMA
     // instead of in front of the first MFMA (where it would be an s_waitcnt vmcnt(0) that drains the prologue's four slots)
 #pragma unroll
@@ -231,8 +237,6 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
     }
 
     // ---- decoder.out + sprite epilogue: per pair of 16-column tiles two slots (k-steps 0..3, 4..7; fragment (ks, t) at (ks & 3) * 2 + t)
-    constexpr float L2E = 1.4426950408889634f;
-    const float sg = -a.obj_scale * L2E, sa = -a.alpha_scale * L2E, ba = -a.alpha_bias * L2E;
 #ifndef DF_PREFETCH
 #define DF_PREFETCH 1
 #endif
@@ -289,8 +293,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[t][j][r];
-                    const float u = (r & 1) ? fmaf(v, sa, ba) : v * sg;
+                    const float u = acc[t][j][r];
 #ifdef DF_EXP_NOEPI
                     o[t * 4 + r] = (_Float16)u;
 #else
@@ -354,8 +357,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[t][j][r];
-                    const float u = (r & 1) ? fmaf(v, sa, ba) : v * sg;
+                    const float u = acc[t][j][r];
 #ifdef DF_EXP_NOEPI
                     o[t * 4 + r] = (_Float16)u;
 #else
@@ -387,7 +389,8 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
 // One thread per 16-byte lane piece of a fragment.  Stream layout per half (slots of 8 fragments):
 //   [W0: 2 slots][W1: 8 slots][W0][W1] (one group per pair of row tiles) then 2 slots per pair of 16-column tiles of this half's decoder.out columns
 __global__ __launch_bounds__(256) void k_dec_pack(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2, int A,
-                                                  int n_out, uint4* __restrict__ st0, uint4* __restrict__ st1, int ns0, int ns1, int pair0_1) {
+                                                  int n_out, uint4* __restrict__ st0, uint4* __restrict__ st1, int ns0, int ns1, int pair0_1,
+                                                  float obj_scale, float alpha_scale) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long per0 = (long long)ns0 * 8 * 64, per1 = (long long)ns1 * 8 * 64;
     if (idx >= per0 + per1) return;
@@ -396,18 +399,21 @@ __global__ __launch_bounds__(256) void k_dec_pack(const float* __restrict__ W0, 
     const int lane = (int)(li & 63), f = (int)((li >> 6) & 7), s = (int)(li >> 9);
     const int q = lane >> 4, m = lane & 15;
     const float* W; int out, in, T, ks;
+    bool last = false;
     if (s < DF_SLOTS_SMALL) {
         const int g = s % 10;
         if (g < 2) { W = W0; out = DF_H1; in = A; const int pl = f >> 2; ks = (f >> 1) & 1; T = 2 * (g * 2 + pl) + (f & 1); }
         else { W = W1; out = DF_H2; in = DF_H1; ks = f >> 1; T = 2 * (g - 2) + (f & 1); }
     } else {
         const int u = s - DF_SLOTS_SMALL;
+        last = true;
         W = W2; out = n_out; in = DF_H2; ks = (u & 1) * 4 + (f >> 1); T = 2 * ((half ? pair0_1 : 0) + (u >> 1)) + (f & 1);
     }
     const int n = (T >> 1) * 32 + (m >> 2) * 8 + (T & 1) * 4 + (m & 3), k0 = ks * 32 + q * 8;
+    const float sc = last ? -((n & 1) ? alpha_scale : obj_scale) * DF_L2E : 1.f;      // sigmoid(scale * v + bias) = 1 / (1 + exp2(acc))
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((n < out && k0 + e < in) ? W[(size_t)n * in + k0 + e] : 0.f);
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((n < out && k0 + e < in) ? W[(size_t)n * in + k0 + e] * sc : 0.f);
     (half ? st1 : st0)[li] = *reinterpret_cast<uint4*>(&o);
 }
 
@@ -425,14 +431,16 @@ size_t dec_fused_stream_bytes(int n_out) {
     return (size_t)(2 * DF_SLOTS_SMALL + 2 * (np0 + np1)) * DF_SLOT_B;
 }
 // stream: dec_fused_stream_bytes(n_out) bytes of workspace; W0 [128][A], W1 [256][128], W2 [n_out][256] fp32 row-major (the parameters)
-int dec_fused_pack(const float* W0, const float* W1, const float* W2, int A, int n_out, void* stream_buf, hipStream_t s) {
+int dec_fused_pack(const float* W0, const float* W1, const float* W2, int A, int n_out, float obj_scale, float alpha_scale, void* stream_buf,
+                   hipStream_t s) {
     int np0, np1;
     dec_split(n_out, np0, np1);
     const int ns0 = DF_SLOTS_SMALL + 2 * np0, ns1 = DF_SLOTS_SMALL + 2 * np1;
     uint4* st0 = reinterpret_cast<uint4*>(stream_buf);
     uint4* st1 = st0 + (size_t)ns0 * (DF_SLOT_B / 16);
     const long long total = (long long)(ns0 + ns1) * 8 * 64;
-    hipLaunchKernelGGL(k_dec_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W0, W1, W2, A, n_out, st0, st1, ns0, ns1, np0);
+    hipLaunchKernelGGL(k_dec_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W0, W1, W2, A, n_out, st0, st1, ns0, ns1, np0,
+                       obj_scale, alpha_scale);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
@@ -463,7 +471,7 @@ extern "C" int spair_decoder_fwd16(const void* z_attr16, int ld_za, const float*
                                    float obj_scale, float alpha_scale, float alpha_bias, void* stream_buf, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!dec_fused_supported(A, n_out, ld_za, N, ld_s)) return SPAIR_ERR_UNSUPPORTED;
-    int rc = dec_fused_pack(W0, W1, W2, A, n_out, stream_buf, s);
+    int rc = dec_fused_pack(W0, W1, W2, A, n_out, obj_scale, alpha_scale, stream_buf, s);
     if (rc != SPAIR_OK) return rc;
     return dec_fused_fwd(z_attr16, ld_za, stream_buf, b0, b1, b2, H1, H2, sprites, ld_s, N, A, n_out, obj_scale, alpha_scale, alpha_bias, s);
 }

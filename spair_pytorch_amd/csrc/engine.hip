@@ -574,7 +574,7 @@ static int prep_weights(Ctx& c, bool need_dgrad, int part) {
     }
     if (part == 1 && c.use_dec_fused)
         TRY(dec_fused_pack(c.params + c.PL.lin[LIN_DEC0].w, c.params + c.PL.lin[LIN_DEC1].w, c.params + c.PL.lin[LIN_DEC2].w, c.d.A,
-                           c.d.P * c.d.P * (c.d.C + 1), c.w.dec_stream, c.s));
+                           c.d.P * c.d.P * (c.d.C + 1), c.d.obj_logit_scale, c.d.alpha_logit_scale, c.w.dec_stream, c.s));
     if (part == 1) {
         push(c.params + c.PL.lin[LIN_BOXH1].b, c.w.bias_boxh, 1, c.L.NP, c.L.NP + 8, 0, 0);
         push(c.params + c.PL.lin[LIN_BOXH0].b, c.w.bias_boxh + c.L.NP, 1, 8, 8, 0, 0);
