@@ -225,7 +225,8 @@ def attach_pmc_traffic(kernels, B, image, dtype):
     import glob
     if not (B == 256 and image == 128 and dtype == "bf16"):
         return
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    # configs[1] sets only: the 256x256 (configs[3]) sets are named r*_c3_* / r*_c4_*
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if "_c3_" not in f and "_c4_" not in f)
     if not files:
         return
     path = files[-1]

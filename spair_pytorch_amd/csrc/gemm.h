@@ -65,6 +65,8 @@ int spair_colsum_impl(const float* A, int lda, int R, int N, float* out, hipStre
 // gemm16.hip: bf16-stored operands
 int spair_gemm_nt16_impl(const GemmNT& g, bool conv, hipStream_t s);
 int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s);
+// tn_ring.hip: the same product through the DMA-staged split-K kernel (bf16 B, scratch required); SPAIR_ERR_UNSUPPORTED -> caller's kernel
+int spair_gemm_tn_ring(GemmTN g, bool conv, hipStream_t s);
 // stem (Cin = 1, 4x4, Cout = 128) weight + bias gradient; dY bf16 [B*Hout*Hout][128], xp padded fp32 input [B][Hin][Hin]
 int spair_stem_wgrad16_impl(const void* dY, const float* xp, float* dW, float* db, float* part, long long part_cap, int B, int Hin,
                             int stride, int Hout, hipStream_t s);

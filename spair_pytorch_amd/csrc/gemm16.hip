@@ -1215,6 +1215,10 @@ int spair_gemm_tn16_impl(GemmTN g, bool conv, bool b_bf16, hipStream_t s) {
         }
         g.M = BM; g.N = BN; g.Mstore = BM; g.Nstore = BN; g.lda = g.tile[0].lda; g.ldb = g.tile[0].ldb;
     }
+    if (b_bf16) {      // DMA-staged loader / consumer kernel (tn_ring.hip) wherever it applies
+        const int rc = spair_gemm_tn_ring(g, conv, s);
+        if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
+    }
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN) * (g.ngroup > 1 ? g.ngroup : 1);
     // one full round of resident blocks: 256 CUs x 3 blocks (150 VGPRs, 35 KB LDS); a 4/3-round grid wastes a third of the time
     int nsplit = max(1, min(ceil_div(g.R, 256), 768 / tiles));

@@ -229,6 +229,28 @@ def test_gemm_tn16_plain():
     assert (cs.cpu().double() - A.float().cpu().double().sum(0)).abs().max() <= 1e-4 * A.float().cpu().double().sum(0).abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("R,M,N", [(5000, 1568, 256), (4100, 104, 56), (65536, 256, 128), (300, 128, 2048)])
+def test_gemm_tn_ring_plain(R, M, N):
+    """tn_ring.hip (DMA-staged split-K weight-gradient GEMM, taken whenever scratch is passed and B is bf16): plain rows, R not a multiple of
+    the 64-row stage, partial tiles in both directions, bias gradient through the ones-fragment MFMA; two runs agree bit for bit."""
+    L = _lib()
+    g = torch.Generator().manual_seed(R + M)
+    A, B = _bf(torch.randn(R, M, generator=g)).cuda(), _bf(torch.randn(R, N, generator=g)).cuda()
+    scratch = torch.empty(1536 * 128 * 128, device="cuda")
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), 0.25, device="cuda")
+        cs = torch.zeros(M, device="cuda")
+        L.check(L.lib().spair_gemm_tn16(L.ptr(A), M, L.ptr(B), N, 1, L.ptr(C), N, M, N, R, None, 0, 0, L.ptr(cs), L.ptr(scratch),
+                                        ctypes.c_longlong(scratch.numel()), L.stream()), "tn ring")
+        outs.append((C.cpu(), cs.cpu()))
+    ref = A.float().cpu().double().t() @ B.float().cpu().double()
+    assert (outs[0][0].double() - 0.25 - ref).abs().max() <= 2e-5 * ref.abs().max()
+    ref_cs = A.float().cpu().double().sum(0)
+    assert (outs[0][1].double() - ref_cs).abs().max() <= 1e-4 * ref_cs.abs().max() + 1e-3
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("B,Hin", [(3, 142), (2, 54)])
 def test_stem_wgrad16_vs_torch(B, Hin):
     """Backbone layer 0 (1 -> 128 channels, 4x4, stride 2): dedicated weight/bias gradient kernel vs torch autograd."""

@@ -231,5 +231,7 @@ def test_gradient_bucket_events_open_an_overlap_window():
         open(os.path.join(ROOT, "gpurun_out", "r03_ddp_overlap_window.txt"), "w").write(text)
     except OSError:
         pass
-    assert r[1] >= 0.8 and r[2] >= 0.3 and r[3] >= 0.0, text
+    # windows as shares of the backward (they shrink with every speed-up of the tail behind them): the decoder bucket (3.1 MB) is ready with
+    # at least a fifth of the backward still to run, the cell nets' (1.7 MB) with a tenth
+    assert r[1] >= 0.2 * r[0] and r[2] >= 0.1 * r[0] and r[3] >= 0.0, text
     assert r[1] >= r[2] >= r[3], text
