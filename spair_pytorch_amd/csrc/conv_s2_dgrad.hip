@@ -36,13 +36,6 @@ struct ConvDgradArgs {
     const float* stem_xp; float* stem_part; int stem_hin, stem_s;
 };
 
-#ifdef DG_STAMP
-__device__ unsigned long long g_dg_st[2 * 8 * 256];
-extern "C" int spair_dg_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dg_st), sizeof(g_dg_st)) == hipSuccess ? 0 : -3; }
-#define DG_T(i) do { if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 1200)) g_dg_st[((blockIdx.x != 3) * 8 + wave) * 256 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DG_T(i)
-#endif
 // Swizzle key of weight-tile row n (16-byte chunk c of the row sits at position c ^ key): the computing waves read the rows in the PERMUTED
 // order n(T, m) = 32 (T >> 1) + 8 (m >> 2) + 4 (T & 1) + (m & 3) (so that a lane ends up with 8 consecutive output channels, see the kernel);
 // with the usual key n & 7 the 16 rows of a fragment would only produce 4 distinct keys.  This one gives 8, conflict-free for ds_read_b128.
@@ -115,10 +108,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         dg_wait<4>();                            // everything but tile 1
 #pragma unroll 1
         for (int kt = 0; kt < 32; ++kt) {
-            DG_T(4 * kt);
-            __builtin_amdgcn_s_barrier();        // barrier(kt): the computing waves are done with step kt - 1 (ring slot (kt + 2) % 3)
+            __builtin_amdgcn_s_barrier();        // barrier(kt): the computing waves have read all of tile kt - 1 (ring slot (kt + 2) % 3)
             asm volatile("" ::: "memory");
-            DG_T(4 * kt + 1);
             if (kt < 2) {                        // half 1 (first read at step 4): 2 x 4 pieces per loader, in front of the weight tile
                 issue_patch(1, kt, 4);
                 issue_b(kt + 2);
@@ -127,11 +118,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                 issue_b(kt + 2);
                 dg_wait<4>();
             }
-            if (STEM && (kt & 7) == 7) __builtin_amdgcn_s_barrier();       // the class epilogue's barrier E (stem product only)
+            if (STEM && kt != 0 && (kt & 7) == 0) __builtin_amdgcn_s_barrier();      // barrier E of the class that ended with step kt - 1 (the
+                                                                                     // computing waves run its epilogue behind barrier(kt))
         }
         __builtin_amdgcn_s_barrier();            // barrier(32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target this workgroup's LDS
-        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // E of the last class, X, Y
         return;
     }
 
@@ -165,9 +157,35 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    f32x4 acc[4][4];                             // [channel tile t][pixel tile j]
+    bf16x8 wfA[4], pfA[4], wfB[4], pfB[4];
+    auto read_frags = [&](int kt, int half, int tap, int ks, bf16x8 (&wf)[4], bf16x8 (&pf)[4]) {
+        const char* bs = bt + (kt % 3) * DG_BT_B;
+        const char* pb = patch + half * DG_PATCH_B;
+        const int toff = -((tap >> 1) * Wp + (tap & 1));
+        const int c = ks * 4 + q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = wrow0 + (t >> 1) * 32 + (t & 1) * 4;
+            wf[t] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ wkey) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pp = pbase[j] + toff;
+            pf[j] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
+        }
+    };
+    auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&pf)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                // barrier(0): tile 0 and the first patch half have landed
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0, 0, wfA, pfA);
     for (int cls = 0; cls < 4; ++cls) {
-        const int py = cls >> 1, px = cls & 1;
-        f32x4 acc[4][4];                         // [channel tile t][pixel tile j]
+        const int py = cls >> 1, px = cls & 1;                         // [channel tile t][pixel tile j]
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -194,38 +212,29 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             sp[2] = *reinterpret_cast<const float2*>(src + a.stem_hin);
             sp[3] = *reinterpret_cast<const float2*>(src + a.stem_hin + 2);
         }
-#pragma unroll
+        // K steps of the class, software-pipelined across the workgroup barriers: the fragments of (kt, ks 1) are read while the MFMAs of
+        // (kt, ks 0) run, those of (kt + 1, ks 0) -- right behind barrier(kt + 1), which certifies that tile -- while the MFMAs of (kt, ks 1)
+        // run.  Issued just in front of their MFMAs, every one of the 16 fragment reads of a K step exposed its LDS latency (4 waves reading
+        // 64 KB per step keep the LDS pipe busy for longer than the 512 MFMA cycles): a K step took 1,675 cycles.
+#pragma unroll 1
         for (int h4 = 0; h4 < 8; ++h4) {
-            const int half = h4 >> 2, tap = h4 & 3, kt = cls * 8 + h4;
-            DG_T(4 * kt);
-            __builtin_amdgcn_s_barrier();        // barrier(kt): tile kt (and, from step 4 on, the second patch half) has landed
+            const int kt = cls * 8 + h4;
+            read_frags(kt, h4 >> 2, h4 & 3, 1, wfB, pfB);
+            __builtin_amdgcn_sched_barrier(0);   // (pins the order: left alone hipcc sinks every read to just in front of its first MFMA)
+            mma(wfA, pfA);
+            __builtin_amdgcn_sched_barrier(0);
+            // every read of tile kt is in registers: its ring slot may be refilled.  (The builtin, not inline asm: hipcc's own wait
+            // insertion does not see through asm and would wait for these reads AGAIN in front of the MFMAs below -- with the next
+            // tile's reads already queued behind them, i.e. for those too.)
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();        // barrier(kt + 1): tile kt + 1 has landed (barrier(32): nothing follows)
             asm volatile("" ::: "memory");
-            DG_T(4 * kt + 1);
-            const char* bs = bt + (kt % 3) * DG_BT_B;
-            const char* pb = patch + half * DG_PATCH_B;
-            const int toff = -((tap >> 1) * Wp + (tap & 1));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 wf[4], pf[4];
-                const int c = ks * 4 + q;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int n = wrow0 + (t >> 1) * 32 + (t & 1) * 4;
-                    wf[t] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ wkey) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pp = pbase[j] + toff;
-                    pf[j] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
-            }
+            read_frags(kt + 1, ((h4 + 1) & 7) >> 2, (h4 + 1) & 3, 0, wfA, pfA);      // (behind barrier(32): stale bytes of slot 2, never used)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wfB, pfB);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- class epilogue on registers: gate = stored activation of the layer below > 0 (bf16 sign / zero test), 8 channels of one pixel per lane
-        DG_T(4 * (cls * 8 + 7) + 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -275,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             // (the next class overwrites the tile / patches only behind its 8 K-step barriers)
         }
     }
-    __builtin_amdgcn_s_barrier();                // barrier(32)
     if (STEM) {
+        __builtin_amdgcn_s_barrier();            // X: every wave is done with the last class's stem product (reads of Gs)
         float* Ws = reinterpret_cast<float*>(Gs);            // [128 ch][17]
         const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
@@ -292,7 +301,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         asm volatile("" ::: "memory");
         float4* pt = reinterpret_cast<float4*>(a.stem_part + (size_t)blockIdx.x * DG_STEM_FLOATS);
         for (int qq = tid; qq < DG_STEM_FLOATS / 4; qq += 256) pt[qq] = reinterpret_cast<const float4*>(Ws)[qq];
-        __builtin_amdgcn_s_barrier();
     }
 }
 

@@ -259,16 +259,16 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
     }
     auto half_body = [&](int i_run, auto w_c, bf16x8 (&Fc)[8], bf16x8 (&Fn)[8], f32x4 (&acc)[2][DF_RT], int hs) {
         constexpr int W = decltype(w_c)::value;
-        DF_T(3 * (i_run - DF_SLOTS_SMALL));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of slot i_run are done: its buffer may be overwritten after the barrier
+        // this wave's reads of slot i_run are done: its buffer may be overwritten after the barrier.  (The builtin: hipcc's own wait insertion
+        // does not see through an inline-asm s_waitcnt and would wait for these reads again, behind the next slot's.)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         df_wait<W>();
-        DF_T(3 * (i_run - DF_SLOTS_SMALL) + 1);
         __builtin_amdgcn_s_barrier();
-        DF_T(3 * (i_run - DF_SLOTS_SMALL) + 2);
         asm volatile("" ::: "memory");
         issue(i_run + 1 + DF_D);
         __builtin_amdgcn_sched_barrier(0);
         load_frags(Fn, i_run + 1);
+        __builtin_amdgcn_sched_barrier(0);       // the reads are ISSUED here (left alone hipcc sinks them below the MFMAs, right in front of the wait)
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc[kq * 2], as_bf16x8(h2f[j][hs * 4 + kq]), acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc[kq * 2 + 1], as_bf16x8(h2f[j][hs * 4 + kq]), acc[1][j], 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto pair_body = [&](int pr, auto wa_c, auto wb_c) {
         const int i_run = DF_SLOTS_SMALL + 2 * pr;

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int TR_BM = 128, TR_BK = 64, TR_NST = 3;
+constexpr int TR_BM = 128, TR_BK = 64;
 constexpr int TR_GRP_B = TR_BK * 128;            // one 64-column group of a stage: 64 rows x 128 B
 
 typedef short tr_v4s16 __attribute__((ext_vector_type(4)));
@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
     return u.v;
 }
 
-template <int BN, bool BCONV>
+template <int BN, bool BCONV, int NST>
 __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
     constexpr int NGB = BN / 64;                      // 64-column groups of B
     constexpr int STAGE_B = (2 + NGB) * TR_GRP_B;     // A: groups 0, 1; B: groups 2 ..
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)byte_off, 0, 0, 0);
         };
         auto issue = [&](int st) {
-            char* sb = tr_sm + (st % TR_NST) * STAGE_B;
+            char* sb = tr_sm + (st % NST) * STAGE_B;
             const bool live = st < nst;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
                     glds(rsB, (rok & b_ok[gi]) ? (rb + b_col[gi]) * 2u : BUF_OOB, sb + (2 + gi) * TR_GRP_B + rl * 128);
             }
         };
-        issue(0);
-        issue(1);
-        tr_wait<PER>();                              // stage 0 has landed
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st) issue(st);
+        tr_wait<PER * (NST - 2)>();                  // stage 0 has landed
 #pragma unroll 1
         for (int kt = 0; kt < nst; ++kt) {
             __builtin_amdgcn_s_barrier();            // barrier(kt): stage kt is complete for everyone; the computing waves are done with stage kt - 1
             asm volatile("" ::: "memory");
-            issue(kt + 2);                           // into the slot of stage kt - 1 (zeros past the last stage: keeps the counts uniform)
-            tr_wait<PER>();                          // stage kt + 1 has landed
+            issue(kt + NST - 1);                     // into the slot of stage kt - 1 (zeros past the last stage: keeps the counts uniform)
+            tr_wait<PER * (NST - 2)>();              // stage kt + 1 has landed
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing DMAs target this workgroup's LDS
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
     for (int kt = 0; kt < nst; ++kt) {
         __builtin_amdgcn_s_barrier();                // barrier(kt): stage kt has landed
         asm volatile("" ::: "memory");
-        const char* sb = tr_sm + (kt % TR_NST) * STAGE_B;
+        const char* sb = tr_sm + (kt % NST) * STAGE_B;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[TN];
@@ -192,16 +192,16 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
     }
 }
 
-template <int BN, bool BCONV>
+template <int BN, bool BCONV, int NST>
 int tr_launch(const GemmTN& g, dim3 grid, hipStream_t s) {
-    constexpr int lds = TR_NST * (2 + BN / 64) * TR_GRP_B;
+    constexpr int lds = NST * (2 + BN / 64) * TR_GRP_B;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tn_ring<BN, BCONV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tn_ring<BN, BCONV, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return SPAIR_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_tn_ring<BN, BCONV>), grid, dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_tn_ring<BN, BCONV, NST>), grid, dim3(512), lds, s, g);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
@@ -234,8 +234,11 @@ int spair_gemm_tn_ring(GemmTN g, bool conv, hipStream_t s) {
     if ((long long)grid.x * (TR_BM * BN + TR_BM) > g.part_cap) return SPAIR_ERR_UNSUPPORTED;
     g.colpart = g.part + (size_t)grid.x * TR_BM * BN;
     int rc;
-    if (BN == 256) rc = conv ? tr_launch<256, true>(g, grid, s) : tr_launch<256, false>(g, grid, s);
-    else rc = conv ? tr_launch<128, true>(g, grid, s) : tr_launch<128, false>(g, grid, s);
+    static const int nst128 = [] { const char* e = getenv("SPAIR_TN_RING_NST"); return e ? atoi(e) : 3; }();
+    if (BN == 256) rc = conv ? tr_launch<256, true, 3>(g, grid, s) : tr_launch<256, false, 3>(g, grid, s);
+    else if (nst128 == 5) rc = conv ? tr_launch<128, true, 5>(g, grid, s) : tr_launch<128, false, 5>(g, grid, s);
+    else if (nst128 == 4) rc = conv ? tr_launch<128, true, 4>(g, grid, s) : tr_launch<128, false, 4>(g, grid, s);
+    else rc = conv ? tr_launch<128, true, 3>(g, grid, s) : tr_launch<128, false, 3>(g, grid, s);
     if (rc != SPAIR_OK) return rc;
     return spair_tn_reduce(g, TR_BM, BN, s);
 }

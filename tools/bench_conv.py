@@ -54,3 +54,31 @@ for name, B, Ho in (("conv_1 dgrad", 256, 34), ("conv_2 dgrad", 256, 16)):
     t_old = timeit(old)
     fl = 2.0 * M * C * 512 * 4
     print("%s: patch-resident %.3f ms (%.0f TFLOP/s) | implicit GEMM, 4 launches %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
+
+# weight gradients: the DMA-staged split-K kernel (tn_ring.hip, taken when scratch is passed) vs gemm_tn16_kernel (no scratch: fp32 atomics)
+scratch = torch.empty(1536 * 128 * 128, device="cuda")
+for name, B, Hout in (("conv_1 wgrad", 256, 31), ("conv_2 wgrad", 256, 15)):
+    Hin, C = 2 * Hout + 2, 128
+    x = torch.randn(B, Hin, Hin, C, device="cuda").to(bf)
+    M = B * Hout * Hout
+    dy = torch.randn(M, C, device="cuda").to(bf)
+    dW = torch.zeros(C, 2048, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    conv13 = (ctypes.c_int * 13)(Hin, Hin, C, Hout, Hout, 4, 4, 2, 2, 1, 1, 0, 0)
+    t_new = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(dy), C, L.ptr(x), 0, 1, L.ptr(dW), 2048, C, 2048, M, conv13, C, 16, L.ptr(db), L.ptr(scratch),
+                                                       ctypes.c_longlong(scratch.numel()), L.stream()), name))
+    t_old = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(dy), C, L.ptr(x), 0, 1, L.ptr(dW), 2048, C, 2048, M, conv13, C, 16, L.ptr(db), None,
+                                                       ctypes.c_longlong(0), L.stream()), name))
+    fl = 2.0 * M * C * 2048
+    print("%s: ring (+reduce) %.3f ms (%.0f TFLOP/s) | register-staged, atomics %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
+for name, R, M, N in (("decoder.out wgrad", 65536, 1568, 256), ("decoder.1 wgrad", 65536, 256, 128), ("enc.0 wgrad", 65536, 256, 784)):
+    A = torch.randn(R, M, device="cuda").to(bf)
+    Bm = torch.randn(R, (N + 7) // 8 * 8, device="cuda").to(bf)
+    Cw = torch.zeros(M, N, device="cuda")
+    cs = torch.zeros(M, device="cuda")
+    t_new = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(A), M, L.ptr(Bm), Bm.shape[1], 1, L.ptr(Cw), N, M, N, R, None, 0, 0, L.ptr(cs), L.ptr(scratch),
+                                                       ctypes.c_longlong(scratch.numel()), L.stream()), name))
+    t_old = timeit(lambda: L.check(lib.spair_gemm_tn16(L.ptr(A), M, L.ptr(Bm), Bm.shape[1], 1, L.ptr(Cw), N, M, N, R, None, 0, 0, L.ptr(cs), None,
+                                                       ctypes.c_longlong(0), L.stream()), name))
+    fl = 2.0 * M * N * R
+    print("%s: ring (+reduce) %.3f ms (%.0f TFLOP/s) | register-staged, atomics %.3f ms (%.0f TFLOP/s)" % (name, t_new, fl / t_new / 1e9, t_old, fl / t_old / 1e9))
