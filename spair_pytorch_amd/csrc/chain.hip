@@ -56,33 +56,19 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
 // boundaries and barriers: pipe_fill() for layer l+1 is issued right after the MFMAs of layer l.
 constexpr int NW = 8;                     // waves per workgroup
 constexpr int NTH = NW * 64;
-#ifndef CHAIN_RD
-#define CHAIN_RD 12      // measured: 16 / 20 / 24 fragments in flight per wave change nothing (0.91 -> 0.93-0.95 ms)
-#endif
-constexpr int RD = CHAIN_RD;
-#ifndef CHAIN_NT
-#define CHAIN_NT 1        // the row-buffer stores are non-temporal: they stream past the L2 that holds the weights every workgroup re-reads each wavefront (chain fwd 0.854 -> 0.836 ms, bwd 0.861 -> 0.851)
-#endif
-#if CHAIN_NT
+constexpr int RD = 12;      // weight fragments in flight per wave (measured: 16 / 20 / 24 change nothing, 0.91 -> 0.93-0.95 ms)
+// the row-buffer stores are non-temporal: they stream past the L2 that holds the weights every workgroup re-reads each wavefront (chain fwd
+// 0.854 -> 0.836 ms, bwd 0.861 -> 0.851)
 template <typename T> __device__ __forceinline__ void ch_gstore_nt(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void ch_gstore_nt(float4* p, const float4& v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
 }
 #define CH_GSTORE(p, v) ch_gstore_nt((p), (v))
-#else
-#define CH_GSTORE(p, v) (*(p) = (v))
-#endif
-#ifndef CHAIN_NT_LD
-#define CHAIN_NT_LD 1     // the backward kernel's read-once row data (bundle, glimpse derivatives) is loaded non-temporally (chain bwd 0.852 -> 0.833 ms)
-#endif
+// the backward kernel's read-once row data (bundle, glimpse derivatives) is loaded non-temporally (chain bwd 0.852 -> 0.833 ms)
 __device__ __forceinline__ uint4 ch_gload16(const void* p) {
-#if CHAIN_NT_LD
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(v[0], v[1], v[2], v[3]);
-#else
-    return *reinterpret_cast<const uint4*>(p);
-#endif
 }
 #define CH_GLOAD16(p) ch_gload16(p)
 __device__ __forceinline__ float4 ch_gloadf4(const float* p) {
@@ -389,16 +375,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
-#ifdef CHAIN_SUBSTAMP
-            asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));      // MFMA results complete
-            CH_STAMP();
-#endif
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
             wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
-#ifdef CHAIN_SUBSTAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            CH_STAMP();
-#endif
         } else {
             copy_rows_b16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
         }
@@ -495,17 +473,6 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const bool xin = (xw[q] & 0x10000u) != 0u;
                 const float mx = (xw[q] & 0x20000u) ? gmult : 0.f;
                 const float wx1 = __uint_as_float(xf[q]), wx0 = 1.f - wx1;
-#ifdef GT_CHECK
-                {
-                    float ix, mx2, iy2, my2;
-                    stn_src_coord_b(nb_sh[row][2], 2.f * nb_sh[row][0] - 1.f, pbase_sh[j0 + q], a.I, a.ac, true, ix, mx2);
-                    stn_src_coord_b(nb_sh[row][3], 2.f * nb_sh[row][1] - 1.f, pbase_sh[i], a.I, a.ac, true, iy2, my2);
-                    const int x0b = (int)floorf(ix), y0b = (int)floorf(iy2);
-                    const bool bad = x0b != x0 || (ix - (float)x0b) != wx1 || mx2 != mx || (((x0b + 1) < a.I) != xin) || y0b != y0 ||
-                                     (iy2 - (float)y0b) != wy1 || my2 != my || (((y0b + 1) < a.I) != yin);
-                    if (bad && a.stamps) atomicAdd(reinterpret_cast<unsigned long long*>(a.stamps) + 4000, 1ull);
-                }
-#endif
                 const int x1 = xin ? x0 + 1 : x0;
                 const float m1 = xin ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
                 const float v00 = px(r0o + x0), v01 = m1 * px(r0o + x1), v10 = n1 * px(r1o + x0), v11 = m1 * n1 * px(r1o + x1);

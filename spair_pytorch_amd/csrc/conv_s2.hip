@@ -31,13 +31,6 @@ struct ConvPatchArgs {
     int B, Hin, Hout, M, K;                      // M = B * Hout * Hout, K = 16 * 128
 };
 
-#ifdef CP_STAMP
-__device__ unsigned long long g_cp_st[2 * 8 * 128];
-extern "C" int spair_cp_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_st), sizeof(g_cp_st)) == hipSuccess ? 0 : -3; }
-#define CP_T(i) do { if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 600)) g_cp_st[((blockIdx.x != 3) * 8 + wave) * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CP_T(i)
-#endif
 template <int W>
 __device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory"); }
 
@@ -109,21 +102,10 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 const int kt = st * 4 + j4;
-                CP_T(3 * kt);
                 __builtin_amdgcn_s_barrier();          // barrier(kt): the consumers are done with step kt - 1 (slot (kt + 2) % 3, and at j4 = 0 the other patch buffer)
                 asm volatile("" ::: "memory");
-                CP_T(3 * kt + 1);
-#ifndef CP_EXP_NOPATCH
                 if (j4 != 3) issue_patch(st + 1, j4);
-#else
-                if (j4 != 3) issue_patch(9, j4);       // experiment: only out-of-range pieces (zero fill, no memory traffic)
-#endif
-#ifndef CP_EXP_NOB
                 issue_b(kt + 2);
-#else
-                issue_b(1000);
-#endif
-                CP_T(3 * kt + 2);
                 // tile kt + 1 = the last 4 operations of the previous batch; younger: this batch
                 if (j4 == 3) cp_wait<4>(); else cp_wait<4 + CP_NPIECE_W>();
             }
@@ -143,10 +125,8 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 const int kt = st * 4 + j4;
-                CP_T(3 * kt);
                 __builtin_amdgcn_s_barrier();          // barrier(kt): tile kt (and at j4 = 0 this stage's patch) has landed for every loader
                 asm volatile("" ::: "memory");
-                CP_T(3 * kt + 1);
                 const char* bs = bt + (kt % 3) * CP_BT_B;
                 const int tap = (j4 >> 1) * Ws + (j4 & 1);
 #pragma unroll

@@ -72,13 +72,6 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const uint4& v) {
     return c.b;
 }
 
-#ifdef DF_STAMP
-__device__ unsigned long long g_df_st[8 * 256];
-extern "C" int spair_df_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_st), sizeof(g_df_st)) == hipSuccess ? 0 : -3; }
-#define DF_T(i) do { if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 301)) g_df_st[((blockIdx.x != 0) * 4 + wave) * 256 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DF_T(i)
-#endif
 template <int W>
 __device__ __forceinline__ void df_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");
@@ -135,21 +128,12 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
 
     auto issue = [&](int s) {         // slot s of the stream -> ring slot s % DF_NS; past the end: the last slot again (never consumed) so that
                                       // every iteration issues the same number of operations
-#ifdef DF_EXP_NODMA
-        const char* src = strm + (size_t)min(s, 3) * DF_SLOT_B + (wave * 2) * 1024 + lane * 16;     // always the same (L2 / L1-hot) slots
-#else
         const char* src = strm + (size_t)min(s, ns - 1) * DF_SLOT_B + (wave * 2) * 1024 + lane * 16;
-#endif
         char* dst = ring + (s % DF_NS) * DF_SLOT_B + (wave * 2) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
                                          (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
     };
-#ifdef DF_STAGGER
-    // the two workgroups that share a CU (ids b and b + grid/2 under in-order dispatch; speed only) run the same program from the same
-    // start: half of them are delayed so that one's MFMA phases meet the other's waits / epilogues
-    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_sleep(DF_STAGGER);
-#endif
 #pragma unroll
     for (int s = 0; s < DF_D; ++s) issue(s);
 
@@ -237,10 +221,6 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
     }
 
     // ---- decoder.out + sprite epilogue: per pair of 16-column tiles two slots (k-steps 0..3, 4..7; fragment (ks, t) at (ks & 3) * 2 + t)
-#ifndef DF_PREFETCH
-#define DF_PREFETCH 1
-#endif
-#if DF_PREFETCH
     // The fragments of slot i+1 are read from LDS while the MFMAs of slot i run: at the top of iteration i the wave waits for slot i+1
     // (not i), and the barrier there also tells everyone that slot i's fragments are in registers -- its buffer is refilled at once.
     // Without this every slot started with a full LDS round trip (8 reads, s_waitcnt lgkmcnt(0)) in front of its 32 MFMAs.
@@ -295,20 +275,12 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float u = acc[t][j][r];
-#ifdef DF_EXP_NOEPI
-                    o[t * 4 + r] = (_Float16)u;
-#else
                     o[t * 4 + r] = (_Float16)__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(u) + 1.f);
-#endif
                 }
             const int row = row0 + j * 16 + r16;
             uint4 ov;
             __builtin_memcpy(&ov, &o, 16);
-#ifdef DF_EXP_NOSTORE
-            buf_store16(rs, (row < -1) ? 0u : BUF_OOB, ov);
-#else
             buf_store16(rs, (row < a.N && col < a.n_out) ? ((unsigned)row * (unsigned)a.ld_s + (unsigned)col) * 2u : BUF_OOB, ov);
-#endif
         }
     };
     // waits (operations younger than the DMAs of slot i+1 at the top of iteration i): 6 DMAs + the stores of iterations i-4 .. i-1, except
@@ -323,66 +295,6 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_dec_fwd(DecFwdArgs a) {
 #pragma unroll 1
     for (int pr = 2; pr < npairs; ++pr)
         pair_body(pr, std::integral_constant<int, df_wait_of_slot(S0 + 4)>{}, std::integral_constant<int, df_wait_of_slot(S0 + 5)>{});
-#else
-    auto pair_body = [&](int pr, auto wa_c, auto wb_c) {
-        constexpr int WA = decltype(wa_c)::value, WB = decltype(wb_c)::value;
-        const int i_run = DF_SLOTS_SMALL + 2 * pr;
-        const float4 bA = bias4(DF_H1 + DF_H2 + pr * 32 + q * 8);
-        const float4 bB = bias4(DF_H1 + DF_H2 + pr * 32 + q * 8 + 4);
-        f32x4 acc[2][DF_RT];
-#pragma unroll
-        for (int j = 0; j < DF_RT; ++j) { acc[0][j] = (f32x4){bA.x, bA.y, bA.z, bA.w}; acc[1][j] = (f32x4){bB.x, bB.y, bB.z, bB.w}; }
-#pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-            if (hs == 0) { df_wait<WA>(); } else { df_wait<WB>(); }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue(i_run + hs + DF_D);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const bf16x8 w0 = frag(i_run + hs, kq * 2), w1 = frag(i_run + hs, kq * 2 + 1);
-#pragma unroll
-                for (int j = 0; j < DF_RT; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, as_bf16x8(h2f[j][hs * 4 + kq]), acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, as_bf16x8(h2f[j][hs * 4 + kq]), acc[1][j], 0, 0, 0);
-                }
-            }
-        }
-        // sprite epilogue (models.py:485-492): even columns grey, odd alpha; analytic sigmoid through exp2 / rcp; fp16 pairs
-        const int col = (pair0 + pr) * 32 + q * 8;
-#pragma unroll
-        for (int j = 0; j < DF_RT; ++j) {
-            h8_t o;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = acc[t][j][r];
-#ifdef DF_EXP_NOEPI
-                    o[t * 4 + r] = (_Float16)u;
-#else
-                    o[t * 4 + r] = (_Float16)__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(u) + 1.f);
-#endif
-                }
-            const int row = row0 + j * 16 + r16;
-            uint4 ov;
-            __builtin_memcpy(&ov, &o, 16);
-#ifdef DF_EXP_NOSTORE
-            buf_store16(rs, (row < -1) ? 0u : BUF_OOB, ov);
-#else
-            buf_store16(rs, (row < a.N && col < a.n_out) ? ((unsigned)row * (unsigned)a.ld_s + (unsigned)col) * 2u : BUF_OOB, ov);
-#endif
-        }
-    };
-    // wait counts: the stores of the four preceding slots differ for the first two pairs (layer 1's 2 per slot), then (0, 4) repeats
-    pair_body(0, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 0)>{}, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 1)>{});
-    if (npairs > 1)
-        pair_body(1, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 2)>{}, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 3)>{});
-#pragma unroll 1
-    for (int pr = 2; pr < npairs; ++pr)
-        pair_body(pr, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 4)>{}, std::integral_constant<int, df_wait_of_slot(DF_SLOTS_SMALL + 5)>{});
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs target this workgroup's LDS: they must land before it is released
 #undef DF_ACQUIRE
 }

@@ -366,7 +366,6 @@ static int side_stream(SideStream*& out) {
         // dependent chain -- when both have workgroups to place, the chain's go first
         int prio_least = 0, prio_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = 0;
-        if (getenv("SPAIR_SIDE_PRIO")) prio_least = atoi(getenv("SPAIR_SIDE_PRIO"));
         hipStream_t st = nullptr;
         if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least) != hipSuccess) return SPAIR_ERR_LAUNCH;
         for (int i = 0; i < 6; ++i)

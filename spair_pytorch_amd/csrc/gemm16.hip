@@ -85,60 +85,28 @@ __device__ __forceinline__ bf16x8 lds_tr_frag16(const __bf16* tile, int ld, int 
 // matrix is 1: the bias gradient) -- and d act0 is never written to HBM (321 MB out + 321 MB back in at config 2).  Each
 // workgroup leaves a [128][17] fp32 partial; spair_gemm_nt16_impl sums them (two small passes, no atomics).
 #define STEM_PART_FLOATS (128 * 17)
-// LDS operand tiles: SWZ = rows of exactly BK elements (128 or 64 bytes) with the 16-byte chunk index XOR-ed by a function of the row
+// LDS operand tiles: rows of exactly BK elements (128 or 64 bytes) with the 16-byte chunk index XOR-ed by a function of the row
 // -- chunk ^ (row & 7) at BK 64, chunk ^ (-(row >> 2) & 3) at BK 32 -- which makes every ds_read_b128 fragment read and every
 // ds_write_b128 staging write conflict-free (ds_read_b128 serves lanes {0-3, 12-15, 20-27} etc. together: with rows padded by
 // 16 bytes instead, 7 of each group's 16 lanes shared a bank pair with another, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 - 0.46).
 template <int BK>
 __device__ __forceinline__ int nt16_swz(int row) { return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3); }
 
-// GL (needs SWZ): the operand tiles go HBM/L2 -> LDS by direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPR round trip, no
+// Staging: the operand tiles go HBM/L2 -> LDS by direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPR round trip, no
 // ds_write pass; a wave-instruction writes 1 KiB = 8 (BK 64) or 16 (BK 32) whole unpadded tile rows at base + lane * 16, so the XOR
 // swizzle is applied on the SOURCE side: the lane that owns LDS chunk c of row r fetches global chunk c ^ swz(r)); masked lanes pass an
 // out-of-range offset and the range check writes zeros.
-#ifdef NT16_STAMP
-// diagnostic builds only (tools/build_variant.sh ... -DNT16_STAMP): cycles per K-loop phase, summed over K tiles, waves and workgroups
-__device__ unsigned long long g_nt16_st[8];
-extern "C" int spair_nt16_stamps(unsigned long long* out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_nt16_st), sizeof(g_nt16_st)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_nt16_st), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#define NT16_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define NT16_T(var)
-#endif
-template <bool ACONV, bool C16, bool STEM, int BK, bool SWZ, bool GL>
+template <bool ACONV, bool C16, bool STEM, int BK>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT g) {
-    static_assert(!GL || SWZ, "direct-to-LDS staging needs the unpadded swizzled tile");
     static_assert(BK == 64 || BK == 32, "K tile");
-    constexpr int BM = 128, BN = 128, LD = SWZ ? BK : BK + 8;
+    constexpr int BM = 128, BN = 128, LD = BK;       // unpadded swizzled rows
     constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
     constexpr int KQ = BK / 8, RPI = 256 / KQ;                          // 16-byte chunks per tile row; rows staged per pass of the block
     constexpr int NA = BM * KQ / 256, NB = BN * KQ / 256;               // 16-byte chunks per thread: 4 + 4 (BK 64), 2 + 2 (BK 32)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-#ifndef NT16_RING64
-#define NT16_RING64 0     // 1: the 3-deep ring at BK 64 too (96 KB of LDS: one workgroup per CU) -- A/B builds only
-#endif
-    constexpr int NBUF = (GL && (BK == 32 || NT16_RING64)) ? 3 : 2;      // direct-to-LDS at BK 32: a 3-deep ring, two K tiles in flight behind a counted wait
-    // Two A/B build switches, both measured and left OFF (tools/build_variant.sh <name> gemm16.hip -DNT16_A3B2=1 / -DNT16_FRAG_AHEAD=1;
-    // conv_1 forward 0.230-0.236 ms with either or both against 0.233 ms without, every other launch of tools/bench_gemm16.py within
-    // the run-to-run spread too).  What the K loop costs, from builds that skip operand fetches after the third K tile
-    // (-DNT16_EXP_NO_A / _NO_B): conv_1 forward 0.222 ms = 0.147 ms with no fetches at all (1,055 TFLOP/s: LDS reads + MFMA + epilogue +
-    // a 4.5-round grid) + 0.053-0.060 for the gathered A tile + 0.015-0.022 for the L2-hot weight tile.
-#ifndef NT16_NT_STORE
-#define NT16_NT_STORE 0   // bit 0: sprites, bit 1: bf16 outputs leave through non-temporal stores
-#endif
-#ifndef NT16_FRAG_AHEAD
-#define NT16_FRAG_AHEAD 0 // 1: all 16 fragment reads of a K tile (BK 64) are issued before its first MFMA
-#endif
-#ifndef NT16_A3B2
-#define NT16_A3B2 0       // 1: direct-to-LDS at BK 64 with three A buffers (fetched two tiles ahead), two B buffers: 80 KB, still two workgroups per CU
-#endif
-    constexpr bool A3B2 = GL && BK == 64 && NBUF == 2 && NT16_A3B2;
-    constexpr int NBUF_A = A3B2 ? 3 : NBUF;
-    __bf16* As0 = smem;                       // [NBUF_A][BM*LD]
-    __bf16* Bs0 = smem + NBUF_A * BM * LD;    // [NBUF][BN*LD]
+    constexpr int NBUF = BK == 32 ? 3 : 2;      // BK 32: a 3-deep ring, two K tiles in flight behind a counted wait; BK 64: two buffers (73.7 KB, 2 workgroups per CU)
+    __bf16* As0 = smem;                       // [NBUF][BM*LD]
+    __bf16* Bs0 = smem + NBUF * BM * LD;      // [NBUF][BN*LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -171,7 +139,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     // conv kernels VALU-issue bound): every row's element offset is computed ONCE (32-bit), the tap's offset once per K tile, and a
     // chunk's address is one add.  Tensors must stay below 2^31 elements (checked by the launcher).
     const int kq_slot = tid % KQ;                                        // this thread's LDS chunk slot in its rows
-    const int kq = GL ? (kq_slot ^ nt16_swz<BK>(tid / KQ)) : kq_slot;   // ... and the global k-chunk it fetches (GL: source-side swizzle)
+    const int kq = kq_slot ^ nt16_swz<BK>(tid / KQ);                    // ... and the global k-chunk it fetches (source-side swizzle)
     ConvTap16 a_ct;
     unsigned a_base[NA];                 // element offset of (b, y*sy+oy, x*sx+ox, 0) (conv) or of row m (plain)
     int a_y[NA], a_x[NA];                // conv: y*sy+oy, x*sx+ox for the bounds test of data-gradient gathers
@@ -204,62 +172,22 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
     }
 
     const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(A), rsB = buf_rsrc(B);
-    uint4 ra[NA], rb[NB];
     const int tap_wraps = ACONV ? ceil_div_dev(BK, g.conv.Cin) : 0;
     const int Klast = g.K - 8;
-    // (no branch around a load: a conditional VM op makes the pending count unknown and every wait becomes vmcnt(0); tiles past K are
-    //  fetched from clamped addresses and zeroed by selects)
-    auto load_tiles = [&](int k0, uint4 (&ra)[NA], uint4 (&rb)[NB]) {
+    // the loads land in LDS buffer `buf` directly (no branch around a load: a conditional VM op makes the pending count unknown and every
+    // wait becomes vmcnt(0); tiles past K are requested out of range and land as zeros)
+    auto glds16 = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, __bf16* tile, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + (i * 256 + wave * 64) * 16), 16,
+                                                 (int)byte_off, 0, 0, 0);
+    };
+    auto glds_tiles = [&](int k0, int buf) {
+        __bf16* As = As0 + buf * BM * LD;
+        __bf16* Bs = Bs0 + buf * BN * LD;
         const int k = k0 + kq * 8;
         const bool kok = k < g.K;
         const bool live = k0 < g.K;                      // wave-uniform
         const unsigned kc = (unsigned)min(k, Klast);
         if (ACONV) {
-            int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
-            if (BK == 64 && g.n_ktab > 0) {     // wave-uniform: tap-parity K order, one (tap, 64-channel block) per K tile
-                const unsigned e = g.ktab[min(k0 >> 6, g.n_ktab - 1)];
-                t_ky = (int)(e >> 24); t_kx = (int)((e >> 16) & 255u); t_ci = (int)(e & 0xffffu) + kq * 8;
-            }
-            const int dy = t_ky * g.conv.dky, dx = t_kx * g.conv.dkx;
-            const unsigned tapoff = (unsigned)((dy * g.conv.Win + dx) * g.conv.Cin + min(t_ci, g.conv.Cin - 8));
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                bool ok = a_ok[i] && kok;
-                unsigned off = a_base[i] + tapoff;
-                if (need_bounds) {      // wave-uniform: forward-geometry gathers never leave the tensor
-                    const int sy = a_y[i] + dy, sx = a_x[i] + dx;
-                    const bool in = sy >= 0 && sy < g.conv.Hin && sx >= 0 && sx < g.conv.Win;
-                    ok = ok && in;
-                    off = in ? off : 0u;
-                }
-                ra[i] = buf_load16(rsA, (ok && live) ? off * 2u : BUF_OOB);
-            }
-            if (live) ctap_advance(g.conv, a_ct, BK, tap_wraps);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = buf_load16(rsA, (a_ok[i] && kok) ? (a_base[i] + kc) * 2u : BUF_OOB);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB);
-    };
-    const int kqs = (SWZ && !GL) ? (kq ^ nt16_swz<BK>(tid / KQ)) : kq_slot;       // RPI is a multiple of 8 (BK 64) / of 16 (BK 32): the same for every pass
-    // GL: the same offsets, the loads land in LDS buffer `buf` directly
-    auto glds16 = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte_off, __bf16* tile, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + (i * 256 + wave * 64) * 16), 16,
-                                                 (int)byte_off, 0, 0, 0);
-    };
-    auto glds_part = [&](int k0, int bufa, int bufb, bool doA, bool doB) {     // doA / doB: compile-time constants at every call site
-        __bf16* As = As0 + bufa * BM * LD;
-        __bf16* Bs = Bs0 + bufb * BN * LD;
-        const int k = k0 + kq * 8;
-        const bool kok = k < g.K;
-        const bool live = k0 < g.K;                      // wave-uniform
-        const unsigned kc = (unsigned)min(k, Klast);
-#ifdef NT16_EXP_NO_A
-        if (k0 >= 3 * BK) goto b_only;
-#endif
-        if (!doA) {
-        } else if (ACONV) {
             int t_ky = a_ct.ky, t_kx = a_ct.kx, t_ci = a_ct.ci;
             if (BK == 64 && g.n_ktab > 0) {
                 const unsigned e = g.ktab[min(k0 >> 6, g.n_ktab - 1)];
@@ -284,26 +212,9 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
 #pragma unroll
             for (int i = 0; i < NA; ++i) glds16(rsA, (a_ok[i] && kok) ? (a_base[i] + kc) * 2u : BUF_OOB, As, i);
         }
-#ifdef NT16_EXP_NO_A
-    b_only:
-#endif
-#ifdef NT16_EXP_NO_B      // experiment: the weight tile is fetched for the first K tiles only (wrong results; what do the B loads cost?)
-        if (k0 >= 3 * BK) return;
-#endif
-        if (!doB) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) glds16(rsB, (b_ok[i] && kok) ? (b_base[i] + kc) * 2u : BUF_OOB, Bs, i);
     };
-    auto glds_tiles = [&](int k0, int buf) { glds_part(k0, buf, buf, true, true); };
-    auto store_tiles = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
-        __bf16* As = As0 + buf * BM * LD;
-        __bf16* Bs = Bs0 + buf * BN * LD;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[(tid / KQ + i * RPI) * LD + kqs * 8]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[(tid / KQ + i * RPI) * LD + kqs * 8]) = rb[i];
-    };
-
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -311,34 +222,11 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (g.K + BK - 1) / BK;
-    auto mfma_tile2 = [&](int bufa, int bufb) {
-        const __bf16* As = As0 + bufa * BM * LD;
-        const __bf16* Bs = Bs0 + bufb * BN * LD;
+    auto mfma_tile = [&](int buf) {
+        const __bf16* As = As0 + buf * BM * LD;
+        const __bf16* Bs = Bs0 + buf * BN * LD;
         const int arow = wm * WM + (lane & 15), brow = wn * WN + (lane & 15);
-        const int sw = SWZ ? nt16_swz<BK>(lane & 15) : 0;       // the fragment rows differ from lane & 15 by multiples of 16
-#if NT16_FRAG_AHEAD
-        // every fragment of the K tile is requested before the first MFMA (16 ds_read_b128 at BK 64: 64 VGPRs): with one register set the
-        // second 32-deep slice's reads could only be issued once the first slice's MFMAs had consumed theirs, and each slice paid its
-        // own LDS latency (stamps: 927 cycles per K tile for 512 cycles of MFMA)
-        bf16x8 af[BK / 32][TM], bfr[BK / 32][TN];
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            const int kg = ((ks * 4 + (lane >> 4)) ^ sw) * 8;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(&As[(arow + i * 16) * LD + kg]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + j * 16) * LD + kg]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8 * (BK / 32), 0);
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 * (BK / 32), 0);
-#else
+        const int sw = nt16_swz<BK>(lane & 15);                 // the fragment rows differ from lane & 15 by multiples of 16
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
@@ -353,34 +241,8 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-#endif
     };
-    auto mfma_tile = [&](int buf) { mfma_tile2(buf, buf); };
-    if constexpr (A3B2) {
-        // K tile 64: the gathered / streamed A tile is what the wait before the barrier was exposed to (with both operand fetches
-        // removed conv_1 forward ran 0.147 ms, with only A's removed 0.169, only B's 0.207, both present 0.222): A gets a third buffer and
-        // is fetched TWO tiles ahead, the L2-hot weight tile B stays double-buffered one tile ahead.  B(kt+1) is issued BEFORE A(kt+2), so
-        // the counted wait (all but the NA youngest) retires A(kt+1) and B(kt+1) and leaves A(kt+2) in flight across the barrier.
-        glds_part(0, 0, 0, true, false);
-        glds_part(0, 0, 0, false, true);
-        glds_part(BK, 1, 0, true, false);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int acur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int anext2 = acur == 0 ? 2 : acur - 1;       // (kt + 2) % 3
-            glds_part((kt + 1) * BK, 0, (kt + 1) & 1, false, true);
-            glds_part((kt + 2) * BK, anext2, 0, true, false);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_tile2(acur, kt & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-            __builtin_amdgcn_s_barrier();
-            acur = acur == 2 ? 0 : acur + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue re-uses the operand buffers
-        __syncthreads();
-    } else if constexpr (GL && NBUF == 3) {
+    if constexpr (NBUF == 3) {
         // ring of three: tile kt+2 is issued before the MFMAs of tile kt; the wait before the (raw) barrier only retires tile kt+1's
         // NA + NB loads -- tile kt+2 stays in flight across it (a __syncthreads() would drain it: it waits vmcnt(0) with LDS-DMA pending).
         // Buffer (kt+2) % 3 was last read in step kt-1, behind that step's barrier.
@@ -389,81 +251,30 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
         __builtin_amdgcn_s_barrier();
         int bcur = 0;
-#ifdef NT16_STAMP
-        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
-#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int bnext2 = bcur == 0 ? 2 : bcur - 1;       // (kt + 2) % 3
-            NT16_T(t0);
             glds_tiles((kt + 2) * BK, bnext2);
             __builtin_amdgcn_sched_barrier(0);
-            NT16_T(t1);
             mfma_tile(bcur);
             __builtin_amdgcn_sched_barrier(0);
-            NT16_T(t2);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
-            NT16_T(t3);
             __builtin_amdgcn_s_barrier();
-            NT16_T(t4);
-#ifdef NT16_STAMP
-            st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_d += t4 - t3;
-#endif
             bcur = bcur == 2 ? 0 : bcur + 1;
         }
-#ifdef NT16_STAMP
-        if (lane == 0) {
-            atomicAdd(&g_nt16_st[0], st_a); atomicAdd(&g_nt16_st[1], st_b); atomicAdd(&g_nt16_st[2], st_c); atomicAdd(&g_nt16_st[3], st_d);
-            atomicAdd(&g_nt16_st[4], (unsigned long long)nk);
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue re-uses the operand buffers
         __syncthreads();
-    } else if constexpr (GL) {
+    } else {
         glds_tiles(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#ifdef NT16_STAMP
-        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
-#endif
         for (int kt = 0; kt < nk; ++kt) {
-            NT16_T(t0);
             glds_tiles((kt + 1) * BK, (kt + 1) & 1);     // the other buffer: last read one iteration ago, behind the previous barrier
             __builtin_amdgcn_sched_barrier(0);
-            NT16_T(t1);
             mfma_tile(kt & 1);
             __builtin_amdgcn_sched_barrier(0);
-            NT16_T(t2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            NT16_T(t3);
-            __syncthreads();
-            NT16_T(t4);
-#ifdef NT16_STAMP
-            st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_d += t4 - t3;
-#endif
-        }
-#ifdef NT16_STAMP
-        if (lane == 0) {
-            atomicAdd(&g_nt16_st[0], st_a); atomicAdd(&g_nt16_st[1], st_b); atomicAdd(&g_nt16_st[2], st_c); atomicAdd(&g_nt16_st[3], st_d);
-            atomicAdd(&g_nt16_st[4], (unsigned long long)nk);
-        }
-#endif
-    } else {
-    load_tiles(0, ra, rb);
-    store_tiles(0, ra, rb);
-    __syncthreads();
-    // (a second register set with the tile after next in flight -- wait vmcnt(8) instead of vmcnt(0) before the LDS writes -- was
-    //  measured: nothing for a lone workgroup, spills at 3 workgroups per CU.  The K step is bound by its LDS read -> MFMA -> LDS write
-    //  sequence, not by the global-load latency.)
-    {
-        for (int kt = 0; kt < nk; ++kt) {
-            load_tiles((kt + 1) * BK, ra, rb);
-            __builtin_amdgcn_sched_barrier(0);      // loads issued here; nothing that consumes them may move above the MFMAs
-            mfma_tile(kt & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles((kt + 1) & 1, ra, rb);      // the other buffer: last read one iteration ago, behind the previous barrier
             __syncthreads();
         }
-    }
     }
 
     // epilogue.  The accumulators go through LDS (the operand buffers are free now) so that everything that touches HBM is a
@@ -610,11 +421,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 h8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-#if NT16_NT_STORE & 1
-                __builtin_nontemporal_store(o, reinterpret_cast<h8*>(dst));
-#else
                 *reinterpret_cast<h8*>(dst) = o;
-#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -626,11 +433,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_nt16_kernel(GemmNT
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-#if NT16_NT_STORE & 2
-                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dst));
-#else
                 *reinterpret_cast<bf16x8*>(dst) = o;
-#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -766,17 +569,13 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
         const long long rows_out = g.use_cmap ? (long long)ceil_div(g.M, g.cmap.Hout * g.cmap.Wout) * g.cmap.Hc * g.cmap.Wc : (long long)g.M;
         if (rows_out * g.ldc >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
     }
-    // K tile: 64 (73.7 KB of LDS, 2 workgroups per CU) or 32 (41 KB, 3 per CU, the epilogue staged in two passes).  Measured: the
-    // long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out data gradient 0.099 vs 0.128 ms), the short-K
-    // ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148 ms).  SPAIR_NT16_BK=32|64 forces one.
-    static const int bk_env = [] { const char* e = getenv("SPAIR_NT16_BK"); return e ? atoi(e) : 0; }();
+    // K tile: 64 (two operand buffers, 73.7 KB of LDS with the epilogue staging tile, 2 workgroups per CU) or 32 (ring of three, 48 KB, 3 per
+    // CU, the epilogue staged in two passes).  Measured: the long-K launches are faster at 64 (conv_1 forward 0.263 vs 0.288 ms, decoder.out
+    // data gradient 0.099 vs 0.128 ms), the short-K ones, where the epilogue weighs most, at 32 (decoder.out forward, K = 256: 0.172 -> 0.148).
     if (g.n_ktab > 0 && (!conv || g.n_ktab > 64 || g.n_ktab * 64 != g.K || (g.conv.Cin & 63))) return SPAIR_ERR_SHAPE;
-    const int bk = g.n_ktab > 0 ? 64 : (bk_env == 32 || bk_env == 64) ? bk_env : (g.K >= 1024 ? 64 : 32);
-    static const int swz = [] { const char* e = getenv("SPAIR_NT16_SWZ"); return e ? atoi(e) : 1; }();      // 0: padded rows (A/B timing)
-    static const int glds = [] { const char* e = getenv("SPAIR_NT16_GLDS"); return e ? atoi(e) : 1; }();    // 0: operands staged through registers
-    const int nbuf = (swz && glds && (bk == 32 || NT16_RING64)) ? 3 : 2;
-    const int nbuf_a = (swz && glds && bk == 64 && nbuf == 2 && NT16_A3B2) ? 3 : nbuf;
-    size_t lds = std::max((size_t)(nbuf_a + nbuf) * 128 * (bk + (swz ? 0 : 8)) * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
+    const int bk = (g.n_ktab > 0 || g.K >= 1024) ? 64 : 32;
+    const int nbuf = bk == 32 ? 3 : 2;
+    size_t lds = std::max((size_t)(2 * nbuf) * 128 * bk * 2, (size_t)(bk == 32 ? 64 : 128) * (128 + 4) * 4);   // operands | epilogue staging
     if (g.stem_part) lds = std::max(lds, (size_t)128 * (128 + 8 + 32 + 8) * 2);      // gated tile + patches, bf16
     if (g.nz > 1 && (g.nz > 4 || !g.use_cmap || g.nz != g.cmap.osy * g.cmap.osx)) return SPAIR_ERR_SHAPE;
     dim3 grid(ceil_div(g.M, 128), ceil_div(g.N, 128), 1);
@@ -787,21 +586,15 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
         grid.x = (unsigned)(ceil_div(ceil_div(g.M, 128), 8) * 8 * g.xcd_tiles_n);
         grid.y = 1;
     }
-#define NT16_LAUNCH_SW(AC, C16, ST, BKV, SW, GLV)                                                               \
+#define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV, SW, GLV>),     \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV, SW, GLV>), grid, dim3(256), lds, s, g);            \
-    } while (0)
-#define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
-    do {                                                                                                          \
-        if (swz && glds) NT16_LAUNCH_SW(AC, C16, ST, BKV, true, true);                                            \
-        else if (swz) NT16_LAUNCH_SW(AC, C16, ST, BKV, true, false);                                              \
-        else NT16_LAUNCH_SW(AC, C16, ST, BKV, false, false);                                                      \
+        hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV>), grid, dim3(256), lds, s, g);                     \
     } while (0)
 #define NT16_LAUNCH(AC, C16, ST)                                                                                 \
     do { if (bk == 32) NT16_LAUNCH_BK(AC, C16, ST, 32); else NT16_LAUNCH_BK(AC, C16, ST, 64); } while (0)
@@ -815,7 +608,6 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     else { if (g.c_bf16) NT16_LAUNCH(false, true, false); else NT16_LAUNCH(false, false, false); }
 #undef NT16_LAUNCH
 #undef NT16_LAUNCH_BK
-#undef NT16_LAUNCH_SW
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

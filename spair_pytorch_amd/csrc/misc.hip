@@ -406,8 +406,7 @@ int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float*
     if (Cout % 4) return SPAIR_ERR_ALIGN;
     if (misc_conv0_reads_unpadded(B, Hin, C, k, Cout)) {
         if (s < 1 || s > 4) return SPAIR_ERR_UNSUPPORTED;
-        static const int no_mfma = [] { const char* e = getenv("SPAIR_CONV0_VALU"); return e ? atoi(e) : 0; }();     // 1: the FMA kernel (A/B timing)
-        if (out_bf16 && Cout == 128 && s == 2 && (Hin & 1) == 0 && !no_mfma) {
+        if (out_bf16 && Cout == 128 && s == 2 && (Hin & 1) == 0) {
             hipLaunchKernelGGL(k_conv0_fwd_c1k4_mfma, dim3((Hout + C0_ROWS - 1) / C0_ROWS, B), dim3(256), c0_mfma_xs_bytes(Hin) + 4 * 16 * C0_TP, st, x,
                                w, bias, reinterpret_cast<__bf16*>(out), Hin, Hout, I, pre);
             SPAIR_CHECK_LAUNCH();

@@ -186,12 +186,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(const float* __restrict__ S,
 // Workgroup -> sample mapping is XCD-aware: every object of sample b runs on XCD b%8, so the per-pixel aux map of a
 // sample (I*I*16 B) is only ever cached in one L2.
 // ---------------------------------------------------------------------------------------------
-#ifndef RB_WAVES
 #define RB_WAVES 4
-#endif
-#ifndef RB_CAP
 #define RB_CAP 1024
-#endif
 #define RB_T (64 * RB_WAVES)
 #define RB_TSH (RB_WAVES == 1 ? 6 : RB_WAVES == 2 ? 7 : RB_WAVES == 4 ? 8 : 9)
 __device__ __forceinline__ int rb_span(int T, float inv, int I) { return min((int)ceilf((float)(T + 1) * inv) + 3, I); }
@@ -440,18 +436,12 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                 const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
                 int ac, float obj_scale, float alpha_scale, hipStream_t s);
-// SPAIR_RENDER_V1=1 forces the first-generation kernels (A/B timing only)
-static bool render_force_v1() {
-    static const int v = getenv("SPAIR_RENDER_V1") ? atoi(getenv("SPAIR_RENDER_V1")) : 0;
-    return v != 0;
-}
-
 // s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type.  aux: B*I*I float2 (dBCE/dpre / D, pre).
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
                float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if (B <= 0 || HW <= 0 || I <= 0 || (ld_s & 1)) return SPAIR_ERR_SHAPE;
-    if (!render_force_v1()) {
+    {
         const int rc = render_fwd2(S, ld_s, nbox, pres, depth, ld_pd, x, recon, aux, bce_partial, B, HW, I, P, ac, s_bf16, s);
         if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
     }
@@ -470,7 +460,7 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
                int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if ((ld_s & 1) || (ld_g & 1)) return SPAIR_ERR_ALIGN;
-    if (g_bf16 && s_bf16 && !render_force_v1()) {   // the bf16 step: one wave per object, sampling transposed on the matrix cores
+    if (g_bf16 && s_bf16) {   // the bf16 step: one wave per object, sampling transposed on the matrix cores
         const int rc = render_bwd2(S, ld_s, nbox, pres, depth, ld_pd, aux, gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac,
                                    obj_scale, alpha_scale, s);
         if (rc != SPAIR_ERR_UNSUPPORTED) return rc;

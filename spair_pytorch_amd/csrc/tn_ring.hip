@@ -234,10 +234,8 @@ int spair_gemm_tn_ring(GemmTN g, bool conv, hipStream_t s) {
     if ((long long)grid.x * (TR_BM * BN + TR_BM) > g.part_cap) return SPAIR_ERR_UNSUPPORTED;
     g.colpart = g.part + (size_t)grid.x * TR_BM * BN;
     int rc;
-    static const int nst128 = [] { const char* e = getenv("SPAIR_TN_RING_NST"); return e ? atoi(e) : 3; }();
+    // ring of 3 stages (measured at BN = 128, where 4 and 5 fit: no change -- the stage time is set by the DMA issue rate, not its latency)
     if (BN == 256) rc = conv ? tr_launch<256, true, 3>(g, grid, s) : tr_launch<256, false, 3>(g, grid, s);
-    else if (nst128 == 5) rc = conv ? tr_launch<128, true, 5>(g, grid, s) : tr_launch<128, false, 5>(g, grid, s);
-    else if (nst128 == 4) rc = conv ? tr_launch<128, true, 4>(g, grid, s) : tr_launch<128, false, 4>(g, grid, s);
     else rc = conv ? tr_launch<128, true, 3>(g, grid, s) : tr_launch<128, false, 3>(g, grid, s);
     if (rc != SPAIR_OK) return rc;
     return spair_tn_reduce(g, TR_BM, BN, s);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The bf16 GEMMs of BASELINE config 2 through their C-ABI entry points, one line per shape (GPU box only; developer tool).
-Environment switches of the library (SPAIR_NT16_SWZ, SPAIR_NT16_BK, ...) apply: run twice to A/B."""
+(The SPAIR_NT16_* A/B switches live in tools/exp/patches/gemm16_switches.patch.)"""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

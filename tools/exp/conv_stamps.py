@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-K-step timing of the patch-resident conv kernel's consumer and loader waves (build: tools/build_variant.sh cp_stamp conv_s2.hip
+"""[needs `git apply tools/exp/patches/conv_s2_switches.patch` first: the hooks are not in the product source]
+Diagnostic: per-K-step timing of the patch-resident conv kernel's consumer and loader waves (build: tools/build_variant.sh cp_stamp conv_s2.hip
 -DCP_STAMP; run with SPAIR_HIP_LIB=build/libspair_cp_stamp.so).  Stamps per step: arrival at the barrier | barrier exit | (loaders) issue done."""
 import ctypes, os, sys, runpy
 import numpy as np, torch

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: where a stage-3 slot of the fused decoder forward spends its cycles (build: tools/build_variant.sh df_stamp dec_fused.hip -DDF_STAMP;
+"""[needs `git apply tools/exp/patches/dec_fused_switches.patch` first: the hooks are not in the product source]
+Diagnostic: where a stage-3 slot of the fused decoder forward spends its cycles (build: tools/build_variant.sh df_stamp dec_fused.hip -DDF_STAMP;
 run with SPAIR_HIP_LIB=build/libspair_df_stamp.so).  Stamps per slot: top | after the counted wait | after the barrier."""
 import ctypes, os, sys, runpy
 import numpy as np, torch

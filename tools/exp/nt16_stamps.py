@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""K-loop phase cycles of gemm_nt16 (diagnostic build: tools/build_variant.sh nt16st gemm16.hip -DNT16_STAMP, SPAIR_HIP_LIB=build/libspair_nt16st.so)."""
+"""[needs `git apply tools/exp/patches/gemm16_switches.patch` first: the hooks are not in the product source]
+K-loop phase cycles of gemm_nt16 (diagnostic build: tools/build_variant.sh nt16st gemm16.hip -DNT16_STAMP, SPAIR_HIP_LIB=build/libspair_nt16st.so)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

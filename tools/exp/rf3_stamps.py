@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Forward renderer: cycles a strip's wave spends issuing sprite DMA, waiting for it, compositing.
+"""[needs `git apply tools/exp/patches/render2_switches.patch` first: the hooks are not in the product source]
+Forward renderer: cycles a strip's wave spends issuing sprite DMA, waiting for it, compositing.
 Needs the diagnostic build: tools/build_variant.sh rfst render2.hip -DRF3_STAMP; SPAIR_HIP_LIB=build/libspair_rfst.so python tools/exp/rf3_stamps.py"""
 import ctypes, os, sys
 import numpy as np, torch

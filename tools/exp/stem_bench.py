@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The stem conv alone at BASELINE configs[1] (B=256, 128 -> 142 padded -> 70): bf16 (matrix cores) vs SPAIR_CONV0_VALU=1 (FMA kernel)."""
+"""The stem conv alone at BASELINE configs[1] (B=256, 128 -> 142 padded -> 70): bf16 (matrix cores) (the SPAIR_CONV0_VALU switch that forced the FMA kernel was removed in round 3)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
