@@ -7,9 +7,11 @@
 //     and of B (BN = 128 or 256 columns), a ring of 3 stages (96 / 144 KB of LDS, one workgroup per CU);
 //   * 4 COMPUTING waves (2 x 2, 64 x BN/2 outputs each) read transposed fragments (ds_read_b64_tr_b16) and run 32 / 64 MFMAs per stage
 //     behind ONE workgroup barrier.
-// Stage layout: [64-column group][64 rows][128 B]; the eight 16-byte chunks of a row segment are stored pair-swizzled, pair ^ (row & 3), applied
-// on the SOURCE side of the DMA (its LDS side is always wave base + lane * 16), so the 16 rows x 32 B of a transposing read fall on all four
-// 32-byte bank groups: 4 LDS cycles per read, the minimum.  Rows past the split's end and columns past the operand's extent are requested out
+// Stage layout: [64-column group][64 rows][128 B]; the eight 16-byte chunks of a row segment are stored pair-swizzled, pair ^ key(row) with
+// key(row) = (row & 3) ^ ((row >> 3) & 1), applied on the SOURCE side of the DMA (its LDS side is always wave base + lane * 16).  A transposing
+// read (ds_read_b64_tr_b16) is served in two groups of 32 lanes, each 8 rows {r, r+1, r+2, r+3, r+8, ..., r+11} x 32 B against 64 banks of 4 B:
+// with the key the eight 32-byte pieces fall on eight different bank groups (2 LDS cycles per read, the minimum).  With pair ^ (row & 3) alone
+// rows r and r + 8 shared their banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 (profiles/r03_b_sq_counters.txt).  Rows past the split's end and columns past the operand's extent are requested out
 // of range of the buffer descriptor: the DMA writes zeros.
 // Output: the fp32 partial tile of this split (+ the column sums of A = the bias gradient, taken with one extra MFMA against a fragment of
 // ones), summed over the splits in a fixed order by k_tn_reduce (gemm.hip) -- no atomics, gradients repeat bit for bit.
@@ -69,21 +71,25 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
         // ------------------------------------------------------------ loader waves: rows 16 lw + 8 i + (lane >> 3), i = 0, 1, of every group
         const int lw = wave - 4;
         const int rsub = lane >> 3, pos = lane & 7;
-        const int c = pos ^ ((rsub & 3) << 1);       // the source chunk this lane fetches in every piece (row & 3 == rsub & 3 for all its rows)
+        // the source chunk this lane fetches in the pieces of its row i: its rows are 16 lw + 8 i + rsub, so key = (rsub & 3) ^ i
         const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(gA), rsB = buf_rsrc(gB);
-        unsigned a_col[2], b_col[NGB];
-        bool a_ok[2], b_ok[NGB];
+        unsigned a_col[2][2], b_col[2][NGB];
+        bool a_ok[2][2], b_ok[2][NGB];
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) { const int m = m0 + gi * 64 + c * 8; a_ok[gi] = m < g_M; a_col[gi] = (unsigned)m; }
+        for (int i = 0; i < 2; ++i) {
+            const int c = pos ^ ((((rsub & 3) ^ i) & 3) << 1);
 #pragma unroll
-        for (int gi = 0; gi < NGB; ++gi) {
-            const int n = n0 + gi * 64 + c * 8;
-            b_ok[gi] = n < g_N;
-            if (BCONV) {      // n = tap * Cin + ci -> offset of that tap's pixel and channel from the output pixel's first input element
-                const int nn = min(n, g_N - 8), tap = nn / g.conv.Cin, ci = nn - tap * g.conv.Cin, ky = tap / g.conv.kw, kx = tap - ky * g.conv.kw;
-                b_col[gi] = (unsigned)((ky * g.conv.dky * g.conv.Win + kx * g.conv.dkx) * g.conv.Cin + ci);
-            } else {
-                b_col[gi] = (unsigned)n;
+            for (int gi = 0; gi < 2; ++gi) { const int m = m0 + gi * 64 + c * 8; a_ok[i][gi] = m < g_M; a_col[i][gi] = (unsigned)m; }
+#pragma unroll
+            for (int gi = 0; gi < NGB; ++gi) {
+                const int n = n0 + gi * 64 + c * 8;
+                b_ok[i][gi] = n < g_N;
+                if (BCONV) {      // n = tap * Cin + ci -> offset of that tap's pixel and channel from the output pixel's first input element
+                    const int nn = min(n, g_N - 8), tap = nn / g.conv.Cin, ci = nn - tap * g.conv.Cin, ky = tap / g.conv.kw, kx = tap - ky * g.conv.kw;
+                    b_col[i][gi] = (unsigned)((ky * g.conv.dky * g.conv.Win + kx * g.conv.dkx) * g.conv.Cin + ci);
+                } else {
+                    b_col[i][gi] = (unsigned)n;
+                }
             }
         }
         const int HW = BCONV ? g.conv.Hout * g.conv.Wout : 1;
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
                     rb = (unsigned)row * (unsigned)g_ldb;
                 }
 #pragma unroll
-                for (int gi = 0; gi < 2; ++gi) glds(rsA, (rok & a_ok[gi]) ? (ra + a_col[gi]) * 2u : BUF_OOB, sb + gi * TR_GRP_B + rl * 128);
+                for (int gi = 0; gi < 2; ++gi) glds(rsA, (rok & a_ok[i][gi]) ? (ra + a_col[i][gi]) * 2u : BUF_OOB, sb + gi * TR_GRP_B + rl * 128);
 #pragma unroll
                 for (int gi = 0; gi < NGB; ++gi)
-                    glds(rsB, (rok & b_ok[gi]) ? (rb + b_col[gi]) * 2u : BUF_OOB, sb + (2 + gi) * TR_GRP_B + rl * 128);
+                    glds(rsB, (rok & b_ok[i][gi]) ? (rb + b_col[i][gi]) * 2u : BUF_OOB, sb + (2 + gi) * TR_GRP_B + rl * 128);
             }
         };
 #pragma unroll
@@ -133,9 +139,9 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int rowoff = (8 * g4 + q) * 128 + (p << 3);
-    int poff[4];                                     // pair j of a group sits at pair position j ^ (row & 3) = j ^ q
+    int poff[4];                                     // pair j of a group sits at pair position j ^ key(row); the lane's rows 8 g4 + q (+ 4, + 32): key = q ^ (g4 & 1)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) poff[j] = rowoff + ((j ^ q) << 5);
+    for (int j = 0; j < 4; ++j) poff[j] = rowoff + ((j ^ q ^ (g4 & 1)) << 5);
     const int a_base = wm * TR_GRP_B;                              // the wave's 64 rows of C = one group of A
     const int b_base = (2 + wn * (NGB / 2)) * TR_GRP_B;            // its BN / 2 columns = NGB / 2 groups of B
     const bool do_colsum = g_colsum != nullptr && (grouped || nt_ == 0) && wn == 0;

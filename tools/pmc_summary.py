@@ -6,10 +6,23 @@ import collections
 import sys
 
 
+def short_name(full):
+    """k_name<template args> without return type, namespace or the parameter list ("void (anonymous namespace)::k_x<1, 2>(Args)")."""
+    n = full.replace("(anonymous namespace)::", "").replace("void ", "")
+    depth, out = 0, []
+    for ch in n:
+        if ch == "<": depth += 1
+        if ch == "(" and depth == 0: break
+        if ch == ">": depth -= 1
+        out.append(ch)
+    return "".join(out).strip()
+
+
+
 def load(path):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = short_name(r["Kernel_Name"])
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     return acc

@@ -7,13 +7,26 @@ import csv
 import glob
 import sys
 
+
+def short_name(full):
+    """k_name<template args> without return type, namespace or the parameter list ("void (anonymous namespace)::k_x<1, 2>(Args)")."""
+    n = full.replace("(anonymous namespace)::", "").replace("void ", "")
+    depth, out = 0, []
+    for ch in n:
+        if ch == "<": depth += 1
+        if ch == "(" and depth == 0: break
+        if ch == ">": depth -= 1
+        out.append(ch)
+    return "".join(out).strip()
+
+
 data = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            n = short_name(r["Kernel_Name"])
             data[n + " grid=" + r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("nt16", "tn16", "chain", "render", "pw_stack", "conv0", "count_kl", "k_dec", "k_conv")
+keep = ("nt16", "tn16", "tn_ring", "chain", "render", "pw_stack", "conv0", "count_kl", "k_dec", "k_conv")
 print("%-58s %9s %9s %9s %9s %9s %9s %9s" % ("kernel", "mfma_util", "lds_busy", "bank_conf", "wait_any", "wait_inst", "issue", "valu"))
 for k in sorted(data):
     if not any(t in k for t in keep):
