@@ -19,10 +19,14 @@ namespace {
 
 constexpr int MT = 16;                    // rows per wavefront tile
 constexpr int F = 100, REC = 56, CTX = 224, A_ = 50, NP = 100, GLN = 784, PG = 28;    // PG: glimpse side (chain_fwd_supported requires P == 28)
-constexpr int KC = 352, LD_XC = KC + 8;   // [feat | ctx] padded to 11 k-steps
-constexpr int KX = 160, LD_XT = KX + 8;   // [pass | box | attr | depth] padded to 5 k-steps
-constexpr int KG = 800, LD_GL = KG + 8;   // glimpse padded to 25 k-steps
-constexpr int LD_H = 256 + 8;
+// LDS row pitches of the MFMA A operands: K + 16 elements, i.e. a multiple of 64 B plus 32.  ds_read_b128 serves a wave in four groups of 16
+// lanes (rows {0-3, 12-15} of one k-chunk with rows {4-11} of the next) against 64 banks: with the usual K + 8 (pitch = 16 mod 64 B) two rows of
+// every group share a bank quad and each fragment read takes 8 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.47 fwd, 0.35 bwd).
+constexpr int CH_PAD = 16;                // (same box, same run: K + 8 -> K + 16 = chain fwd 0.833 -> 0.820 ms, bwd 0.865 -> 0.852)
+constexpr int KC = 352, LD_XC = KC + CH_PAD;  // [feat | ctx] padded to 11 k-steps
+constexpr int KX = 160, LD_XT = KX + CH_PAD;  // [pass | box | attr | depth] padded to 5 k-steps
+constexpr int KG = 800, LD_GL = KG + CH_PAD;  // glimpse padded to 25 k-steps
+constexpr int LD_H = 256 + CH_PAD;
 constexpr int LD_O = 112;
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains every outstanding global access (s_waitcnt vmcnt(0)):

@@ -19,7 +19,7 @@
 namespace {
 
 typedef unsigned short u16;
-constexpr int PW_BM = 128, PW_N = 128, PW_LD = PW_N + 8, PW_MAXL = 4;
+constexpr int PW_BM = 128, PW_N = 128, PW_LD = PW_N + 16, PW_MAXL = 4;      // pitch 288 B = 32 mod 64: conflict-free ds_read_b128 fragments (K + 8: 2-way)
 
 struct PwArgs {
     const void* X; int ldx, kx;            // first input: bf16 [M][ldx], kx valid columns (<= 128)

@@ -333,7 +333,8 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 // The adjoints and the hat weights are rounded to bf16 for the matrix products (the d-logits are stored as bf16 anyway);
 // z_where gradients are fp32 throughout (pass A), pres / depth gradients come from the texel sums of the products.
 // ---------------------------------------------------------------------------------------------
-#define RB2_ADJ_LD 40                      // bf16 elements per adjoint tile row (80 B: conflict-free ds_read_b128 fragments)
+#define RB2_ADJ_LD 40                      // bf16 elements per adjoint tile row (80 B; 96 B would make the ds_read_b128 fragments conflict-free on
+                                           // gfx950's 16-lane groups but costs a wave of occupancy: measured equal, 0.252 vs 0.252 ms; 112 B: 0.267)
 #define RB2_ROWS 16                        // pixel rows per chunk
 #define RB2_WAVES_PER_SIMD 4            // register budget: 128 (VGPR + AGPR)
 #define RB2_BIG 1.0e9f                      // source coordinate of a padding pixel: every hat weight 0
