@@ -1123,11 +1123,21 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         const LinSpec &l2 = PL.lin[LIN_DEC2], &l1 = PL.lin[LIN_DEC1], &l0 = PL.lin[LIN_DEC0];
         {
             ProfScope ps(PS_DECODER_BWD, c.s);
+            // all three data gradients in one launch (dec_fused_bwd.hip); flags bit 6 / an unsupported shape: three implicit-GEMM launches
+            int rc_f = SPAIR_ERR_UNSUPPORTED;
+            if (!(st->flags & 64)) {
+                ProfScope p2(PS_DEC2_DGRAD, c.s);
+                rc_f = dec_fused_bwd(c.w.dLog, c.w.ld_s, c.w.lin_wt[LIN_DEC2], round_up(per, 8), c.w.lin_wt[LIN_DEC1], c.w.lin_wt[LIN_DEC0], c.w.Hd2,
+                                     c.w.Hd1, c.w.dHd2, c.w.dHd1, P.g_attr_r, L.ld_rec, N, l0.in, per, c.s);
+                if (rc_f != SPAIR_OK && rc_f != SPAIR_ERR_UNSUPPORTED) return rc_f;
+            }
+            if (rc_f == SPAIR_ERR_UNSUPPORTED) {
             { ProfScope p2(PS_DEC2_DGRAD, c.s);
               TRY(nt16(c, c.w.dLog, c.w.ld_s, c.w.lin_wt[LIN_DEC2], round_up(per, 8), c.w.dHd2, SP_DEC_H2, 1, N, SP_DEC_H2, round_up(per, 8), nullptr,
                        c.w.Hd2, SP_DEC_H2, 0)); }
             TRY(nt16(c, c.w.dHd2, SP_DEC_H2, c.w.lin_wt[LIN_DEC1], SP_DEC_H2, c.w.dHd1, SP_DEC_H1, 1, N, SP_DEC_H1, SP_DEC_H2, nullptr, c.w.Hd1, SP_DEC_H1, 0));
             TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
+            }
         }
         if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; c.tn_scratch = c.w.tn_part2; }
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }

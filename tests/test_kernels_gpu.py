@@ -179,6 +179,41 @@ def test_stem_conv_mfma_vs_torch(B, I, pre, post):
 
 
 @pytest.mark.parametrize("N", [72, 1000, 8192])
+def test_decoder_fused_bwd_vs_torch(N):
+    """dec_fused_bwd.hip (the bf16 step's decoder data-gradient chain d-logits -> dH2 -> dH1 -> d z_attr as ONE kernel, backward of
+    models.py:474-492) through its C-ABI entry point against torch fp32 on the same bf16 operands, layer by layer on the kernel's own
+    stored input of that layer.  N = 72 / 1000: partial 128-row blocks; K = 1568 is not a multiple of the 64-deep stage."""
+    import ctypes
+    L = _L()
+    A, LDR, H1, H2, NO = 50, 56, 128, 256, 1568
+    g = torch.Generator().manual_seed(N + 1)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    dL = rb(torch.randn(N, NO, generator=g) * 0.05)
+    W0, W1, W2 = torch.randn(H1, A, generator=g) * 0.2, torch.randn(H2, H1, generator=g) * 0.1, torch.randn(NO, H2, generator=g) * 0.08
+    h1 = rb(torch.relu(torch.randn(N, H1, generator=g)))            # stored forward activations: the relu gates
+    h2 = rb(torch.relu(torch.randn(N, H2, generator=g)))
+    dv = dict(dL=dL.to(torch.bfloat16).cuda(), W2t=W2.t().contiguous().to(torch.bfloat16).cuda(), W1t=W1.t().contiguous().to(torch.bfloat16).cuda(),
+              W0t=W0.t().contiguous().to(torch.bfloat16).cuda(), H2=h2.to(torch.bfloat16).cuda(), H1=h1.to(torch.bfloat16).cuda())
+    dH2 = torch.full((N + 1, H2), -7.0, dtype=torch.bfloat16, device="cuda")
+    dH1 = torch.full((N + 1, H1), -7.0, dtype=torch.bfloat16, device="cuda")
+    dza = torch.full((N + 1, LDR), -7.0, device="cuda")
+    L.check(L.lib().spair_decoder_bwd16(L.ptr(dv["dL"]), NO, L.ptr(dv["W2t"]), NO, L.ptr(dv["W1t"]), L.ptr(dv["W0t"]), L.ptr(dv["H2"]), L.ptr(dv["H1"]),
+                                        L.ptr(dH2), L.ptr(dH1), L.ptr(dza), LDR, ctypes.c_longlong(N), A, NO, L.stream()), "decoder bwd16")
+    torch.cuda.synchronize()
+    assert (dH2[N] == -7.0).all().item() and (dH1[N] == -7.0).all().item() and (dza[N] == -7.0).all().item()      # nothing past the last row
+    assert (dza[:N, A:] == -7.0).all().item()                                                                       # ... or past the A columns
+    g2, g1, gz = dH2[:N].float().cpu(), dH1[:N].float().cpu(), dza[:N, :A].cpu()
+    want2 = (dL @ rb(W2)) * (h2 > 0)
+    want1 = (g2 @ rb(W1)) * (h1 > 0)
+    wantz = g1 @ rb(W0)
+    for got, want, name in ((g2, want2, "dH2"), (g1, want1, "dH1")):
+        d = (got - want).abs()
+        assert (d <= 0.0079 * want.abs() + 2e-6 * want.abs().max()).all().item(), (name, float(d.max()))      # one bf16 step of the fp32 sum
+        assert ((got == 0) == (want == 0)).float().mean().item() > 0.999, name                                 # the gate
+    assert (gz - wantz).abs().max().item() <= 2e-5 * wantz.abs().max().item() + 1e-6                         # fp32 output: summation order only
+
+
+@pytest.mark.parametrize("N", [72, 1000, 8192])
 def test_decoder_fused_fwd_vs_torch(N):
     """dec_fused.hip (the bf16 step's decoder forward, models.py:474-492, as ONE activation-stationary kernel) through its C-ABI entry
     point against torch fp32 on the same bf16-rounded weights: the stored hidden activations (what the weight gradients / relu gates
