@@ -2,7 +2,7 @@
 developer tool).  DB_NO=<n_out> shortens the first layer's K: with 64 / 512 / 1568 logits the launch takes 0.040 / 0.054 / 0.101 ms, i.e. ~20 us per
 workgroup round of fixed cost (epilogues: gate loads, dH2 / dH1 / d z_attr stores, layers 1 and 0) + 1.27 us per 64-deep stage."""
 import ctypes, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spair_pytorch_amd import _lib as L
 lib = L.lib(); bf = torch.bfloat16
 N, A, LDR, NO = 65536, 50, 56, int(os.environ.get("DB_NO", "1568"))
