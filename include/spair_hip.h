@@ -53,7 +53,8 @@ typedef struct SpairStep {
                                 * bit 2: no helper stream (every kernel on the caller's stream);
                                 * bit 3: stem weight gradient as its own kernel (not fused into conv_1's data gradient);
                                 * bit 4: decoder forward as three GEMM launches instead of the fused activation-stationary kernel;
-                                * bit 5: strided backbone convs through the implicit-GEMM kernel instead of the patch-resident one */
+                                * bit 5: strided backbone convs through the implicit-GEMM kernel instead of the patch-resident one;
+                                * bit 6: decoder data gradients as three GEMM launches instead of the fused kernel */
     int draw_noise;            /* spair_forward only: 1 = fill eps_box/eps_attr/eps_depth/u_pres from noise_seed first (what spair_noise_fill
                                 * does, but on the helper stream beside the backbone); the buffers must be writable */
     unsigned long long noise_seed;
@@ -208,6 +209,12 @@ int64_t spair_decoder_fwd16_scratch_bytes(int n_out);
 int spair_decoder_fwd16(const void* z_attr16, int ld_za, const float* W0, const float* b0, const float* W1, const float* b1,
                         const float* W2, const float* b2, void* H1, void* H2, void* sprites, int ld_s, long long N, int A, int n_out,
                         float obj_scale, float alpha_scale, float alpha_bias, void* stream_buf, void* stream);
+/* The decoder's DATA-GRADIENT chain (autograd of the three Linear layers of models.py:474-484 w.r.t. their inputs; csrc/dec_fused_bwd.hip) in one
+ * launch.  dlogits16: bf16 [N][ld_s] (n_out columns, the sigmoid's derivative already applied); W2t16 / W1t16 / W0t16: the TRANSPOSED weights as
+ * bf16, [256][ld2], [128][256], [A][128]; H2 / H1: the stored forward activations bf16 [N][256] / [N][128] (relu gates); outputs: dH2 / dH1 (bf16,
+ * same shapes) and d_z_attr fp32 [N][ld_dza] (A columns written).  A <= 64, n_out % 8 == 0. */
+int spair_decoder_bwd16(const void* dlogits16, int ld_s, const void* W2t16, int ld2, const void* W1t16, const void* W0t16, const void* H2,
+                        const void* H1, void* dH2, void* dH1, float* d_z_attr, int ld_dza, long long N, int A, int n_out, void* stream);
 /* the same with 16-bit sprites, as the bf16 training step runs them: sprites are FP16 (grey, alpha) pairs [N][ld_s] (post-sigmoid values
  * in (0,1): 11 significant bits), d-logits come back as BF16 [N][ld_s] */
 int spair_render_fwd16(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
