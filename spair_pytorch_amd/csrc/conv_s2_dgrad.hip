@@ -65,12 +65,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r16 = lane & 15;
     const int Ho = a.Ho, Hc = a.Hc, Wp = Ho + 2, Hp = Ho + 2;
-    const int m0 = blockIdx.x * DG_BM, mlast = min(m0 + DG_BM, a.M) - 1;
+    // PERSISTENT: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (a tile is short-lived -- 32 K steps -- against
+    // the 3-4 us a 160-KB workgroup takes to launch and fill its first patch; the loaders start the next tile's patch and weight tiles
+    // behind barrier(32), under the computing waves' last class epilogue)
+    const int ntiles = (a.M + DG_BM - 1) / DG_BM;
+    int m0 = 0, E0 = 0, npx = 0;
     // class pixel m = (b, y, x) on the Hc x Hc class grid; g = b * Hc + y.  d_out rows with a zero border: extended row E = b * Hp + yd + 1;
     // tap ty of class row g reads E = g + b + 1 - ty.  The tile needs E0 .. E1, every row Wp = Ho + 2 pixels (xd + 1 = x + 1 - tx).
-    const int g0 = m0 / Hc, g1 = mlast / Hc;
-    const int E0 = g0 + g0 / Hc, E1 = g1 + g1 / Hc + 1;
-    const int npx = (E1 - E0 + 1) * Wp;          // <= DG_PPX (checked by the launcher)
+    auto set_tile = [&](int tile) {
+        m0 = tile * DG_BM;
+        const int mlast = min(m0 + DG_BM, a.M) - 1;
+        const int g0 = m0 / Hc, g1 = mlast / Hc;
+        E0 = g0 + g0 / Hc;
+        npx = (g1 + g1 / Hc + 1 - E0 + 1) * Wp;  // <= DG_PPX (checked by the launcher)
+    };
     const bool loader = wave >= 4;
     const int lw = wave & 3;
 
@@ -102,6 +110,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                 glds(rin, ok ? off : BUF_OOB, piece < DG_PPX / 8 ? dst + piece * 1024 : dg_sm + DG_OFF_DUMP);
             }
         };
+#pragma unroll 1
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        set_tile(tile);
         issue_patch(0, 0, 8);                    // half 0: 32 pieces = 4 loaders x 8
         issue_b(0);
         issue_b(1);
@@ -121,9 +132,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             if (STEM && kt != 0 && (kt & 7) == 0) __builtin_amdgcn_s_barrier();      // barrier E of the class that ended with step kt - 1 (the
                                                                                      // computing waves run its epilogue behind barrier(kt))
         }
-        __builtin_amdgcn_s_barrier();            // barrier(32)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target this workgroup's LDS
-        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // E of the last class, X, Y
+        __builtin_amdgcn_s_barrier();            // barrier(32): every read of this tile's ring and patch is in registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target ring slots the next tile fills (and this workgroup's LDS)
+        if (STEM) __builtin_amdgcn_s_barrier();  // E of the tile's last class
+        }
+        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // X, Y
         return;
     }
 
@@ -137,15 +150,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     int pbase[4];                                // patch pixel of (pixel tile j, pixel r16) at tap (0, 0)
     unsigned orow[4];                            // its output pixel of class (0, 0)
     bool ook[4];
+    auto set_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + r16;
-        ook[j] = m < a.M;
-        const int mc = min(m, a.M - 1);
-        const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
-        pbase[j] = (g + b + 1 - E0) * Wp + x + 1;
-        orow[j] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
-    }
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + r16;
+            ook[j] = m < a.M;
+            const int mc = min(m, a.M - 1);
+            const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
+            pbase[j] = (g + b + 1 - E0) * Wp + x + 1;
+            orow[j] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
+        }
+    };
     // weight-tile rows of this lane: tile t of the wave's 64 channels, lane row m = r16
     const int wkey = (r16 & 3) | (((r16 >> 2) & 1) << 2);
     const int wrow0 = wn * 64 + (r16 >> 2) * 8 + (r16 & 3);          // + 32 (t >> 1) + 4 (t & 1)
@@ -181,6 +196,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
     };
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    set_tile(tile);
+    set_rows();
     __builtin_amdgcn_s_barrier();                // barrier(0): tile 0 and the first patch half have landed
     asm volatile("" ::: "memory");
     read_frags(0, 0, 0, 0, wfA, pfA);
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             // (the next class overwrites the tile / patches only behind its 8 K-step barriers)
         }
     }
+    }      // tiles
     if (STEM) {
         __builtin_amdgcn_s_barrier();            // X: every wave is done with the last class's stem product (reads of Gs)
         float* Ws = reinterpret_cast<float*>(Gs);            // [128 ch][17]
@@ -341,10 +361,16 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS) != hipSuccess) return SPAIR_ERR_LAUNCH;
         attr_set[stem] = true;
     }
-    if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(tiles), dim3(512), DG_LDS, s, a);
-    else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(tiles), dim3(512), DG_LDS, s, a);
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int grid = std::min(tiles, n_cu);      // persistent: one 160-KB workgroup per CU walks the tiles
+    if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(grid), dim3(512), DG_LDS, s, a);
+    else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(grid), dim3(512), DG_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
-    if (stem) return spair_stem_fused_reduce(stem_part, tiles, stem_dw, stem_db, s);
+    if (stem) return spair_stem_fused_reduce(stem_part, grid, stem_dw, stem_db, s);      // one [128][17] partial per workgroup
     return SPAIR_OK;
 }
 
