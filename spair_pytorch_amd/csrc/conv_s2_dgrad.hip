@@ -116,6 +116,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         issue_patch(0, 0, 8);                    // half 0: 32 pieces = 4 loaders x 8
         issue_b(0);
         issue_b(1);
+        // STEM: barrier E of the PREVIOUS tile's last class is joined here, behind the issue and in front of the wait -- the computing waves run
+        // that epilogue meanwhile and would otherwise sit at E until this tile's patch has landed
+        if (STEM && tile != (int)blockIdx.x) __builtin_amdgcn_s_barrier();
         dg_wait<4>();                            // everything but tile 1
 #pragma unroll 1
         for (int kt = 0; kt < 32; ++kt) {
@@ -134,9 +137,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         }
         __builtin_amdgcn_s_barrier();            // barrier(32): every read of this tile's ring and patch is in registers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail DMAs target ring slots the next tile fills (and this workgroup's LDS)
-        if (STEM) __builtin_amdgcn_s_barrier();  // E of the tile's last class
         }
-        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // X, Y
+        if (STEM) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // E of the last tile's last class, X, Y
         return;
     }
 
