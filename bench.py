@@ -179,7 +179,8 @@ def kernel_table(d, B, dtype, ms, cnt, n_sampled):
 
 def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
     """K4 = the glimpse stage of k_chain_fwd.  SpairStep.flags bit 1 makes sample 0's workgroup stamp s_memtime after every stage; the
-    stage's share of the stamped cycles x the kernel's event time = its duration (clock-free).  One extra, untimed step."""
+    stage's share of the stamped cycles x the kernel's event time = its duration (clock-free).  One extra, untimed FORWARD pass (step_fn must not
+    contain a collective: under torchrun only rank 0 gets here)."""
     if not chain_fwd_ms:
         return None
     from spair_pytorch_amd import _lib as L
@@ -299,7 +300,8 @@ def config3_record(dev, args, strides):
     lib.spair_prof_enable(0)
     d = model._last["engine"]["dims"]
     kernels, per_step = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, every)))
-    stn = stn_fwd_from_stamps(model, step, d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
+    # (rank 0 alone runs it, the other ranks have left: a forward pass only -- nothing collective)
+    stn = stn_fwd_from_stamps(model, lambda: model(x, gstep[0]), d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
     if stn:
         kernels["stn_fwd"] = stn
     keep = ("chain_fwd", "chain_bwd", "render_fwd", "render_bwd", "stn_fwd")
@@ -426,7 +428,8 @@ def main():
     kernels, per_step_ms = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, args.prof_every)))
     # K4 (the STN-forward gather is a stage of k_chain_fwd, not a launch): its share of the kernel from the in-kernel stage stamps of
     # one extra step outside the timed region
-    stn = stn_fwd_from_stamps(model, step, d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
+    # (rank 0 alone runs it, the other ranks have left: a forward pass only -- nothing collective)
+    stn = stn_fwd_from_stamps(model, lambda: model(x, gstep[0]), d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
     if stn:
         kernels["stn_fwd"] = stn
     attach_pmc_traffic(kernels, B, args.image, args.dtype)

@@ -88,3 +88,23 @@ def test_two_ranks_overlapped_allreduce_equals_global_batch(tmp_path, dtype, tol
         assert_adam_updates_close(r["params"], p, 1e-4, tight=1e-6)
     else:
         assert np.abs(r["params"] - p).max() <= 2.1e-4
+
+
+def test_bench_runs_under_torchrun_with_two_ranks():
+    """The driver's multi-GPU launch form of bench.py (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), rehearsed with
+    two ranks on the box's one GPU (SPAIR_DIST_BACKEND=gloo; a smaller batch keeps it to seconds): rank 0 must print ONE JSON line with the
+    whole-job throughput, and every rank must exit -- after the timed region rank 0 alone finishes the record (kernel table, the STN stage
+    stamps), so nothing there may contain a collective."""
+    import json
+    env = dict(os.environ, SPAIR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["global_batch"] == 64 and rec["value"] > 0 and np.isfinite(rec["elbo"])
+    assert abs(rec["value"] - 64 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]          # whole-job images/s = world * B * K / time
+    assert "stn_fwd" in rec["kernels"] and rec["roofline"]["kernel"].startswith("chain")
