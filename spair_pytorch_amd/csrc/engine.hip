@@ -1065,6 +1065,32 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     return spair_gemm_tn16_impl(g, false, true, c.s);      // A and B both bf16 rows
 }
 
+// The decoder's two small weight gradients (dense1: 256 x 128, dense0: 128 x A) as ONE grouped split-K launch + one reduce pass: as launches of
+// their own each took ~28 us + a ~20-35 us reduce for 4.3 / 1.7 GFLOP (prologue, partial tiles and launch latency, not work).
+static int decoder_small_wgrad_grouped(Ctx& c, float* grads, long long N) {
+    const LinSpec &l1 = c.PL.lin[LIN_DEC1], &l0 = c.PL.lin[LIN_DEC0];
+    GemmTN g;
+    memset(&g, 0, sizeof(g));
+    int nt = 0;
+    auto add = [&](const LinSpec& l, const void* dY, int ldo, const void* X, int ldi) {      // whole layers, outputs in tiles of 128 rows, in <= 128
+        for (int m0 = 0; m0 < l.out; m0 += 128) {
+            GemmTN::Tile& t = g.tile[nt++];
+            const int ms = std::min(128, l.out - m0);
+            t.A = reinterpret_cast<const __bf16*>(dY) + m0; t.lda = ldo; t.B = X; t.ldb = ldi;
+            t.C = grads + l.w + (size_t)m0 * l.in; t.ldc = l.in; t.colsum = grads + l.b + m0;
+            t.M = round_up(ms, 8); t.N = std::min(round_up(l.in, 8), ldi); t.Mstore = ms; t.Nstore = l.in; t.m_skip = 0; t.n_skip = 0;
+        }
+    };
+    if (l1.in > 128 || l0.in > 128 || (l1.out & 7) || (l0.out & 7) || ceil_div(l1.out, 128) + ceil_div(l0.out, 128) > SPAIR_TN_MAX_TILES)
+        return SPAIR_ERR_UNSUPPORTED;
+    add(l1, c.w.dHd2, SP_DEC_H2, c.w.Hd1, SP_DEC_H1);
+    add(l0, c.w.dHd1, SP_DEC_H1, c.w.Za16, c.L.ld_rec);
+    for (int q = 0; q < nt; ++q) if (g.tile[q].N < g.tile[q].Nstore) return SPAIR_ERR_UNSUPPORTED;
+    g.ngroup = nt; g.R = (int)N;
+    g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
+    return spair_gemm_tn16_impl(g, false, true, c.s);
+}
+
 // Gradient readiness: the backward finishes the three parameter groups in this order -- decoder, per-cell nets, then the backbone together
 // with the edge element -- and each group is one contiguous range of the flat gradient buffer (spair_grad_buckets).  ev[i] (a caller-created
 // hipEvent_t, or null) is recorded on whichever internal stream completes group i, so a data-parallel caller can start that range's
@@ -1141,8 +1167,13 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         }
         if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; c.tn_scratch = c.w.tn_part2; }
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
-        TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
-        TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
+        {
+            const int rc_g = decoder_small_wgrad_grouped(c, grads, N);
+            if (rc_g == SPAIR_ERR_UNSUPPORTED) {
+                TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
+                TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
+            } else if (rc_g != SPAIR_OK) return rc_g;
+        }
         TRY(record_ready(ev_decoder, c.s));
         if (side) { c.s = main_s; c.tn_scratch = nullptr; }
     } else {   // decoder

@@ -107,4 +107,4 @@ def test_bench_runs_under_torchrun_with_two_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["global_batch"] == 64 and rec["value"] > 0 and np.isfinite(rec["elbo"])
     assert abs(rec["value"] - 64 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]          # whole-job images/s = world * B * K / time
-    assert "stn_fwd" in rec["kernels"] and rec["roofline"]["kernel"].startswith("chain")
+    assert "stn_fwd" in rec["kernels"] and rec["roofline"]["kernel"] in rec["kernels"]
