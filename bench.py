@@ -300,8 +300,7 @@ def config3_record(dev, args, strides):
     lib.spair_prof_enable(0)
     d = model._last["engine"]["dims"]
     kernels, per_step = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, every)))
-    # (rank 0 alone runs it, the other ranks have left: a forward pass only -- nothing collective)
-    stn = stn_fwd_from_stamps(model, lambda: model(x, gstep[0]), d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
+    stn = stn_fwd_from_stamps(model, lambda: model(x, gs[0]), d, B, args.dtype, kernels.get("chain_fwd", {}).get("avg_ms"))
     if stn:
         kernels["stn_fwd"] = stn
     keep = ("chain_fwd", "chain_bwd", "render_fwd", "render_bwd", "stn_fwd")
