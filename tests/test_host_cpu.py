@@ -98,3 +98,19 @@ def test_no_cpu_fallback():
     m = SPAIR([1, 128, 128], None, torch.device("cpu"))
     with pytest.raises(L.SpairHipError):
         m(torch.zeros(2, 1, 128, 128), 0)
+
+
+def test_experiment_patches_apply_to_the_product_sources():
+    """tools/exp/patches/*.patch hold the measured-and-rejected variants and the stamp hooks that were moved out of the product kernels: they must
+    keep applying to the sources they refer to (the round-2 band renderer is against round 2's render2.hip and is exempt)."""
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) in this environment")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    patches = sorted(p for p in glob.glob(os.path.join(root, "tools", "exp", "patches", "*.patch")) if "render_fwd4_band" not in p)
+    assert len(patches) >= 6
+    for p in patches:
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-F0", "-i", p], cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(p), r.stdout[-800:])
