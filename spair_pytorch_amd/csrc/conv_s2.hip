@@ -24,7 +24,7 @@ constexpr int CP_PATCH_B = CP_PPX * 128;         // 50,176 B per patch buffer
 constexpr int CP_BT_B = 128 * 128;               // weight tile [128 n][64 k] bf16
 constexpr int CP_NPIECE_W = 5;                   // patch pieces per GB wave per C phase (3 phases x 4 waves x 5 >= 49)
 constexpr int CP_LDS = 3 * CP_BT_B + 2 * CP_PATCH_B + 1024;      // + 1 KiB that the surplus (out-of-range) patch pieces are pointed at
-constexpr int CP_LDC = CP_C + 8;                 // epilogue staging row (bf16 elements)
+constexpr int CP_LDC = CP_C + 16;                // epilogue staging row (bf16 elements): 288 B = 32 mod 64, conflict-free 16-byte row reads (see chain.hip)
 
 struct ConvPatchArgs {
     const u16* in; const u16* wf; const float* bias; u16* out;
