@@ -235,3 +235,40 @@ def test_gradient_bucket_events_open_an_overlap_window():
     # at least a fifth of the backward still to run, the cell nets' (1.7 MB) with a tenth
     assert r[1] >= 0.2 * r[0] and r[2] >= 0.1 * r[0] and r[3] >= 0.0, text
     assert r[1] >= r[2] >= r[3], text
+
+
+@pytest.mark.parametrize("I,B", [(128, 3), (128, 37), (64, 5), (256, 3)])
+def test_round3_kernels_agree_with_the_kernels_they_replaced(I, B):
+    """The round-3 kernels of the bf16 step (fused decoder forward / backward, patch-resident strided convolutions and their data gradients)
+    against the implicit-GEMM / per-layer kernels they replaced (SpairStep.flags bits 4, 5, 6), on batch sizes and image sides that are in
+    no golden fixture: partial row tiles everywhere (B * G * G, B * Hout * Hout not multiples of 128 / 256), fewer tiles than CUs for the
+    persistent workgroups.  Same weights, batch and noise: loss to 1e-5 relative, reconstruction to bf16 rounding, every gradient tensor's
+    direction to 0.999 and norm to 1 % (the two paths round the same fp32 sums at slightly different points)."""
+    from spair_pytorch_amd import models
+    from spair_pytorch_amd.data import scattered_digits
+    G = gi.grid_side(I, STRIDES)
+    x = torch.from_numpy(scattered_digits(77 + B, B, I, 7)[0]).cuda()
+    noise = {k: torch.from_numpy(v).cuda() for k, v in gi.make_noise(78 + B, B, G).items()}
+    m = _model(I, "bf16", seed=5)
+    res = {}
+    old = models.STEP_FLAGS
+    try:
+        for name, flags in (("new", 0), ("old", 16 | 32 | 64)):
+            models.STEP_FLAGS = flags
+            m.zero_grad()
+            loss, recon, z_where, z_pres = m(x, 3000, noise=noise)
+            loss.backward()
+            res[name] = (loss.item(), recon.clone(), z_where.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        models.STEP_FLAGS = old
+    ln, rn, zn, gn = res["new"]
+    lo, ro, zo, go = res["old"]
+    assert np.isfinite(ln) and abs(ln - lo) <= 1e-5 * abs(lo), (ln, lo)
+    assert (rn - ro).abs().max().item() < 4e-3 and (zn - zo).abs().max().item() < 1e-4
+    for k in gn:
+        a, b = gn[k].double().flatten(), go[k].double().flatten()
+        if b.norm().item() < 1e-12:
+            assert a.norm().item() < 1e-9, k
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert cos > 0.999 and abs(a.norm().item() / b.norm().item() - 1.0) < 0.01, (k, cos, a.norm().item() / b.norm().item())
