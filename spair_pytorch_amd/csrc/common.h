@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define SPAIR_OK 0
 #define SPAIR_ERR_SHAPE (-1)
@@ -18,6 +19,32 @@
         hipError_t e__ = hipGetLastError();                    \
         if (e__ != hipSuccess) return SPAIR_ERR_LAUNCH;        \
     } while (0)
+
+
+// Per-DEVICE launch state.  A kernel that needs more than 64 KB of dynamic LDS must be given the attribute on every device it is launched
+// on, and a persistent grid is sized from the CURRENT device's CU count: both are keyed by hipGetDevice() here (one process may drive several
+// devices from several host threads: include/spair_hip.h).  Two threads racing on the same device both set the attribute -- idempotent.
+static inline int spair_dyn_lds_once(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SPAIR_ERR_LAUNCH;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return SPAIR_OK;
+}
+static inline int spair_num_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -198,12 +198,8 @@ int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, voi
         worst = std::max(worst, ((g1 + g1 / Hout + 1) - (g0 + g0 / Hout) + 1) * (Hout + 1));
     }
     if (worst > CP_PPX) return SPAIR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_s2k4_patch), hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS) != hipSuccess)
-            return SPAIR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (spair_dyn_lds_once(reinterpret_cast<const void*>(&k_conv_s2k4_patch), CP_LDS, attr_done) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     ConvPatchArgs a;
     a.in = reinterpret_cast<const u16*>(in); a.wf = reinterpret_cast<const u16*>(wf); a.bias = bias; a.out = reinterpret_cast<u16*>(out);
     a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C;

@@ -357,17 +357,12 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
     a.gate = reinterpret_cast<const u16*>(gate); a.out = reinterpret_cast<u16*>(out);
     a.B = B; a.Ho = Ho; a.Hc = Hc; a.Hi = hin; a.M = (int)M;
     a.stem_xp = stem_xp; a.stem_part = stem_part; a.stem_hin = stem_hin; a.stem_s = stem_s;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[stem]) {
+    static std::atomic<unsigned long long> attr_done[2];
+    {
         const void* fn = stem ? reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true>) : reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS) != hipSuccess) return SPAIR_ERR_LAUNCH;
-        attr_set[stem] = true;
+        if (spair_dyn_lds_once(fn, DG_LDS, attr_done[stem ? 1 : 0]) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     }
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    const int n_cu = spair_num_cus();
     const int grid = std::min(tiles, n_cu);      // persistent: one 160-KB workgroup per CU walks the tiles
     if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(grid), dim3(512), DG_LDS, s, a);
     else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(grid), dim3(512), DG_LDS, s, a);

@@ -320,12 +320,8 @@ int dec_fused_bwd(const void* dL, int ld_s, const void* W2t, int ld2, const void
     a.dH2 = reinterpret_cast<u16*>(dH2); a.dH1 = reinterpret_cast<u16*>(dH1);
     a.dza = dza; a.ld_dza = ld_dza; a.N = (int)N; a.K1 = n_out;
     constexpr int lds = DB_NST * DB_STAGE_B;      // 96 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return SPAIR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (spair_dyn_lds_once(reinterpret_cast<const void*>(&k_dec_bwd), lds, attr_done) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     hipLaunchKernelGGL(k_dec_bwd, dim3((unsigned)((N + DB_ROWS - 1) / DB_ROWS)), dim3(512), lds, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;

@@ -588,12 +588,8 @@ int spair_gemm_nt16_impl(const GemmNT& g_in, bool conv, hipStream_t s) {
     }
 #define NT16_LAUNCH_BK(AC, C16, ST, BKV)                                                                        \
     do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV>),              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static std::atomic<unsigned long long> attr_done{0};                                                      \
+        spair_dyn_lds_once(reinterpret_cast<const void*>(&gemm_nt16_kernel<AC, C16, ST, BKV>), (int)lds, attr_done); \
         hipLaunchKernelGGL((gemm_nt16_kernel<AC, C16, ST, BKV>), grid, dim3(256), lds, s, g);                     \
     } while (0)
 #define NT16_LAUNCH(AC, C16, ST)                                                                                 \

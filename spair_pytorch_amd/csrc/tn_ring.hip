@@ -201,12 +201,8 @@ __global__ __launch_bounds__(512) void k_tn_ring(GemmTN g) {
 template <int BN, bool BCONV, int NST>
 int tr_launch(const GemmTN& g, dim3 grid, hipStream_t s) {
     constexpr int lds = NST * (2 + BN / 64) * TR_GRP_B;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tn_ring<BN, BCONV, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return SPAIR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (spair_dyn_lds_once(reinterpret_cast<const void*>(&k_tn_ring<BN, BCONV, NST>), lds, attr_done) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     hipLaunchKernelGGL((k_tn_ring<BN, BCONV, NST>), grid, dim3(512), lds, s, g);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
@@ -215,10 +211,9 @@ int tr_launch(const GemmTN& g, dim3 grid, hipStream_t s) {
 }  // namespace
 
 // Called by spair_gemm_tn16_impl (gemm16.hip) with a validated problem (bf16 B, load extents multiples of 8, 32-bit element offsets); returns
-// SPAIR_ERR_UNSUPPORTED when the ring kernel does not apply and the caller keeps gemm_tn16_kernel.  SPAIR_TN_RING=0 forces that (A/B timing).
+// SPAIR_ERR_UNSUPPORTED when the ring kernel does not apply and the caller keeps gemm_tn16_kernel.
 int spair_gemm_tn_ring(GemmTN g, bool conv, hipStream_t s) {
-    static const int enabled = [] { const char* e = getenv("SPAIR_TN_RING"); return e ? atoi(e) : 1; }();
-    if (!enabled || !g.part) return SPAIR_ERR_UNSUPPORTED;
+    if (!g.part) return SPAIR_ERR_UNSUPPORTED;
     const bool grouped = g.ngroup > 1;
     if (conv) {
         if (grouped || (g.conv.Cin & 63) || g.conv.kw <= 0) return SPAIR_ERR_UNSUPPORTED;

@@ -301,7 +301,15 @@ class SPAIR(nn.Module):
                 live = sum(int(v["workspace"].numel()) for v in self._engines.values())
                 limit = 2 if (live + nbytes) <= torch.cuda.get_device_properties(dev).total_memory // 4 else 1
             while len(self._engines) >= max(1, limit):      # evict BEFORE allocating: two multi-GB workspaces never coexist needlessly
-                self._engines.pop(next(iter(self._engines)))
+                old = self._engines.pop(next(iter(self._engines)))
+                # `_last` holds a strong reference to the engine of the latest forward: drop it too, or the evicted workspace stays alive
+                # until `_run_forward` reassigns `_last` -- i.e. across the allocation below (a pending backward through it raises, as for
+                # any evicted engine: the step function only holds a weak reference)
+                if getattr(self, "_last", None) is not None and self._last.get("engine") is old:
+                    self._last = None
+                del old
+                if max(1, limit) == 1:
+                    torch.cuda.empty_cache()              # the limit-1 case exists because two workspaces do not fit comfortably: return the block
             e = _Engine(dims=d, generation=0,
                      workspace=torch.zeros(nbytes, dtype=torch.uint8, device=dev),   # zero-initialised ONCE
                      noise=dict(eps_box=torch.empty(batch, 4, G, G, device=dev), eps_attr=torch.empty(batch, A, G, G, device=dev),

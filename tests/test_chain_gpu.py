@@ -75,4 +75,4 @@ def test_helper_stream_off_gives_the_same_step():
         assert (a[k] - b[k]).abs().max().item() == 0.0, k
     assert a["terms"][0].item() == b["terms"][0].item()
     ga, gb = a["grads"].double(), b["grads"].double()
-    assert (ga - gb).norm().item() <= 1e-5 * gb.norm().item()      # fp32 atomics on bias / edge gradients
+    assert (ga - gb).norm().item() <= 1e-5 * gb.norm().item()      # (bit-equal in practice: the bf16 step sums in a fixed order on either stream layout)
