@@ -196,7 +196,9 @@ def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
     from spair_pytorch_amd import _lib as L
     from spair_pytorch_amd import models
     import numpy as np
-    T, NS, GL = 3 * d.G - 2, 20, 6                 # stamps per wavefront; stage 6 = glimpse sampling (tools/chain_stamps.py)
+    ns_, gl_, nb_ = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    L.check(L.lib().spair_chain_stamp_layout(ctypes.byref(ns_), ctypes.byref(gl_), ctypes.byref(nb_)), "stamp_layout")
+    T, NS, GL = 3 * d.G - 2, ns_.value, gl_.value       # stamps per wavefront; interval GL = glimpse sampling (tools/chain_stamps.py)
     if T * NS > 2048:
         return None
     old = models.STEP_FLAGS

@@ -99,6 +99,9 @@ int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg
 int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream);
 /* diagnostic: stage time stamps of the fused forward chain kernel (SpairStep.flags bit 1), n <= 4096 uint64 */
 int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long long* out, int n, void* stream);
+/* layout of that buffer: stamps per wavefront of the forward kernel (from offset 0; stage intervals = stamps - 1), the index of the glimpse
+ * sampling interval (K4: modules.py:216-273 via models.py:387) among them, stamps per wavefront of the backward kernel (from offset 2048) */
+int spair_chain_stamp_layout(int* fwd_per_wavefront, int* fwd_glimpse_interval, int* bwd_per_wavefront);
 int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
 
 /* Opt-in instrumentation for bench.py: HIP events on the caller's stream around regions of the step.

@@ -18,6 +18,12 @@ struct ChainArgs {
     int I, Pp, ac;
 };
 
+// stage stamps (diagnostic, SpairStep.flags bit 1): stamps per wavefront; the forward kernel's intervals are
+// rows | S0 ctx | BOX0 | BOX1 | BOXH+box | glimpse | ENC0 | ENC1 | ENC2 | attr | Z0 | Z1 | ZH+depth | OBJ0 | OBJ1+obj2 | pres
+#define CHAIN_FWD_STAMPS 17
+#define CHAIN_FWD_GLIMPSE 5
+#define CHAIN_BWD_STAMPS 19
+
 int chain_fwd_supported(const SpairDims& d);
 // 1 when the fused forward kernel samples glimpses from an fp16 LDS copy of the image (the per-wavefront reference path then
 // rounds pixels the same way, so the two paths stay comparable to rounding level)

@@ -68,7 +68,11 @@ __device__ __forceinline__ void ch_gstore_nt(float4* p, const float4& v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
 }
+#ifdef CH_ABL_NOSTORE
+#define CH_GSTORE(p, v) do { } while (0)
+#else
 #define CH_GSTORE(p, v) ch_gstore_nt((p), (v))
+#endif
 // the backward kernel's read-once row data (bundle, glimpse derivatives) is loaded non-temporally (chain bwd 0.852 -> 0.833 ms)
 __device__ __forceinline__ uint4 ch_gload16(const void* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -85,7 +89,11 @@ struct WPipe { uint4 q[RD]; };
 template <int KT, int NT, int NT0>
 __device__ __forceinline__ const uint4* tile_base(const uint4* __restrict__ Wp, int wave, int lane) {
     const int nt = min(NT0 + wave, NT - 1);
+#ifdef CH_ABL_WL1
+    return Wp + lane;                      // ablation: every fragment load hits the same 1 KiB (L1-resident)
+#else
     return Wp + (size_t)nt * KT * 64 + lane;
+#endif
 }
 
 template <int KT, int NT, int NT0 = 0>
@@ -93,72 +101,18 @@ __device__ __forceinline__ void pipe_fill(const uint4* __restrict__ Wp, WPipe& p
     const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
 #pragma unroll
     for (int f = 0; f < RD; ++f)
+#ifdef CH_ABL_WL1
+        if (f < KT) p.q[f] = base[(f & 3) * 64];
+#elif defined(CH_ABL_NOW)
+        if (f < KT && f < 1) p.q[f] = base[f * 64];
+#else
         if (f < KT) p.q[f] = base[f * 64];
+#endif
 }
 
-// acc = in[16, K] . W_tile^T for this wave's tile NT0 + wave; K = 32*(KT0+KT1): the first KT0 k-steps read inA, the rest inB.
-template <int KT0, int KT1, int NT, int NT0 = 0>
-__device__ __forceinline__ void wg_gemm(const __bf16* inA, int ldA, const __bf16* inB, int ldB, const uint4* __restrict__ Wp, WPipe& p,
-                                        f32x4& acc, int wave, int lane) {
-    constexpr int KT = KT0 + KT1;
-    constexpr int NMAIN = (KT >= 2 * RD) ? (KT / RD - 1) : 0;    // groups whose RD refills all exist
-    const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
-    const __bf16* pa = inA + (lane & 15) * ldA + (lane >> 4) * 8;
-    const __bf16* pb = (KT1 > 0) ? inB + (lane & 15) * ldB + (lane >> 4) * 8 : pa;
-    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto afrag = [&](int kt) -> bf16x8 {
-        if constexpr (KT1 == 0) return *reinterpret_cast<const bf16x8*>(pa + kt * 32);
-        else return *reinterpret_cast<const bf16x8*>((kt < KT0) ? pa + kt * 32 : pb + (kt - KT0) * 32);
-    };
-#pragma unroll 1
-    for (int g = 0; g < NMAIN; ++g) {
-#pragma unroll
-        for (int d = 0; d < RD; ++d) {
-            const int f = g * RD + d;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f), as_frag(p.q[d]), acc, 0, 0, 0);
-            p.q[d] = base[(size_t)(f + RD) * 64];
-        }
-    }
-#pragma unroll
-    for (int f = NMAIN * RD; f < KT; ++f) {          // compile-time tail: every condition folds
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f), as_frag(p.q[f % RD]), acc, 0, 0, 0);
-        if (f + RD < KT) p.q[f % RD] = base[(size_t)(f + RD) * 64];
-    }
-}
-
-// epilogue: v = acc + bias (+relu); optional bf16 copy to LDS (next layer's input), fp32 copy to LDS (head outputs) and to the
-// HBM row buffer (what backward / weight-gradient GEMMs read).  Lane holds col = nt*16 + (lane&15), rows (lane>>4)*4 + r.
-// relu layers also leave their sign bits: one wave ballot per accumulator register r (bit = lane, i.e. row group lane>>4, column lane&15
-// of the tile) at mb[nt*4 + r] -- the backward kernel reads 2 KB of bits per wavefront instead of re-reading 56 KB of activations
+// relu layers leave their sign bits as wave ballots (see wg_store_t): the backward kernel reads 2 KB of bits per wavefront instead of
+// re-reading 56 KB of activations
 constexpr int MB_HB1 = 0, MB_HB2 = 7, MB_HE1 = 14, MB_HE2 = 30, MB_HZ1 = 38, MB_HZ2 = 45, MB_HO1 = 52, MB_HO2 = 59, MB_TILES = 66;
-template <int NT, bool RELU, int NT0 = 0>
-__device__ __forceinline__ void wg_store(const f32x4& acc, const float* __restrict__ bias, int nout, __bf16* lds_bf, int ld_bf,
-                                         float* lds_f, int ld_f, float* __restrict__ hbm, int ld_hbm, const int* row_r, int nc, int wave,
-                                         int lane, unsigned long long* __restrict__ mb = nullptr, bool hbm_b16 = false) {
-    const int nt = NT0 + wave;
-    const int n = nt * 16 + (lane & 15);
-    if (nt >= NT) return;                                        // wave-uniform
-    const float bv = bias[min(n, nout - 1)];
-    if (RELU && mb) {
-        const unsigned long long b0 = __ballot((acc[0] + bv) > 0.f), b1 = __ballot((acc[1] + bv) > 0.f);
-        const unsigned long long b2 = __ballot((acc[2] + bv) > 0.f), b3 = __ballot((acc[3] + bv) > 0.f);
-        if (lane < 4) mb[nt * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));     // one 32-byte LDS write
-    }
-    if (n >= nout) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) * 4 + r;
-        float v = acc[r] + bv;
-        if (RELU) v = fmaxf(v, 0.f);
-        if (lds_bf) lds_bf[row * ld_bf + n] = (__bf16)v;
-        if (lds_f) lds_f[row * ld_f + n] = v;
-        if (hbm && row < nc) {
-            if (hbm_b16) CH_GSTORE(&reinterpret_cast<__bf16*>(hbm)[(size_t)row_r[row] * ld_hbm + n], (__bf16)v);
-            else CH_GSTORE(&hbm[(size_t)row_r[row] * ld_hbm + n], v);
-        }
-    }
-}
-
 // The "store wave": layers with 7 column tiles leave the 8th wave without work.  It copies the PREVIOUS stage's output rows from
 // LDS to their HBM row buffer (coalesced 16-byte stores) while the other seven compute -- their instruction streams then contain no
 // global store at all, so a wait for a weight fragment is only ever a wait for weight fragments.  (Hidden activations reach HBM as
@@ -193,6 +147,114 @@ __device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, floa
     for (int t = lane; t < nc * CH; t += 64) {
         const int row = t / CH, c = (t - row * CH) * 4;
         CH_GSTORE(reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c), *reinterpret_cast<const float4*>(src + row * lds_ld + c));
+    }
+}
+
+
+// ---- lean GEMM stage, TRANSPOSED MFMA form (round 4) --------------------------------------------------------------------------------------
+// The chain kernels are bound by the instruction streams of their ~16 dependent stages (ablation: with every weight load removed the forward
+// kernel still takes 0.63 of its 0.84 ms; a 4-k-step layer ran ~140 instructions per wave at ~9 cycles each), not by the weight stream.  The
+// stage is therefore written for instruction count and exposed latency:
+//  * operands swapped -- the weight fragment is the A operand, the activation tile the B operand (the register layouts of the two are the
+//    same, so the packs and the LDS reads do not change): D^T[col][row], a lane ends up with FOUR CONSECUTIVE COLUMNS of ONE row
+//    (col = tile*16 + (lane>>4)*4 + r, row = lane & 15) -- one 8-byte LDS write of 4 bf16 (or one 16-byte write of 4 floats) instead of four
+//    2-byte writes with four addresses;
+//  * the accumulator starts as the bias quad (one 16-byte LDS read issued with the activation reads): no bias adds;
+//  * every activation fragment of the stage is read before the first MFMA (the compiler otherwise re-used one register quad and exposed an
+//    LDS round trip per k-step);
+//  * relu sign bits: v_cmp leaves each ballot in an SGPR pair; lane 0 writes the tile's four words with two 16-byte stores.
+// Sign-bit layout (shared with k_chain_bwd): word tile*4 + r, bit = lane  <->  column tile*16 + (lane>>4)*4 + r, row lane & 15.
+template <int KT0, int KT1, int NT, int NT0 = 0>
+__device__ __forceinline__ void wg_gemm_t(const __bf16* inA, int ldA, const __bf16* inB, int ldB, const uint4* __restrict__ Wp, WPipe& p,
+                                          const float* bias_l, f32x4& acc, int wave, int lane) {
+    constexpr int KT = KT0 + KT1;
+    static_assert(KT <= 16, "all activation fragments of the stage are held in registers");
+    const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
+    const int nt = min(NT0 + wave, NT - 1);
+    const __bf16* pa = inA + (lane & 15) * ldA + (lane >> 4) * 8;
+    const __bf16* pb = (KT1 > 0) ? inB + (lane & 15) * ldB + (lane >> 4) * 8 : pa;
+    bf16x8 x[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+        x[kt] = *reinterpret_cast<const bf16x8*>((kt < KT0) ? pa + kt * 32 : pb + (kt - KT0) * 32);
+    acc = *reinterpret_cast<const f32x4*>(bias_l + nt * 16 + (lane >> 4) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < KT; ++f) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[f % RD]), x[f], acc, 0, 0, 0);
+        if (f + RD < KT) p.q[f % RD] = base[(size_t)(f + RD) * 64];
+    }
+}
+
+// Two column tiles per wave (tiles `wave` and `wave + 8`: the encoder's 256-wide first layer) sharing every activation fragment; the K loop
+// runs in chunks of CH k-steps, the next chunk's LDS reads issued before the current chunk's MFMAs.  Ring order: (k-step, tile) pairs.
+template <int KT>
+__device__ __forceinline__ void pipe_fill2(const uint4* __restrict__ Wp, WPipe& p, int wave, int lane) {
+    const uint4* b0 = Wp + (size_t)wave * KT * 64 + lane;
+    const uint4* b1 = Wp + (size_t)(wave + 8) * KT * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < RD; ++s) p.q[s] = ((s & 1) ? b1 : b0)[(s >> 1) * 64];
+}
+template <int KT, int CH>
+__device__ __forceinline__ void wg_gemm_t2(const __bf16* in, int ld, const uint4* __restrict__ Wp, WPipe& p, const float* bias_l, f32x4& acc0,
+                                           f32x4& acc1, int wave, int lane) {
+    static_assert(KT % CH == 0 && RD % 2 == 0, "whole chunks; ring slots alternate between the two tiles");
+    constexpr int NCH = KT / CH, AH = RD / 2;          // AH: k-steps the ring runs ahead
+    const uint4* b0 = Wp + (size_t)wave * KT * 64 + lane;
+    const uint4* b1 = Wp + (size_t)(wave + 8) * KT * 64 + lane;
+    const __bf16* pa = in + (lane & 15) * ld + (lane >> 4) * 8;
+    bf16x8 x[2][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) x[0][j] = *reinterpret_cast<const bf16x8*>(pa + j * 32);
+    acc0 = *reinterpret_cast<const f32x4*>(bias_l + wave * 16 + (lane >> 4) * 4);
+    acc1 = *reinterpret_cast<const f32x4*>(bias_l + (wave + 8) * 16 + (lane >> 4) * 4);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) x[(c + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(pa + ((c + 1) * CH + j) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int f = c * CH + j;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f) % RD]), x[c & 1][j], acc0, 0, 0, 0);
+            if (f + AH < KT) p.q[(2 * f) % RD] = b0[(size_t)(f + AH) * 64];
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f + 1) % RD]), x[c & 1][j], acc1, 0, 0, 0);
+            if (f + AH < KT) p.q[(2 * f + 1) % RD] = b1[(size_t)(f + AH) * 64];
+        }
+    }
+}
+
+// epilogue of a lean stage.  ncol4 = number of output columns rounded up to 4 (quads past it are padding: not written); nbf = columns that
+// get the bf16 LDS copy (the next layer's input tile); hbm16 = bf16 row buffer written straight from the epilogue (8 bytes per lane).
+template <int NT, bool RELU, int NT0 = 0>
+__device__ __forceinline__ void wg_store_t(const f32x4& acc, int ncol4, __bf16* lds_bf, int ld_bf, int nbf, float* lds_f, int ld_f,
+                                           __bf16* __restrict__ hbm16, int ld_hbm, const int* row_r, int nc, int wave, int lane,
+                                           unsigned long long* __restrict__ mb = nullptr) {
+    const int nt = NT0 + wave;
+    if (nt >= NT) return;                                        // wave-uniform
+    const int col0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
+    f32x4 v = acc;
+    if (RELU) {
+        if (mb) {
+            const unsigned long long b0 = __ballot(acc[0] > 0.f), b1 = __ballot(acc[1] > 0.f), b2 = __ballot(acc[2] > 0.f), b3 = __ballot(acc[3] > 0.f);
+            if (lane == 0) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2* q = reinterpret_cast<u64x2*>(mb + nt * 4);
+                q[0] = (u64x2){b0, b1};
+                q[1] = (u64x2){b2, b3};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r], 0.f);
+    }
+    if (col0 >= ncol4) return;
+    if (lds_f) *reinterpret_cast<f32x4*>(lds_f + row * ld_f + col0) = v;
+    if (lds_bf || hbm16) {
+        const bf16x4 o = pack4(v[0], v[1], v[2], v[3]);
+        if (lds_bf && col0 < nbf) *reinterpret_cast<bf16x4*>(lds_bf + row * ld_bf + col0) = o;
+        if (hbm16 && row < nc) CH_GSTORE(reinterpret_cast<bf16x4*>(hbm16 + (size_t)row_r[row] * ld_hbm + col0), o);
     }
 }
 
@@ -231,6 +293,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ int row_r[MT], row_h[MT], row_w[MT], row_cp[MT];
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ short nbr_sh[32 * 32 * 4];
+    __shared__ float w2_sh[7 * 16];             // obj_network.out.weight as the bf16 values the MFMA path would multiply by (0 past column 99)
+    __shared__ float opart[7][4][MT];           // partial presence logits per (wave, column group of its tile, row) (OBJ1's epilogue)
 
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
@@ -241,6 +305,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
 
+    if (tid < 7 * 16) w2_sh[tid] = tid < 100 ? (float)(__bf16)a.w_obj2[tid] : 0.f;
     for (int i = tid; i < MT * LD_XC; i += NTH) Xc[i] = (__bf16)0.f;
     for (int i = tid; i < MT * LD_XT; i += NTH) { XtZ[i] = (__bf16)0.f; XtO[i] = (__bf16)0.f; }
     for (int i = tid; i < MT * LD_GL; i += NTH) Gl[i] = (__bf16)0.f;
@@ -251,9 +316,12 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     for (int i = tid; i < L.HW; i += NTH) cell_hw[i] = (unsigned short)((P.cell_h[i] << 8) | P.cell_w[i]);
     for (int i = tid; i < REC; i += NTH) edge_sh[i] = P.edge[i];
     if (tid < PG) pbase_sh[tid] = stn_base(tid, PG, a.ac);
+    // (every tile's accumulator starts from a whole bias quad: the padding between the layers' entries must read as zero)
 #pragma unroll
-    for (int l = 0; l < CW_COUNT; ++l)
-        for (int i = tid; i < BIAS_CNT[l]; i += NTH) bias_sh[BIAS_OFF[l] + i] = a.bias[l][i];
+    for (int l = 0; l < CW_COUNT; ++l) {
+        const int span = (l + 1 < CW_COUNT ? BIAS_OFF[l + 1] : BIAS_TOT) - BIAS_OFF[l];
+        for (int i = tid; i < span; i += NTH) bias_sh[BIAS_OFF[l] + i] = i < BIAS_CNT[l] ? a.bias[l][min(i, BIAS_CNT[l] - 1)] : 0.f;
+    }
     if constexpr (IMG) {
         const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)b * a.I * a.I);
         for (int i = tid; i < a.I * a.I / 4; i += NTH) {
@@ -370,90 +438,94 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // ---- z_where: box MLP (models.py:76-77)
         {
             f32x4 acc;
-            wg_gemm<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, acc, wave, lane);
+            wg_gemm_t<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, bias_sh + BIAS_OFF[CW_BOX0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
         }
         lds_barrier();
         CH_STAMP();
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, acc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, bias_sh + BIAS_OFF[CW_BOX1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_BOX1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
         } else {
             copy_rows_b16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
+        // BOXH: [passthrough NP | 8 latents].  The passthrough columns go to the z-net's input tile (bf16) from the epilogue itself; the wave
+        // that owns the latent columns (tile 6: columns 96..111) turns them into the box right behind its own stores -- no stage (barrier +
+        // a 16-thread latent pass) of its own.
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, acc, wave, lane);
-            pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_BOXH], NP + 8, nullptr, 0, Ost, LD_O, nullptr, L.ld_ob, row_r, nc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, bias_sh + BIAS_OFF[CW_BOXH], acc, wave, lane);
+            pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
+            wg_store_t<7, false>(acc, NP + 8, XtZ, LD_XT, NP, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
         } else {
-            pipe_fill<25, 16>(a.w[CW_ENC0], pipe, wave, lane);
+            pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
             copy_rows_b16<100>(Hb, LD_H, P.Hb2, SP_LDH, row_r, nc, lane);
         }
-        lds_barrier();
-        CH_STAMP();
-        // ---- box latents (models.py:322-381); passthrough -> z-net input
-        if (wave == 7) copy_rows_f32<NP + 8>(Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, lane);
-        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
-            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(&Ost[row * LD_O + i]);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-            *reinterpret_cast<bf16x4*>(&XtZ[row * LD_XT + i]) = o;
-            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xz) + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = o;
-        }
-        // one latent per lane: threads 64 .. 64 + 4*nc (wave 1, so that wave 0 is free for the copy loop above); lane k of a row owns
-        // z_k -> (cell_y, cell_x, height, width)[k] -> box / nbox element k ^ 1
-        if (tid >= 64 && tid < 64 + 4 * nc) {
-            const int row = (tid - 64) >> 2, k = (tid - 64) & 3, o = k ^ 1;
-            const int h = row_h[row], w = row_w[row];
-            const size_t r = row_r[row];
-            const float* lat = &Ost[row * LD_O + NP];
-            const float mu = freeze_val(H.wheel, lat[k]);
-            const float sd = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(lat[4 + k])));
-            const float sg = sigmoidf_(clamp10(mu + sd * noise_sh[row][k]));
-            float bv, nv;                               // box_forward (cell_math.h), element by element
-            if (k < 2) {
-                bv = (H.max_yx - H.min_yx) * sg + H.min_yx;                         // cell_y (k = 0), cell_x (k = 1)
-                nv = H.cell_over_img * (bv + (float)(k == 0 ? h : w));              // yt, xt
-            } else {
-                bv = (H.max_hw - H.min_hw) * sg + H.min_hw;                         // height (k = 2), width (k = 3)
-                nv = bv * H.anchor / H.img;                                         // ys, xs
+        // ---- box latents (models.py:322-381): one latent per lane of wave 6; lane k of a row owns z_k -> (cell_y, cell_x, height, width)[k]
+        // -> box / nbox element k ^ 1
+        if (wave == 6) {
+            wave_lds_sync();                      // this wave's own Ost columns
+            if (lane < 4 * nc) {
+                const int row = lane >> 2, k = lane & 3, o = k ^ 1;
+                const int h = row_h[row], w = row_w[row];
+                const size_t r = row_r[row];
+                const float* lat = &Ost[row * LD_O + NP];
+                const float mu = freeze_val(H.wheel, lat[k]);
+                const float sd = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(lat[4 + k])));
+                const float sg = sigmoidf_(clamp10(mu + sd * noise_sh[row][k]));
+                float bv, nv;                               // box_forward (cell_math.h), element by element
+                if (k < 2) {
+                    bv = (H.max_yx - H.min_yx) * sg + H.min_yx;                         // cell_y (k = 0), cell_x (k = 1)
+                    nv = H.cell_over_img * (bv + (float)(k == 0 ? h : w));              // yt, xt
+                } else {
+                    bv = (H.max_hw - H.min_hw) * sg + H.min_hw;                         // height (k = 2), width (k = 3)
+                    nv = bv * H.anchor / H.img;                                         // ys, xs
+                }
+                float* st = P.stat + r * SP_LDSTAT;
+                st[ST_MU_BOX + k] = mu;
+                st[ST_SD_BOX + k] = sd;
+                rec_cur[row][o] = bv;
+                nb_sh[row][o] = nv;
+                XtZ[row * LD_XT + NP + o] = (__bf16)bv;
+                XtO[row * LD_XT + NP + o] = (__bf16)bv;
+                P.rec[r * L.ld_rec + o] = bv;
+                reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
+                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
+                P.nbox[r * 4 + o] = nv;
+                P.z_where[(((size_t)b * 4 + o) * G + h) * G + w] = nv;
             }
-            float* st = P.stat + r * SP_LDSTAT;
-            st[ST_MU_BOX + k] = mu;
-            st[ST_SD_BOX + k] = sd;
-            rec_cur[row][o] = bv;
-            nb_sh[row][o] = nv;
-            XtZ[row * LD_XT + NP + o] = (__bf16)bv;
-            XtO[row * LD_XT + NP + o] = (__bf16)bv;
-            P.rec[r * L.ld_rec + o] = bv;
-            reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
-            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
-            P.nbox[r * 4 + o] = nv;
-            P.z_where[(((size_t)b * 4 + o) * G + h) * G + w] = nv;
         }
         lds_barrier();
         CH_STAMP();
         // ---- z_what: glimpse (modules.py:216-273, border padding) + encoder MLP (models.py:383-391)
         // The source coordinates are separable: 28 column and 28 row coordinates per cell, tabulated first (one entry per thread:
         // first tap index | "second tap inside" | "not clipped", fractional weight) instead of being re-derived by every element
-        // (5 coordinate evaluations per 4 elements were ~40 % of the sampling stage's instructions).
-        for (int e = tid; e < nc * 2 * PG; e += NTH) {
-            const int row = e / (2 * PG), rem = e - row * (2 * PG), axis = rem >= PG ? 1 : 0, gi = rem - axis * PG;
-            float cc, mm;
-            stn_src_coord_b(nb_sh[row][axis ? 3 : 2], 2.f * nb_sh[row][axis ? 1 : 0] - 1.f, pbase_sh[gi], a.I, a.ac, true, cc, mm);
-            const int c0 = (int)floorf(cc);
-            gtab[row][axis][gi] = make_uint2((unsigned)c0 | ((c0 + 1) < a.I ? 0x10000u : 0u) | (mm != 0.f ? 0x20000u : 0u), __float_as_uint(cc - (float)c0));
+        // (5 coordinate evaluations per 4 elements were ~40 % of the sampling stage's instructions).  Waves 0..6 build the table; the
+        // 8th copies the box head's output rows and the z-net's passthrough columns to HBM meanwhile.
+        if (wave == 7) {
+            copy_rows_f32<NP + 8>(Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, lane);
+            copy_rows_b16<100>(XtZ, LD_XT, reinterpret_cast<float*>(reinterpret_cast<__bf16*>(P.Xz) + L.x_pass), L.ld_x, row_r, nc, lane);
+        } else {
+            for (int e = tid; e < nc * 2 * PG; e += 7 * 64) {
+                const int row = e / (2 * PG), rem = e - row * (2 * PG), axis = rem >= PG ? 1 : 0, gi = rem - axis * PG;
+                float cc, mm;
+                stn_src_coord_b(nb_sh[row][axis ? 3 : 2], 2.f * nb_sh[row][axis ? 1 : 0] - 1.f, pbase_sh[gi], a.I, a.ac, true, cc, mm);
+                const int c0 = (int)floorf(cc);
+                gtab[row][axis][gi] = make_uint2((unsigned)c0 | ((c0 + 1) < a.I ? 0x10000u : 0u) | (mm != 0.f ? 0x20000u : 0u), __float_as_uint(cc - (float)c0));
+            }
         }
         lds_barrier();
         const float gmult = a.ac ? 0.5f * (float)(a.I - 1) : 0.5f * (float)a.I;      // d(source pixel coordinate) / d(normalised coordinate) where not clipped
+#ifdef CH_ABL_NOGL
+        for (int idx = tid; idx < 0; idx += NTH) {
+#else
         for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
+#endif
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
             const int i = e / PG, j0 = e - i * PG;              // P % 4 == 0: the 4 elements share the row i
             const uint2 ye = gtab[row][1][i];
@@ -498,28 +570,26 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         {   // 256 outputs = 16 tiles: two half-layers of 8 tiles, one tile per wave each
             f32x4 acc0, acc1;
-            wg_gemm<25, 0, 16, 0>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc0, wave, lane);
-            pipe_fill<25, 16, 8>(a.w[CW_ENC0], pipe, wave, lane);
-            wg_gemm<25, 0, 16, 8>(Gl, LD_GL, nullptr, 0, a.w[CW_ENC0], pipe, acc1, wave, lane);
+            wg_gemm_t2<25, 5>(Gl, LD_GL, a.w[CW_ENC0], pipe, bias_sh + BIAS_OFF[CW_ENC0], acc0, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store<16, true, 0>(acc0, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4, true);
-            wg_store<16, true, 8>(acc1, bias_sh + BIAS_OFF[CW_ENC0], 256, Ha, LD_H, nullptr, 0, P.He1, SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4, true);
+            wg_store_t<16, true, 0>(acc0, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
+            wg_store_t<16, true, 8>(acc1, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
         }
         lds_barrier();
         CH_STAMP();
         {
             f32x4 acc;
-            wg_gemm<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, acc, wave, lane);
+            wg_gemm_t<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, bias_sh + BIAS_OFF[CW_ENC1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
-            wg_store<8, true>(acc, bias_sh + BIAS_OFF[CW_ENC1], 128, Hb, LD_H, nullptr, 0, P.He2, SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4, true);
+            wg_store_t<8, true>(acc, 128, Hb, LD_H, 128, nullptr, 0, reinterpret_cast<__bf16*>(P.He2), SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4);
         }
         lds_barrier();
         CH_STAMP();
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, acc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, bias_sh + BIAS_OFF[CW_ENC2], acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ENC2], 2 * A_, nullptr, 0, Ost, LD_O, nullptr, L.ld_oe, row_r, nc, wave, lane);
+            wg_store_t<7, false>(acc, 2 * A_, nullptr, 0, 0, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
         } else {
             (void)0;
         }
@@ -548,9 +618,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // ---- z_depth (models.py:88-97)
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, acc, wave, lane);
+            wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, bias_sh + BIAS_OFF[CW_Z0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
         } else {
             (void)0;
         }
@@ -558,90 +628,89 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, acc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, bias_sh + BIAS_OFF[CW_Z1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_Z1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
         } else {
             copy_rows_b16<100>(Ha, LD_H, P.Hz1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
+        // ZH: [passthrough NP | depth mean, log-std]: passthrough -> obj-net input tile from the epilogue, depth by the wave that owns tile 6
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, acc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, bias_sh + BIAS_OFF[CW_ZH], acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
-            wg_store<7, false>(acc, bias_sh + BIAS_OFF[CW_ZH], NP + 2, nullptr, 0, Ost, LD_O, nullptr, L.ld_oz, row_r, nc, wave, lane);
+            wg_store_t<7, false>(acc, NP + 4, XtO, LD_XT, NP, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
         } else {
             copy_rows_b16<100>(Hb, LD_H, P.Hz2, SP_LDH, row_r, nc, lane);
         }
-        lds_barrier();
-        CH_STAMP();
-        if (wave == 7) copy_rows_f32<NP + 4>(Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, lane);      // 102 used columns, the row holds 104
-        for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {
-            const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(&Ost[row * LD_O + i]);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-            *reinterpret_cast<bf16x4*>(&XtO[row * LD_XT + i]) = o;
-            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xo) + (size_t)row_r[row] * L.ld_x + L.x_pass + i) = o;
-        }
-        if (tid < nc) {
-            const int h = row_h[tid], w = row_w[tid];
-            const size_t r = row_r[tid];
-            const float eps = noise_sh[tid][4 + A_];
-            float mu, sd, depth;
-            depth_forward(Ost[tid * LD_O + NP], Ost[tid * LD_O + NP + 1], eps, H, mu, sd, depth);
-            float* st = P.stat + r * SP_LDSTAT;
-            st[ST_MU_DEPTH] = mu;
-            st[ST_SD_DEPTH] = sd;
-            rec_cur[tid][4 + A_] = depth;
-            XtO[tid * LD_XT + NP + 4 + A_] = (__bf16)depth;
-            P.rec[r * L.ld_rec + 4 + A_] = depth;
-            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_depth] = (__bf16)depth;
+        if (wave == 6) {
+            wave_lds_sync();
+            if (lane < nc) {
+                const size_t r = row_r[lane];
+                const float eps = noise_sh[lane][4 + A_];
+                float mu, sd, depth;
+                depth_forward(Ost[lane * LD_O + NP], Ost[lane * LD_O + NP + 1], eps, H, mu, sd, depth);
+                float* st = P.stat + r * SP_LDSTAT;
+                st[ST_MU_DEPTH] = mu;
+                st[ST_SD_DEPTH] = sd;
+                rec_cur[lane][4 + A_] = depth;
+                XtO[lane * LD_XT + NP + 4 + A_] = (__bf16)depth;
+                P.rec[r * L.ld_rec + 4 + A_] = depth;
+                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_depth] = (__bf16)depth;
+            }
         }
         lds_barrier();
         CH_STAMP();
         // ---- z_pres (models.py:100-102,393-411)
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, acc, wave, lane);
+            wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, bias_sh + BIAS_OFF[CW_OBJ0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ0], 100, Ha, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
         } else {
-            (void)0;
-        }
-        lds_barrier();
-        CH_STAMP();
-        if (wave < 7) {
-            f32x4 acc;
-            wg_gemm<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, acc, wave, lane);
-            pipe_fill<4, 1>(a.w[CW_OBJ2], pipe, wave, lane);
-            wg_store<7, true>(acc, bias_sh + BIAS_OFF[CW_OBJ1], 100, Hb, LD_H, nullptr, 0, nullptr, SP_LDH, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
-        } else {
-            copy_rows_b16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
+            copy_rows_f32<NP + 4>(Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, lane);      // 102 used columns, the row holds 104
+            copy_rows_b16<100>(XtO, LD_XT, reinterpret_cast<float*>(reinterpret_cast<__bf16*>(P.Xo) + L.x_pass), L.ld_x, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
         // this row's presence noise, read now: the pres stage below shares its barrier interval with park(), which overwrites noise_sh
         const float u_pres_reg = noise_sh[min(tid, MT - 1)][4 + A_ + 1];
+        // OBJ1, and the one-column output layer with it: each lane multiplies its four (bf16-rounded, as the MFMA would see them) hidden values by
+        // the output weight of its column, a DPP reduction over the 16 columns of the tile leaves one partial logit per (wave, row) -- a
+        // 100 -> 1 layer as an MFMA stage of its own cost a full barrier interval (0.9 us) for one useful output column
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm<4, 0, 1>(Hb, LD_H, nullptr, 0, a.w[CW_OBJ2], pipe, acc, wave, lane);
+            wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, bias_sh + BIAS_OFF[CW_OBJ1], acc, wave, lane);
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
-            wg_store<1, false>(acc, bias_sh + BIAS_OFF[CW_OBJ2], 1, nullptr, 0, Ost, LD_O, P.Oo, L.ld_oo, row_r, nc, wave, lane);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
+            // this lane's four columns of its row against the output weights (both as the bf16 values an MFMA would see): one partial per
+            // (wave, column group, row); the presence stage adds the 28 of a row
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2_sh + wave * 16 + (lane >> 4) * 4);
+            float pz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pz = fmaf((float)(__bf16)fmaxf(acc[r], 0.f), w2[r], pz);
+            opart[wave][lane >> 4][lane & 15] = pz;
         } else {
-            copy_rows_b16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
+            copy_rows_b16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
         if (tid < nc) {
             const int h = row_h[tid], w = row_w[tid];
             const size_t r = row_r[tid];
-            const float pres = pres_forward(Ost[tid * LD_O], u_pres_reg, H);
+            float logit = 0.f;
+#pragma unroll
+            for (int q = 0; q < 28; ++q) logit += (&opart[0][0][0])[q * MT + tid];
+            logit += bias_sh[BIAS_OFF[CW_OBJ2]];
+            const float pres = pres_forward(logit, u_pres_reg, H);
+            P.Oo[r * L.ld_oo] = logit;
             rec_cur[tid][REC - 1] = pres;
             P.rec[r * L.ld_rec + REC - 1] = pres;
             P.z_pres[((size_t)b * G + h) * G + w] = pres;
         }
+        if (wave == 7) copy_rows_b16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
         // (no barrier: nothing below reads what the pres threads write, and they no longer read noise_sh; the next wavefront's row-setup
         //  barrier orders all of it before S0)
         park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
@@ -745,10 +814,12 @@ __device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __rest
     wg_gemm_wide<KT, NT>(in, LD_H, Wt, wave, lane, [&](int j, int nt, const f32x4& acc) {
         const int n = nt * 16 + (lane & 15);
         if (n >= nout) return;
+        // sign bits in the forward kernel's (transposed) layout: word tile*4 + (column & 3), bit (column >> 2)*16 + row
+        const unsigned int mw = (unsigned int)(mb[nt * 4 + (lane & 3)] >> (((lane & 15) >> 2) * 16 + (lane >> 4) * 4));
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = (lane >> 4) * 4 + rr;
-            const float v = ((mb[nt * 4 + rr] >> lane) & 1ull) ? acc[rr] : 0.f;
+            const float v = ((mw >> rr) & 1u) ? acc[rr] : 0.f;
             if (dOut_ && row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
             dst[row * LD_H + n] = (__bf16)v;
         }
@@ -765,7 +836,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Ab[MT * LD_H];
     __shared__ float grec[MT][REC];
     __shared__ float gnbw[NW][MT][4], nb_sh[MT][4];      // gnbw: per-WAVE partial d nbox of the glimpse epilogue, summed in wave order (no atomics: run-to-run identical)
-    __shared__ float dOo_sh[MT], zp_sh[MT];
+    __shared__ float zp_sh[MT];
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
     __shared__ float gtile[NW][16][17];       // wave-private transpose tile of the glimpse-gradient epilogue
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
@@ -888,8 +959,11 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         // Ho2 elements for the rank-1 stage below (row tid/25, columns 4*(tid%25)..+3 -> tile q4/4, register row&3)
         const unsigned long long* const mbt = P.mbits + ((size_t)b * T + t) * (MB_TILES * 4);
         const unsigned long long mbq = mbt[min(tid, MB_TILES * 4 - 1)];
-        const int ho_row = min(tid / 25, MT - 1), ho_q4 = tid - (tid / 25) * 25;
-        const unsigned long long mbo = mbt[(MB_HO2 + (ho_q4 >> 2)) * 4 + (ho_row & 3)];
+        const int ho_q4 = min(tid & 31, 24);          // the pres stage's mapping: 32 lanes per row, lanes 0..24 own 4 columns of Ho2 each
+        // the four sign-bit words of this thread's columns 4*l .. 4*l+3 (tile l>>2, column group l&3: one word per column)
+        typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+        const u64x2_t mbo01 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4);
+        const u64x2_t mbo23 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4 + 2);
         WPre wpre;
         wide_prefetch<4, 7>(a.wt[CW_OBJ1], wave, lane, wpre);     // first tile of the first data-gradient GEMM of this wavefront
         // saved glimpse derivatives for this wave's 7 ENC0 tiles, in the row-major mapping of the epilogue's second half (lane -> row
@@ -928,7 +1002,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit)
+        // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit) and, by the same lanes, the rank-1
+        // data gradient of the obj net's output layer: dHo2 = dOo (x) W_out masked by relu -- every lane of a row evaluates the row's d logit
+        // (the reduction leaves the KL sum in all 32), lanes 0..24 produce 4 columns each from the sign-bit word they prefetched
         {
             const int row = tid >> 5, l = tid & 31;
             float kl = 0.f;
@@ -942,30 +1018,25 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
             kl = dpp_add_<0xB1>(kl); kl = dpp_add_<0x4E>(kl); kl = dpp_add_<0x141>(kl); kl = dpp_add_<0x140>(kl);     // 16-lane rows (DPP)
             kl += __shfl_xor(kl, 16, 64);                                                                             // the two rows of a 32-lane group
-            if (row < nc && l == 0) {
-                const size_t r = row_r[row];
+            float d = 0.f;
+            if (row < nc) {
                 const float* bd = bundle_sh[row];
-                const float d = pres_backward(grec[row][REC - 1] + bd[BD_GPR], zp_sh[row], bd[BD_ST + ST_PZ], kl, bd[BD_OO], ks, H);
-                dOo_sh[row] = d;
-                reinterpret_cast<__bf16*>(P.dOo)[r * L.ld_oo] = (__bf16)d;
+                d = pres_backward(grec[row][REC - 1] + bd[BD_GPR], zp_sh[row], bd[BD_ST + ST_PZ], kl, bd[BD_OO], ks, H);
+                if (l == 0) reinterpret_cast<__bf16*>(P.dOo)[(size_t)row_r[row] * L.ld_oo] = (__bf16)d;
+            }
+            if (l < 25) {
+                const float4 w = *reinterpret_cast<const float4*>(&wobj_sh[l * 4]);
+                const int hs = (l & 3) * 16 + row;                                                           // bit of (column group, row)
+                const unsigned int hb = (unsigned int)((mbo01[0] >> hs) & 1ull) | ((unsigned int)((mbo01[1] >> hs) & 1ull) << 1) |
+                                        ((unsigned int)((mbo23[0] >> hs) & 1ull) << 2) | ((unsigned int)((mbo23[1] >> hs) & 1ull) << 3);
+                bf16x4 o;
+                o[0] = (__bf16)((hb & 1u) ? d * w.x : 0.f); o[1] = (__bf16)((hb & 2u) ? d * w.y : 0.f);
+                o[2] = (__bf16)((hb & 4u) ? d * w.z : 0.f); o[3] = (__bf16)((hb & 8u) ? d * w.w : 0.f);
+                if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dHo2) + (size_t)row_r[row] * SP_LDH + l * 4) = o;
+                *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + l * 4]) = o;
             }
         }
-        lds_barrier();
-        CB_STAMP();
         if (tid < MB_TILES * 4) mb_sh[tid] = mbq;            // first consumer is behind the next barrier
-        // ---- obj net: dHo2 = dOo (x) W_out (rank 1), masked by relu: the thread that prefetched a float4 of Ho2 produces those 4
-        // elements (no LDS round trip for this mask)
-        if (tid < MT * 25) {
-            const int row = tid / 25, q4 = tid - row * 25;
-            const float4 w = *reinterpret_cast<const float4*>(&wobj_sh[q4 * 4]);
-            const float d = row < nc ? dOo_sh[row] : 0.f;
-            const unsigned int hb = (unsigned int)(mbo >> ((row >> 2) * 16 + (q4 & 3) * 4)) & 15u;      // bits of columns 4*q4 .. 4*q4+3
-            const float4 v = make_float4((hb & 1u) ? d * w.x : 0.f, (hb & 2u) ? d * w.y : 0.f, (hb & 4u) ? d * w.z : 0.f, (hb & 8u) ? d * w.w : 0.f);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-            if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dHo2) + (size_t)row_r[row] * SP_LDH + q4 * 4) = o;
-            *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + q4 * 4]) = o;
-        }
         lds_barrier();
         CB_STAMP();
         // 7-tile layers: the 8th wave has no tile; the layer-output gradient (bf16 in LDS) is copied to HBM by that wave one stage later

@@ -864,7 +864,7 @@ static int cells_fwd(Ctx& c) {
         a.bias[CW_Z0] = pr + PL.lin[LIN_Z0].b; a.bias[CW_Z1] = pr + PL.lin[LIN_Z1].b; a.bias[CW_ZH] = c.w.bias_zh;
         a.bias[CW_OBJ0] = pr + PL.lin[LIN_OBJ0].b; a.bias[CW_OBJ1] = pr + PL.lin[LIN_OBJ1].b; a.bias[CW_OBJ2] = pr + PL.lin[LIN_OBJ2].b;
         a.x = c.x; a.I = c.d.I; a.Pp = c.d.P; a.ac = c.d.align_corners;
-        a.w_obj2 = nullptr; a.gedge = nullptr; a.stamps = (c.st.flags & 2) ? c.w.stamps : nullptr;
+        a.w_obj2 = pr + PL.lin[LIN_OBJ2].w; a.gedge = nullptr; a.stamps = (c.st.flags & 2) ? c.w.stamps : nullptr;
         for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = nullptr;
         return chain_fwd(a, c.s);
     }
@@ -1268,6 +1268,14 @@ extern "C" int spair_chain_stamps(const SpairDims* d, const void* workspace, uns
     TRY(validate(*d));
     const Ws w = carve(*d, const_cast<void*>(workspace));
     if (hipMemcpyAsync(out, w.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    return SPAIR_OK;
+}
+
+// diagnostic: how the stamp buffer is laid out -- stamps per wavefront of the forward kernel (at offset 0), index of the glimpse-sampling
+// interval among its stage intervals (K4), stamps per wavefront of the backward kernel (at offset 2048)
+extern "C" int spair_chain_stamp_layout(int* fwd_per_wavefront, int* fwd_glimpse_interval, int* bwd_per_wavefront) {
+    if (!fwd_per_wavefront || !fwd_glimpse_interval || !bwd_per_wavefront) return SPAIR_ERR_SHAPE;
+    *fwd_per_wavefront = CHAIN_FWD_STAMPS; *fwd_glimpse_interval = CHAIN_FWD_GLIMPSE; *bwd_per_wavefront = CHAIN_BWD_STAMPS;
     return SPAIR_OK;
 }
 

@@ -17,24 +17,26 @@ for _ in range(2):
 torch.cuda.synchronize()
 e = m._last["engine"]
 T = 3 * 16 - 2
-NS = 20
+_ns, _gl, _nb = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+L.check(L.lib().spair_chain_stamp_layout(ctypes.byref(_ns), ctypes.byref(_gl), ctypes.byref(_nb)), "stamp_layout")
+NS = _ns.value
 out = torch.zeros(4096, dtype=torch.int64, device="cuda")
 L.check(L.lib().spair_chain_stamps(ctypes.byref(e["dims"]), L.ptr(e["workspace"]), L.ptr(out), T * NS, L.stream()), "stamps")
 st = out.cpu().numpy()[:T * NS].reshape(T, NS).astype(np.float64)
 d = np.diff(st, axis=1)          # [T, NS-1] stage durations in s_memtime ticks (100 MHz => 10 ns)
-names = ["rows", "S0 ctx", "BOX0", "BOX1", "BOXH", "box", "glimpse", "ENC0", "ENC1", "ENC2", "attr", "Z0", "Z1", "ZH", "depth", "OBJ0", "OBJ1", "OBJ2", "pres"]
+names = ["rows", "S0 ctx", "BOX0", "BOX1", "BOXH+box", "glimpse", "ENC0", "ENC1", "ENC2", "attr", "Z0", "Z1", "ZH+depth", "OBJ0", "OBJ1+obj2", "pres"]
 tick_ns = 1.0 / 2.1   # s_memtime counts shader cycles (~2.1 GHz under load): report in us assuming that clock
-print("per-wavefront mean stage time (us), over %d wavefronts; total %.1f us/step" % (T, d[:, :19].sum(1).mean() * tick_ns / 1e3))
-for i in range(19):
+print("per-wavefront mean stage time (us), over %d wavefronts; total %.1f us/step" % (T, d[:, :NS - 1].sum(1).mean() * tick_ns / 1e3))
+for i in range(NS - 1):
     print("%-8s %7.2f" % (names[i], d[:, i].mean() * tick_ns / 1e3))
 print("step-to-step (incl. loop overhead): %.2f us" % (np.diff(st[:, 0]).mean() * tick_ns / 1e3))
 
-NB = int(os.environ.get("NB_STAGES", "20"))
+NB = _nb.value
 out2 = torch.zeros(4096, dtype=torch.int64, device="cuda")
 L.check(L.lib().spair_chain_stamps(ctypes.byref(e["dims"]), L.ptr(e["workspace"]), L.ptr(out2), 4096, L.stream()), "stamps")
 sb = out2.cpu().numpy()[2048:2048 + T * NB].reshape(T, NB).astype(np.float64)
 db = np.diff(sb, axis=1)
-bn = ["rows", "grec", "pres", "dHo2", "OBJ1", "OBJ0", "depth", "ZH", "Z1", "Z0", "attr", "ENC2", "ENC1", "ENC0+stn", "box", "BOXH", "BOX1", "BOX0", "dfeat/edge"]
+bn = ["rows", "grec", "pres+dHo2", "OBJ1", "OBJ0", "depth", "ZH", "Z1", "Z0", "attr", "ENC2", "ENC1", "ENC0+stn", "box", "BOXH", "BOX1", "BOX0", "dfeat/edge"]
 print("backward: total %.1f us/step" % (db.sum(1).mean() * tick_ns / 1e3))
 for i in range(db.shape[1]):
     print("%-10s %7.2f" % (bn[i] if i < len(bn) else "?", db[:, i].mean() * tick_ns / 1e3))
