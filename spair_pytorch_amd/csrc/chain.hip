@@ -151,6 +151,44 @@ __device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, floa
 }
 
 
+// ---- chain-local fast math.  The latent transforms sit on the critical path of a 46-step dependent chain as ~120-instruction sequences of
+// one or four waves (IEEE division = 10 instructions, expf = 12): here they are v_exp_f32 / v_rcp_f32 / v_log_f32 forms, ~1 ulp each --
+// far inside what the bf16 operands of the surrounding GEMMs do to the same values (the fp32 parity mode never runs these kernels).
+#ifdef CH_EXACT_MATH
+__device__ __forceinline__ float ch_sigmoid(float x) { return sigmoidf_(x); }
+__device__ __forceinline__ float ch_log(float x) { return logf(x); }
+#else
+__device__ __forceinline__ float ch_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
+__device__ __forceinline__ float ch_log(float x) { return 0.693147180559945f * __builtin_amdgcn_logf(x); }
+#endif
+
+// The store wave's row copier: PIECES pieces of PB (8 or 16) bytes per row, LDS -> HBM row buffer.  Eight lanes serve one row (a pass
+// covers 8 rows: every row of a wavefront on grids up to 16 x 16), so the row's base addresses are formed once and every further piece
+// is an instruction-immediate offset on both sides: 2 instructions per 64 pieces, all LDS reads of the pass issued before its first store
+// (a serial read -> wait -> store loop with a division per piece made the store wave the slowest wave of the 7-tile stages).
+template <int PIECES, int PB>
+__device__ __forceinline__ void copy_rows8(const void* lds_, int lds_pitch, void* hbm_, unsigned hbm_pitch, const int* row_r, int r0, int nc, int lane) {
+    constexpr int NI = (PIECES + 7) / 8;
+    typedef unsigned int uv __attribute__((ext_vector_type(PB / 4)));
+    const int row = r0 + (lane >> 3), p0 = lane & 7;
+    const char* src = reinterpret_cast<const char*>(lds_) + row * lds_pitch + p0 * PB;
+    char* dst = reinterpret_cast<char*>(hbm_) + ((unsigned)row_r[row] * hbm_pitch + (unsigned)(p0 * PB));      // every row buffer is < 4 GB
+    uv v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        if (8 * (i + 1) <= PIECES || p0 + 8 * i < PIECES) v[i] = *reinterpret_cast<const uv*>(src + i * 8 * PB);
+    if (row < nc) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (8 * (i + 1) <= PIECES || p0 + 8 * i < PIECES) CH_GSTORE(reinterpret_cast<uv*>(dst + i * 8 * PB), v[i]);
+    }
+}
+template <int PIECES, int PB>
+__device__ __forceinline__ void copy_rows_w(const void* lds, int lds_pitch, void* hbm, size_t hbm_pitch, const int* row_r, int nc, int lane) {
+    copy_rows8<PIECES, PB>(lds, lds_pitch, hbm, (unsigned)hbm_pitch, row_r, 0, nc, lane);
+    if (nc > 8) copy_rows8<PIECES, PB>(lds, lds_pitch, hbm, (unsigned)hbm_pitch, row_r, 8, nc, lane);
+}
+
 // ---- lean GEMM stage, TRANSPOSED MFMA form (round 4) --------------------------------------------------------------------------------------
 // The chain kernels are bound by the instruction streams of their ~16 dependent stages (ablation: with every weight load removed the forward
 // kernel still takes 0.63 of its 0.84 ms; a 4-k-step layer ran ~140 instructions per wave at ~9 cycles each), not by the weight stream.  The
@@ -274,8 +312,10 @@ template <bool IMG>
 __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float bias_sh[BIAS_TOT];
     __shared__ __attribute__((aligned(16))) float edge_sh[REC];
+    // features of the next wavefront, parked at the end of the current one and read by its S0 stage only: in between the same floats stage
+    // the rows' sd_attr (16 x 52) and stat (16 x 12) values for the store wave
     __shared__ __attribute__((aligned(16))) float feat_sh[MT][F];
-    __shared__ __attribute__((aligned(16))) float noise_sh[MT][REC];      // [eps_box 4 | eps_attr A | eps_depth | u_pres]
+    __shared__ __attribute__((aligned(16))) float noise_sh[MT][REC];      // [eps_box 4 | eps_attr A | eps_depth | logit(u_pres)]
     __shared__ unsigned short cell_hw[32 * 32];
     __shared__ float pbase_sh[32];                                         // base coordinate of glimpse index j (stn_base), no division per element
     __shared__ __attribute__((aligned(16))) unsigned long long mbf_sh[MB_TILES * 4];
@@ -288,13 +328,14 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Hb[MT * LD_H];
     __shared__ __attribute__((aligned(16))) float Ost[MT * LD_O];
     __shared__ __attribute__((aligned(16))) float recs[4][MT][REC];
-    __shared__ float nb_sh[MT][4];
+    __shared__ __attribute__((aligned(16))) float nb_sh[MT][4];
     __shared__ __attribute__((aligned(16))) uint2 gtab[MT][2][PG];          // glimpse source coordinates per (row, axis, index)
-    __shared__ int row_r[MT], row_h[MT], row_w[MT], row_cp[MT];
+    __shared__ int row_r[2][MT], row_hw[2][MT], row_cp[MT];                 // row tables of the current ([t & 1]) and the previous wavefront
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ short nbr_sh[32 * 32 * 4];
-    __shared__ float w2_sh[7 * 16];             // obj_network.out.weight as the bf16 values the MFMA path would multiply by (0 past column 99)
-    __shared__ float opart[7][4][MT];           // partial presence logits per (wave, column group of its tile, row) (OBJ1's epilogue)
+    __shared__ __attribute__((aligned(16))) float w2_sh[7 * 16];            // obj_network.out.weight as the bf16 values the MFMA path would multiply by (0 past column 99)
+    __shared__ __attribute__((aligned(16))) float opart[MT][28];            // partial presence logits: row x (wave, column group of its tile) (OBJ1's epilogue)
+    __shared__ float logit_sh[MT];
 
     const CellLayout& L = a.L;
     const CellBufs& P = a.P;
@@ -304,6 +345,10 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
+    float* const sd_stage = &feat_sh[0][0];                    // [MT][52]
+    float* const stat_stage = &feat_sh[0][0] + MT * 52;        // [MT][12]: mu_box 4 | sd_box 4 | mu_depth | sd_depth | 0 | 0
+    constexpr int LD_SD = 52, LD_ST = 12;
+    static_assert(MT * (52 + 12) <= MT * F, "staging fits the feature tile");
 
     if (tid < 7 * 16) w2_sh[tid] = tid < 100 ? (float)(__bf16)a.w_obj2[tid] : 0.f;
     for (int i = tid; i < MT * LD_XC; i += NTH) Xc[i] = (__bf16)0.f;
@@ -341,19 +386,20 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const int pf_frow = min(tid0, MT * (F / 4) - 1) / (F / 4), pf_fc4 = (min(tid0, MT * (F / 4) - 1) - pf_frow * (F / 4)) * 4;
     int pf_nrow[2];
     const float* pf_nsrc[2];
+    bool pf_isu[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = min(tid0 + q * NTH, MT * REC - 1);
         const int row = i / REC, j = i - row * REC;
         pf_nrow[q] = row;
+        pf_isu[q] = j == REC - 1;
         pf_nsrc[q] = j < 4        ? P.eps_box + ((size_t)b * 4 + j) * G * G
                      : j < 4 + A_ ? P.eps_attr + ((size_t)b * A_ + (j - 4)) * G * G
                      : j == 4 + A_ ? P.eps_depth + (size_t)b * G * G
                                    : P.u_pres + (size_t)b * G * G;
     }
-    auto prefetch = [&](int tn, int tidv) {       // branch-free (clamped indices): conditional loads would make every later wait on the
+    auto prefetch = [&](int tn) {                 // branch-free (clamped indices): conditional loads would make every later wait on the
                                                   // weight ring a vmcnt(0), i.e. a wait for THESE loads
-        (void)tidv;
         const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
         {
             const int hw = cell_hw[c0n + min(pf_frow, ncn - 1)];
@@ -373,15 +419,37 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = tidv + q * NTH;
-            if (i < MT * REC) noise_sh[i / REC][i % REC] = pf_noise[q];
+            // the presence noise is parked as the logistic noise it becomes (models.py:402-409): log(u + 1e-9) - log(1 - u + 1e-9), here,
+            // off the chain, instead of two logarithms inside the presence stage
+            const float v = pf_isu[q] ? ch_log(pf_noise[q] + 1e-9f) - ch_log(1.f - pf_noise[q] + 1e-9f) : pf_noise[q];
+            if (i < MT * REC) noise_sh[i / REC][i % REC] = v;
         }
     };
-    prefetch(0, tid);
+    prefetch(0);
     park(tid);
 
+    // The store wave's end-of-wavefront flush (one wavefront late, beside BOX0): the record rows, the box, the presence logit and the
+    // two output maps of wavefront tp, whose row tables sit in slot tp & 1.  Everything a latent stage produces goes to LDS only.
+    auto flush_records = [&](int tp, int ncp, int ln) {
+        const int* rr = row_r[tp & 1];
+        copy_rows_w<REC / 4, 16>(&recs[tp & 3][0][0], REC * 4, P.rec, (size_t)L.ld_rec * 4, rr, ncp, ln);
+        if (ln < 4 * ncp) {        // lane (row, k): nbox element k and its z_where map entry
+            const int row = ln >> 2, k = ln & 3, hw = row_hw[tp & 1][row];
+            const float nv = nb_sh[row][k];
+            P.nbox[(size_t)rr[row] * 4 + k] = nv;
+            P.z_where[(((size_t)b * 4 + k) * G + (hw >> 8)) * G + (hw & 255)] = nv;
+        }
+        if (ln < ncp) {
+            const int hw = row_hw[tp & 1][ln];
+            P.Oo[(size_t)rr[ln] * L.ld_oo] = logit_sh[ln];
+            P.z_pres[((size_t)b * G + (hw >> 8)) * G + (hw & 255)] = recs[tp & 3][ln][REC - 1];
+        }
+    };
+
     WPipe pipe;
-    pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
+    pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);      // (all eight waves here: the ring registers must be defined on every path)
     int stamp_i = 0;
+    int nc_prev = 0;
 #define CH_STAMP() do { if (a.stamps && b == 0 && tid == 0) a.stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int t = 0; t < T; ++t) {
         // opaque per-iteration copies: keeps LICM from hoisting every layer's lane-dependent address arithmetic out of the
@@ -394,53 +462,47 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         const int nc = dstart_sh[t + 1] - c0;
         unsigned long long* const mbt = mbf_sh;                 // sign-bit ballots of this wavefront, flushed to HBM at its end
         float (*rec_cur)[REC] = recs[t & 3];
+        int* const rr_cur = row_r[t & 1];
+        int* const hw_cur = row_hw[t & 1];
         if (tid < MT) {
             const int cp = c0 + min(tid, nc - 1);
-            const int hw = cell_hw[cp];
             row_cp[tid] = cp;
-            row_r[tid] = cp * L.B + b;
-            row_h[tid] = hw >> 8;
-            row_w[tid] = hw & 255;
+            rr_cur[tid] = cp * L.B + b;
+            hw_cur[tid] = cell_hw[cp];
         }
         lds_barrier();                       // also orders park() of the previous wavefront before S0's reads
-        prefetch(min(t + 1, T - 1), tid);
+        prefetch(min(t + 1, T - 1));
         CH_STAMP();
-        // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread
+        // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread, LDS only (the store wave copies the finished rows to
+        // the Xb row buffer beside BOX0)
         // (only the wavefront's nc live rows: the tile's other rows keep whatever finite values an earlier wavefront left -- their
         //  outputs are never stored)
-        for (int idx = tid; idx < nc * (KC / 4); idx += NTH) {
-            const int row = idx / (KC / 4), c4 = (idx - row * (KC / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c4 < F + CTX) {
-                if (c4 < F) {
-                    v = *reinterpret_cast<const float4*>(&feat_sh[row][c4]);
-                } else {
-                    const int s = (c4 - F) / REC, j = (c4 - F) - s * REC;
-                    const int nbc = nbr_sh[row_cp[row] * 4 + s];
-                    if (nbc >= 0) {
-                        const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);      // UL: t-3, U: t-2, UR and L: t-1
-                        v = *reinterpret_cast<const float4*>(&recs[(t - dt) & 3][nbc - dstart_sh[t - dt]][j]);
-                    } else {
-                        v = *reinterpret_cast<const float4*>(&edge_sh[j]);
-                    }
-                }
-                const size_t r = row_r[row];
-                // (every operand of the weight-gradient GEMMs is stored as bf16 by this kernel: same leading dimensions in elements,
-                //  the buffers are sized for the per-wavefront path's fp32; the z / obj nets read these columns from Xb too)
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.Xb) + r * L.ld_xb + c4) = pack4(v.x, v.y, v.z, v.w);
+        for (int idx = tid; idx < nc * ((F + CTX) / 4); idx += NTH) {
+            const int row = idx / ((F + CTX) / 4), c4 = (idx - row * ((F + CTX) / 4)) * 4;
+            float4 v;
+            if (c4 < F) {
+                v = *reinterpret_cast<const float4*>(&feat_sh[row][c4]);
+            } else {
+                const int s = (c4 - F) / REC, j = (c4 - F) - s * REC;
+                const int nbc = nbr_sh[row_cp[row] * 4 + s];
+                const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);      // UL: t-3, U: t-2, UR and L: t-1
+                const float* src = nbc >= 0 ? &recs[(t - dt) & 3][nbc - dstart_sh[max(t - dt, 0)]][j] : &edge_sh[j];
+                v = *reinterpret_cast<const float4*>(src);
             }
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-            *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = o;
+            *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = pack4(v.x, v.y, v.z, v.w);
         }
         lds_barrier();
         CH_STAMP();
         // ---- z_where: box MLP (models.py:76-77)
-        {
+        if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, bias_sh + BIAS_OFF[CW_BOX0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HB1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB1 * 4);
+        } else {
+            // (every operand of the weight-gradient GEMMs is stored as bf16 by this kernel: same leading dimensions in elements, the buffers
+            //  are sized for the per-wavefront path's fp32; the z / obj nets read these columns from Xb too)
+            if (t > 0) flush_records(t - 1, nc_prev, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -448,9 +510,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, bias_sh + BIAS_OFF[CW_BOX1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HB2 * 4);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB2 * 4);
         } else {
-            copy_rows_b16<100>(Ha, LD_H, P.Hb1, SP_LDH, row_r, nc, lane);
+            copy_rows_w<25, 8>(Ha, LD_H * 2, P.Hb1, (size_t)SP_LDH * 2, rr_cur, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -460,44 +522,38 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, bias_sh + BIAS_OFF[CW_BOXH], acc, wave, lane);
-            pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
-            wg_store_t<7, false>(acc, NP + 8, XtZ, LD_XT, NP, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
+            wg_store_t<7, false>(acc, NP + 8, XtZ, LD_XT, NP, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         } else {
-            pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
-            copy_rows_b16<100>(Hb, LD_H, P.Hb2, SP_LDH, row_r, nc, lane);
+            copy_rows_w<25, 8>(Hb, LD_H * 2, P.Hb2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
+            copy_rows_w<(F + CTX + 4) / 8, 16>(Xc, LD_XC * 2, P.Xb, (size_t)L.ld_xb * 2, rr_cur, nc, lane);      // (beside wave 6's latent pass)
         }
+        pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
         // ---- box latents (models.py:322-381): one latent per lane of wave 6; lane k of a row owns z_k -> (cell_y, cell_x, height, width)[k]
-        // -> box / nbox element k ^ 1
+        // -> box / nbox element k ^ 1.  LDS only: records, stats and the box reach HBM through the store wave.
         if (wave == 6) {
             wave_lds_sync();                      // this wave's own Ost columns
             if (lane < 4 * nc) {
                 const int row = lane >> 2, k = lane & 3, o = k ^ 1;
-                const int h = row_h[row], w = row_w[row];
-                const size_t r = row_r[row];
+                const int hw = hw_cur[row];
                 const float* lat = &Ost[row * LD_O + NP];
                 const float mu = freeze_val(H.wheel, lat[k]);
-                const float sd = freeze_val(H.wheel, 2.f * sigmoidf_(clamp10(lat[4 + k])));
-                const float sg = sigmoidf_(clamp10(mu + sd * noise_sh[row][k]));
+                const float sd = freeze_val(H.wheel, 2.f * ch_sigmoid(clamp10(lat[4 + k])));
+                const float sg = ch_sigmoid(clamp10(mu + sd * noise_sh[row][k]));
                 float bv, nv;                               // box_forward (cell_math.h), element by element
                 if (k < 2) {
                     bv = (H.max_yx - H.min_yx) * sg + H.min_yx;                         // cell_y (k = 0), cell_x (k = 1)
-                    nv = H.cell_over_img * (bv + (float)(k == 0 ? h : w));              // yt, xt
+                    nv = H.cell_over_img * (bv + (float)(k == 0 ? (hw >> 8) : (hw & 255)));      // yt, xt
                 } else {
                     bv = (H.max_hw - H.min_hw) * sg + H.min_hw;                         // height (k = 2), width (k = 3)
-                    nv = bv * H.anchor / H.img;                                         // ys, xs
+                    nv = bv * H.anchor / H.img;                                         // ys, xs (a true division, as the reference: the sampling
+                                                                                        // grid's floor() decisions downstream are sensitive to the last bit)
                 }
-                float* st = P.stat + r * SP_LDSTAT;
-                st[ST_MU_BOX + k] = mu;
-                st[ST_SD_BOX + k] = sd;
+                stat_stage[row * LD_ST + ST_MU_BOX + k] = mu;
+                stat_stage[row * LD_ST + ST_SD_BOX + k] = sd;
                 rec_cur[row][o] = bv;
                 nb_sh[row][o] = nv;
                 XtZ[row * LD_XT + NP + o] = (__bf16)bv;
                 XtO[row * LD_XT + NP + o] = (__bf16)bv;
-                P.rec[r * L.ld_rec + o] = bv;
-                reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
-                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_box + o] = (__bf16)bv;
-                P.nbox[r * 4 + o] = nv;
-                P.z_where[(((size_t)b * 4 + o) * G + h) * G + w] = nv;
             }
         }
         lds_barrier();
@@ -506,10 +562,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // The source coordinates are separable: 28 column and 28 row coordinates per cell, tabulated first (one entry per thread:
         // first tap index | "second tap inside" | "not clipped", fractional weight) instead of being re-derived by every element
         // (5 coordinate evaluations per 4 elements were ~40 % of the sampling stage's instructions).  Waves 0..6 build the table; the
-        // 8th copies the box head's output rows and the z-net's passthrough columns to HBM meanwhile.
+        // 8th copies the box head's output rows to HBM meanwhile.
         if (wave == 7) {
-            copy_rows_f32<NP + 8>(Ost, LD_O, P.Ob, L.ld_ob, row_r, nc, lane);
-            copy_rows_b16<100>(XtZ, LD_XT, reinterpret_cast<float*>(reinterpret_cast<__bf16*>(P.Xz) + L.x_pass), L.ld_x, row_r, nc, lane);
+            copy_rows_w<(NP + 8) / 4, 16>(Ost, LD_O * 4, P.Ob, (size_t)L.ld_ob * 4, rr_cur, nc, lane);
         } else {
             for (int e = tid; e < nc * 2 * PG; e += 7 * 64) {
                 const int row = e / (2 * PG), rem = e - row * (2 * PG), axis = rem >= PG ? 1 : 0, gi = rem - axis * PG;
@@ -563,17 +618,17 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             bf16x4 o;
             o[0] = (__bf16)out[0]; o[1] = (__bf16)out[1]; o[2] = (__bf16)out[2]; o[3] = (__bf16)out[3];
             *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
-            CH_GSTORE(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)row_r[row] * L.ld_gl + e), o);
-            CH_GSTORE(reinterpret_cast<u32x4_t*>(P.gxy + (size_t)row_r[row] * L.ld_gl + e), ((u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]}));
+            CH_GSTORE(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)rr_cur[row] * L.ld_gl + e), o);
+            CH_GSTORE(reinterpret_cast<u32x4_t*>(P.gxy + (size_t)rr_cur[row] * L.ld_gl + e), ((u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]}));
         }
         lds_barrier();
         CH_STAMP();
-        {   // 256 outputs = 16 tiles: two half-layers of 8 tiles, one tile per wave each
+        {   // 256 outputs = 16 tiles, two per wave sharing every glimpse fragment
             f32x4 acc0, acc1;
             wg_gemm_t2<25, 5>(Gl, LD_GL, a.w[CW_ENC0], pipe, bias_sh + BIAS_OFF[CW_ENC0], acc0, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
-            wg_store_t<16, true, 0>(acc0, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
-            wg_store_t<16, true, 8>(acc1, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, row_r, nc, wave, lane, mbt + MB_HE1 * 4);
+            wg_store_t<16, true, 0>(acc0, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, rr_cur, nc, wave, lane, mbt + MB_HE1 * 4);
+            wg_store_t<16, true, 8>(acc1, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, rr_cur, nc, wave, lane, mbt + MB_HE1 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -581,7 +636,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm_t<8, 0, 8>(Ha, LD_H, nullptr, 0, a.w[CW_ENC1], pipe, bias_sh + BIAS_OFF[CW_ENC1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ENC2], pipe, wave, lane);
-            wg_store_t<8, true>(acc, 128, Hb, LD_H, 128, nullptr, 0, reinterpret_cast<__bf16*>(P.He2), SP_ENC_H2, row_r, nc, wave, lane, mbt + MB_HE2 * 4);
+            wg_store_t<8, true>(acc, 128, Hb, LD_H, 128, nullptr, 0, reinterpret_cast<__bf16*>(P.He2), SP_ENC_H2, rr_cur, nc, wave, lane, mbt + MB_HE2 * 4);
         }
         lds_barrier();
         CH_STAMP();
@@ -589,40 +644,34 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, bias_sh + BIAS_OFF[CW_ENC2], acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
-            wg_store_t<7, false>(acc, 2 * A_, nullptr, 0, 0, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
-        } else {
-            (void)0;
+            wg_store_t<7, false>(acc, 2 * A_, nullptr, 0, 0, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         }
         lds_barrier();
         CH_STAMP();
-        // ---- attributes (models.py:83-85)
-        if (wave == 7) copy_rows_f32<2 * A_>(Ost, LD_O, P.Oe, L.ld_oe, row_r, nc, lane);
+        // ---- attributes (models.py:83-85): LDS only
+        if (wave == 7) copy_rows_w<(2 * A_) / 4, 16>(Ost, LD_O * 4, P.Oe, (size_t)L.ld_oe * 4, rr_cur, nc, lane);
         for (int idx = tid; idx < nc * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
-            const size_t r = row_r[row];
-            const float eps = noise_sh[row][4 + j];
-            float sd, attr;
-            attr_forward(Ost[row * LD_O + j], Ost[row * LD_O + A_ + j], eps, sd, attr);
+            const float sd = 2.f * ch_sigmoid(clamp10(Ost[row * LD_O + A_ + j]));
+            const float attr = Ost[row * LD_O + j] + sd * noise_sh[row][4 + j];
+            const __bf16 ab = (__bf16)attr;
             rec_cur[row][4 + j] = attr;
-            XtZ[row * LD_XT + NP + 4 + j] = (__bf16)attr;
-            XtO[row * LD_XT + NP + 4 + j] = (__bf16)attr;
-            P.sd_attr[r * L.ld_rec + j] = sd;
-            P.rec[r * L.ld_rec + 4 + j] = attr;
-            P.Za[r * L.ld_rec + j] = attr;
-            reinterpret_cast<__bf16*>(P.Za16)[r * L.ld_rec + j] = (__bf16)attr;      // decoder input, no conversion pass
-            reinterpret_cast<__bf16*>(P.Xz)[r * L.ld_x + L.x_attr + j] = (__bf16)attr;
-            reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_attr + j] = (__bf16)attr;
+            XtZ[row * LD_XT + NP + 4 + j] = ab;
+            XtO[row * LD_XT + NP + 4 + j] = ab;
+            sd_stage[row * LD_SD + j] = sd;
+            if (j < 2) sd_stage[row * LD_SD + A_ + j] = 0.f;      // the copied row is 52 wide
         }
         lds_barrier();
         CH_STAMP();
-        // ---- z_depth (models.py:88-97)
+        // ---- z_depth (models.py:88-97); the store wave: the z-net's whole input tail [pass | box | attr] (a stage later: the decoder's input
+        // rows -- the attr columns of the same tile, their two pad columns being the tile's zero depth / pad slots -- and sd_attr)
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, bias_sh + BIAS_OFF[CW_Z0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HZ1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HZ1 * 4);
         } else {
-            (void)0;
+            copy_rows_w<39, 8>(XtZ, LD_XT * 2, reinterpret_cast<__bf16*>(P.Xz) + L.x_pass, (size_t)L.ld_x * 2, rr_cur, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -630,9 +679,11 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_Z1], pipe, bias_sh + BIAS_OFF[CW_Z1], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_ZH], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HZ2 * 4);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HZ2 * 4);
         } else {
-            copy_rows_b16<100>(Ha, LD_H, P.Hz1, SP_LDH, row_r, nc, lane);
+            copy_rows_w<25, 8>(Ha, LD_H * 2, P.Hz1, (size_t)SP_LDH * 2, rr_cur, nc, lane);
+            copy_rows_w<13, 8>(XtZ + NP + 4, LD_XT * 2, P.Za16, (size_t)L.ld_rec * 2, rr_cur, nc, lane);
+            copy_rows_w<13, 16>(sd_stage, LD_SD * 4, P.sd_attr, (size_t)L.ld_rec * 4, rr_cur, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -641,82 +692,81 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, bias_sh + BIAS_OFF[CW_ZH], acc, wave, lane);
             pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
-            wg_store_t<7, false>(acc, NP + 4, XtO, LD_XT, NP, Ost, LD_O, nullptr, 0, row_r, nc, wave, lane);
+            wg_store_t<7, false>(acc, NP + 4, XtO, LD_XT, NP, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         } else {
-            copy_rows_b16<100>(Hb, LD_H, P.Hz2, SP_LDH, row_r, nc, lane);
+            copy_rows_w<25, 8>(Hb, LD_H * 2, P.Hz2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
         }
         if (wave == 6) {
             wave_lds_sync();
             if (lane < nc) {
-                const size_t r = row_r[lane];
-                const float eps = noise_sh[lane][4 + A_];
-                float mu, sd, depth;
-                depth_forward(Ost[lane * LD_O + NP], Ost[lane * LD_O + NP + 1], eps, H, mu, sd, depth);
-                float* st = P.stat + r * SP_LDSTAT;
-                st[ST_MU_DEPTH] = mu;
-                st[ST_SD_DEPTH] = sd;
+                const float mu = freeze_val(H.wheel, Ost[lane * LD_O + NP]);
+                const float sd = freeze_val(H.wheel, 2.f * ch_sigmoid(clamp10(Ost[lane * LD_O + NP + 1])));
+                const float depth = 4.f * ch_sigmoid(clamp10(mu + sd * noise_sh[lane][4 + A_]));
+                stat_stage[lane * LD_ST + ST_MU_DEPTH] = mu;
+                stat_stage[lane * LD_ST + ST_SD_DEPTH] = sd;
+                stat_stage[lane * LD_ST + 10] = 0.f;
+                stat_stage[lane * LD_ST + 11] = 0.f;
                 rec_cur[lane][4 + A_] = depth;
                 XtO[lane * LD_XT + NP + 4 + A_] = (__bf16)depth;
-                P.rec[r * L.ld_rec + 4 + A_] = depth;
-                reinterpret_cast<__bf16*>(P.Xo)[r * L.ld_x + L.x_depth] = (__bf16)depth;
             }
         }
         lds_barrier();
         CH_STAMP();
-        // ---- z_pres (models.py:100-102,393-411)
+        // ---- z_pres (models.py:100-102,393-411); the store wave: z head rows, the obj-net's input tail [pass | box | attr | depth]
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, bias_sh + BIAS_OFF[CW_OBJ0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HO1 * 4);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HO1 * 4);
         } else {
-            copy_rows_f32<NP + 4>(Ost, LD_O, P.Oz, L.ld_oz, row_r, nc, lane);      // 102 used columns, the row holds 104
-            copy_rows_b16<100>(XtO, LD_XT, reinterpret_cast<float*>(reinterpret_cast<__bf16*>(P.Xo) + L.x_pass), L.ld_x, row_r, nc, lane);
+            copy_rows_w<(NP + 4) / 4, 16>(Ost, LD_O * 4, P.Oz, (size_t)L.ld_oz * 4, rr_cur, nc, lane);      // 102 used columns, the row holds 104
         }
         lds_barrier();
         CH_STAMP();
         // this row's presence noise, read now: the pres stage below shares its barrier interval with park(), which overwrites noise_sh
         const float u_pres_reg = noise_sh[min(tid, MT - 1)][4 + A_ + 1];
         // OBJ1, and the one-column output layer with it: each lane multiplies its four (bf16-rounded, as the MFMA would see them) hidden values by
-        // the output weight of its column, a DPP reduction over the 16 columns of the tile leaves one partial logit per (wave, row) -- a
-        // 100 -> 1 layer as an MFMA stage of its own cost a full barrier interval (0.9 us) for one useful output column
+        // the output weight of its column -- a 100 -> 1 layer as an MFMA stage of its own cost a full barrier interval (0.9 us) for one
+        // useful output column.  One partial per (row, wave, column group); the presence stage adds the 28 of a row.
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, bias_sh + BIAS_OFF[CW_OBJ1], acc, wave, lane);
             pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, row_r, nc, wave, lane, mbt + MB_HO2 * 4);
-            // this lane's four columns of its row against the output weights (both as the bf16 values an MFMA would see): one partial per
-            // (wave, column group, row); the presence stage adds the 28 of a row
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HO2 * 4);
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2_sh + wave * 16 + (lane >> 4) * 4);
             float pz = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pz = fmaf((float)(__bf16)fmaxf(acc[r], 0.f), w2[r], pz);
-            opart[wave][lane >> 4][lane & 15] = pz;
+            opart[lane & 15][wave * 4 + (lane >> 4)] = pz;
         } else {
-            copy_rows_b16<100>(Ha, LD_H, P.Ho1, SP_LDH, row_r, nc, lane);
+            copy_rows_w<25, 8>(Ha, LD_H * 2, P.Ho1, (size_t)SP_LDH * 2, rr_cur, nc, lane);
+            copy_rows_w<3, 16>(stat_stage, LD_ST * 4, P.stat, (size_t)SP_LDSTAT * 4, rr_cur, nc, lane);
+            copy_rows_w<39, 8>(XtO, LD_XT * 2, reinterpret_cast<__bf16*>(P.Xo) + L.x_pass, (size_t)L.ld_x * 2, rr_cur, nc, lane);
         }
         lds_barrier();
         CH_STAMP();
         if (tid < nc) {
-            const int h = row_h[tid], w = row_w[tid];
-            const size_t r = row_r[tid];
-            float logit = 0.f;
+            float logit = bias_sh[BIAS_OFF[CW_OBJ2]];
 #pragma unroll
-            for (int q = 0; q < 28; ++q) logit += (&opart[0][0][0])[q * MT + tid];
-            logit += bias_sh[BIAS_OFF[CW_OBJ2]];
-            const float pres = pres_forward(logit, u_pres_reg, H);
-            P.Oo[r * L.ld_oo] = logit;
+            for (int q = 0; q < 7; ++q) {
+                const f32x4 pq = *reinterpret_cast<const f32x4*>(&opart[tid][q * 4]);
+                logit += (pq[0] + pq[1]) + (pq[2] + pq[3]);
+            }
+            // pres_forward (cell_math.h) with the logistic noise already formed at park time
+            const float pres = ch_sigmoid(clamp10(freeze_val(H.wheel, logit)) + u_pres_reg);
+            logit_sh[tid] = logit;
             rec_cur[tid][REC - 1] = pres;
-            P.rec[r * L.ld_rec + REC - 1] = pres;
-            P.z_pres[((size_t)b * G + h) * G + w] = pres;
         }
-        if (wave == 7) copy_rows_b16<100>(Hb, LD_H, P.Ho2, SP_LDH, row_r, nc, lane);
+        if (wave == 7) copy_rows_w<25, 8>(Hb, LD_H * 2, P.Ho2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
         // (no barrier: nothing below reads what the pres threads write, and they no longer read noise_sh; the next wavefront's row-setup
         //  barrier orders all of it before S0)
         park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
         if (tid < MB_TILES * 4) P.mbits[((size_t)b * T + t) * (MB_TILES * 4) + tid] = mbf_sh[tid];     // one coalesced 2 KB store
+        nc_prev = nc;
         CH_STAMP();
     }
+    lds_barrier();
+    if (wave == 7) flush_records(T - 1, nc_prev, tid0 & 63);
 }
 
 
