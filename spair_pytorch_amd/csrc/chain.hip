@@ -786,94 +786,70 @@ namespace {
 
 constexpr int LD_R = 328;      // ring row: [feat 100 | ctx 224] fp32
 
-// out[16, NT*16] = in[16, 32*KT] . Wt ; wide-N / short-K form: A fragments held in registers, column tiles streamed with a 2-tile
-// weight-fragment double buffer; `epi(nt, acc)` consumes each tile as soon as it is complete (it must ignore nt >= NT).
-// Straight-line between a tile's loads and its MFMAs (see wg_gemm): the trip count is the same for every wave and tiles past
-// the end are clamped, never branched around.
-// first weight tile (fragments 0..3) of the NEXT data-gradient GEMM, issued before the barrier that ends the current stage: the
-// GEMM then starts on registers that are already (being) filled instead of exposing an L2 round trip per stage
-struct WPre { uint4 q[4]; };
+// ---- backward GEMM stages, lean transposed form (see wg_gemm_t): out^T[n][row] = sum_k Wt[n][k] * in[row][k] with a wide N (7 .. 49 column
+// tiles, tile nt = wave + 8 j for this wave's j-th tile) and a short K (4 or 8 k-steps).  The gradient tile's fragments are read once per
+// stage; the weight fragments of ALL of this wave's tiles run through the same RD-deep register ring as in the forward kernel, in
+// (tile, k-step) order, refilled behind each MFMA; `mid()` is called once behind the stage's last MFMA and before its last epilogue -- the
+// place where the NEXT layer's first ring fill is issued (round 3 issued it behind the epilogue, at the barrier: every small stage then began
+// by waiting out an L2 round trip).  `epi(j, nt, acc)`: lane holds columns nt*16 + (lane>>4)*4 .. +3 of row lane & 15.
 template <int KT, int NT>
-__device__ __forceinline__ void wide_prefetch(const uint4* __restrict__ Wt, int wave, int lane, WPre& pre) {
-    const uint4* b0 = Wt + (size_t)min(wave, NT - 1) * KT * 64 + lane;
+__device__ __forceinline__ void pipe_fill_w(const uint4* __restrict__ Wt, WPipe& p, int wave, int lane) {
+    constexpr int MY = (NT + NW - 1) / NW, TOT = MY * KT;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) pre.q[kt] = b0[kt * 64];
+    for (int s_ = 0; s_ < RD; ++s_)
+        if (s_ < TOT) p.q[s_] = Wt[((size_t)min(wave + NW * (s_ / KT), NT - 1) * KT + (s_ % KT)) * 64 + lane];
 }
-
-template <int KT, int NT, class Epi>
-__device__ __forceinline__ void wg_gemm_wide(const __bf16* in, int ld, const uint4* __restrict__ Wt, int wave, int lane, Epi epi, const WPre& pre) {
-    // epi(j, nt, acc): j = ordinal of the tile within this wave (compile-time constant: the pair loop is fully unrolled so that
-    // per-tile data prefetched into registers can be indexed statically)
-    constexpr int MY = (NT + NW - 1) / NW, PAIRS = (MY + 1) / 2;
-    bf16x8 af[KT];
-    const int arow = lane & 15, kg = (lane >> 4) * 8;
+template <int KT, int NT, class Epi, class Mid>
+__device__ __forceinline__ void wg_gemm_wt(const __bf16* in, int ld, const uint4* __restrict__ Wt, WPipe& p, int wave, int lane, Epi epi, Mid mid) {
+    constexpr int MY = (NT + NW - 1) / NW, TOT = MY * KT;
+    const __bf16* pa = in + (lane & 15) * ld + (lane >> 4) * 8;
+    bf16x8 x[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) af[kt] = *reinterpret_cast<const bf16x8*>(in + arow * ld + kt * 32 + kg);
-    auto tile_ptr = [&](int nt) { return Wt + (size_t)min(nt, NT - 1) * KT * 64 + lane; };
-    uint4 bq[2][KT];
-    {
-        const uint4* b0 = tile_ptr(wave);
+    for (int kt = 0; kt < KT; ++kt) x[kt] = *reinterpret_cast<const bf16x8*>(pa + kt * 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < MY; ++j) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt < 4) bq[0][kt] = pre.q[kt];
-            else bq[0][kt] = b0[kt * 64];
+            const int s_ = j * KT + kt;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[s_ % RD]), x[kt], acc, 0, 0, 0);
+            if (s_ + RD < TOT)
+                p.q[s_ % RD] = Wt[((size_t)min(wave + NW * ((s_ + RD) / KT), NT - 1) * KT + ((s_ + RD) % KT)) * 64 + lane];
         }
-    }
-#pragma unroll
-    for (int pr = 0; pr < PAIRS; ++pr) {
-        const int nt0 = wave + 2 * pr * NW, nt1 = nt0 + NW, nt2 = nt0 + 2 * NW;
-        {
-            const uint4* b1 = tile_ptr(nt1);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) bq[1][kt] = b1[kt * 64];
-        }
-        {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[0][kt]), acc, 0, 0, 0);
-            epi(2 * pr, nt0, acc);
-        }
-        {
-            const uint4* b2 = tile_ptr(nt2);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) bq[0][kt] = b2[kt * 64];
-        }
-        {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], as_frag(bq[1][kt]), acc, 0, 0, 0);
-            epi(2 * pr + 1, nt1, acc);
-        }
+        if (j == MY - 1) mid();
+        epi(j, wave + NW * j, acc);
     }
 }
 
 // One hidden layer of the data-gradient chain: dPre[16, nout] = (dOut . W) * relu'(H).  The relu masks are the sign bits the forward
 // kernel left as wave ballots (mb[tile*4 + r], bit = lane): the MFMA output layout is the same in both kernels, so a lane tests its
-// own bit.  All 66 tiles x 4 words of a wavefront (2 KB) are fetched with one 8-byte load per thread and parked in LDS.
+// own bit of the tile's four words.  All 66 tiles x 4 words of a wavefront (2 KB) are fetched with one 8-byte load per thread and parked in LDS.
 static_assert(NTH >= MB_TILES * 4, "one sign-bit word per thread");
 // backward bundle row (floats): encoder output [mean A | logstd A] (104) | sd_attr (56) | g_attr from the decoder (56) | eps_attr (56)
 // | nbox 4 | g_nbox 4 | box logstd 4 | stat 12 | eps_box 4 | eps_depth, z_pres, g_pres, obj logit, g_depth, depth mean, depth logstd
 constexpr int BD_OE = 0, BD_SD = 104, BD_GA = 160, BD_EA = 216, BD_NB = 272, BD_GNB = 276, BD_OBL = 280, BD_ST = 284, BD_EB = 296,
               BD_EPSD = 300, BD_ZP = 301, BD_GPR = 302, BD_OO = 303, BD_GDR = 304, BD_OZ0 = 305, BD_OZ1 = 306, BD_W = 308;
 
-template <int KT, int NT>
-__device__ __forceinline__ void hidden_bwd(const __bf16* in, const uint4* __restrict__ Wt, const unsigned long long* mb, int ldh,
-                                           float* __restrict__ dOut_, int nout, __bf16* dst, const int* row_r, int nc, int wave, int lane,
-                                           const WPre& pre) {
-    __bf16* __restrict__ dOut = reinterpret_cast<__bf16*>(dOut_);       // gradient row buffers hold bf16 in the fused path (see k_chain_bwd)
-    wg_gemm_wide<KT, NT>(in, LD_H, Wt, wave, lane, [&](int j, int nt, const f32x4& acc) {
-        const int n = nt * 16 + (lane & 15);
-        if (n >= nout) return;
-        // sign bits in the forward kernel's (transposed) layout: word tile*4 + (column & 3), bit (column >> 2)*16 + row
-        const unsigned int mw = (unsigned int)(mb[nt * 4 + (lane & 3)] >> (((lane & 15) >> 2) * 16 + (lane >> 4) * 4));
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = (lane >> 4) * 4 + rr;
-            const float v = ((mw >> rr) & 1u) ? acc[rr] : 0.f;
-            if (dOut_ && row < nc) dOut[(size_t)row_r[row] * ldh + n] = (__bf16)v;
-            dst[row * LD_H + n] = (__bf16)v;
-        }
-    }, pre);
+template <int NT>
+__device__ __forceinline__ void hidden_epi(int nt, const f32x4& acc, const unsigned long long* mb, int ncol4, __bf16* dst, __bf16* __restrict__ dOut16,
+                                           int ldh, const int* row_r, int nc, int lane) {
+    if (nt >= NT) return;                                        // wave-uniform
+    const int col0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
+    if (col0 >= ncol4) return;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 m01 = *reinterpret_cast<const u64x2*>(mb + nt * 4), m23 = *reinterpret_cast<const u64x2*>(mb + nt * 4 + 2);
+    const float v0 = ((m01[0] >> lane) & 1ull) ? acc[0] : 0.f, v1 = ((m01[1] >> lane) & 1ull) ? acc[1] : 0.f;
+    const float v2 = ((m23[0] >> lane) & 1ull) ? acc[2] : 0.f, v3 = ((m23[1] >> lane) & 1ull) ? acc[3] : 0.f;
+    const bf16x4 o = pack4(v0, v1, v2, v3);
+    *reinterpret_cast<bf16x4*>(dst + row * LD_H + col0) = o;
+    if (dOut16 && row < nc) *reinterpret_cast<bf16x4*>(dOut16 + (size_t)row_r[row] * ldh + col0) = o;
+}
+
+// chain-local fast forms of the latent gradients (cell_math.h holds the reference forms; see ch_sigmoid)
+__device__ __forceinline__ float ch_kl_gauss(float mu, float sd, float m, float rs) {      // rs = 1 / prior std
+    const float q = sd * rs, vr = q * q, d = (mu - m) * rs;
+    return 0.5f * (vr + d * d - 1.f - ch_log(vr));
 }
 
 }  // namespace
@@ -885,10 +861,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Aa[MT * LD_H];
     __shared__ __attribute__((aligned(16))) __bf16 Ab[MT * LD_H];
     __shared__ float grec[MT][REC];
-    __shared__ float gnbw[NW][MT][4], nb_sh[MT][4];      // gnbw: per-WAVE partial d nbox of the glimpse epilogue, summed in wave order (no atomics: run-to-run identical)
+    __shared__ __attribute__((aligned(16))) float gnbw[NW][MT][4];      // per-WAVE partial d nbox of the glimpse epilogue, summed in wave order (no atomics: run-to-run identical)
+    __shared__ __attribute__((aligned(16))) float nb_sh[MT][4];
     __shared__ float zp_sh[MT];
     __shared__ __attribute__((aligned(16))) unsigned long long mb_sh[MB_TILES * 4];
-    __shared__ float gtile[NW][16][17];       // wave-private transpose tile of the glimpse-gradient epilogue
     __shared__ int row_r[MT], row_h[MT], row_w[MT];
     __shared__ __attribute__((aligned(16))) int cons_sh[MT][4];
     __shared__ int nbr_row[MT][4];
@@ -900,7 +876,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ int dstart_sh[3 * 32 + 2];
     __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
     __shared__ float pbase_sh[32];          // base coordinate of glimpse index j (stn_base)
-    __shared__ float prior_sh[12];          // prior mean[6] | std[6]: a lane-indexed read of the kernel-argument struct would be a
+    __shared__ float prior_sh[18];          // prior mean[6] | std[6] | 1 / std[6]: a lane-indexed read of the kernel-argument struct would be a
                                             // global load + vmcnt(0) wait in the middle of the prefetch window
 
     const CellLayout& L = a.L;
@@ -916,7 +892,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     if (tid < PG) pbase_sh[tid] = stn_base(tid, PG, a.ac);
     if (tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { prior_sh[i] = H.prior_mean[i]; prior_sh[6 + i] = H.prior_std[i]; }
+        for (int i = 0; i < 6; ++i) { prior_sh[i] = H.prior_mean[i]; prior_sh[6 + i] = H.prior_std[i]; prior_sh[12 + i] = 1.f / H.prior_std[i]; }
     }
 
     for (int i = tid; i < MT * LD_H; i += NTH) { Aa[i] = (__bf16)0.f; Ab[i] = (__bf16)0.f; }
@@ -976,6 +952,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     bundle_park();
     __syncthreads();
 
+    WPipe pipe;
+    pipe_fill_w<4, 7>(a.wt[CW_OBJ1], pipe, wave, lane);      // the first data-gradient GEMM of the first wavefront
     int stamp_j = 2048;
 #define CB_STAMP() do { if (a.stamps && b == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int t = T - 1; t >= 0; --t) {
@@ -1005,8 +983,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
-        // relu sign bits of this wavefront: one word per thread to park (threads 0..263), plus the word that holds this thread's four
-        // Ho2 elements for the rank-1 stage below (row tid/25, columns 4*(tid%25)..+3 -> tile q4/4, register row&3)
+        // relu sign bits of this wavefront: one word per thread to park (threads 0..263), plus the four words that hold this thread's four
+        // Ho2 elements for the rank-1 product of the presence stage
         const unsigned long long* const mbt = P.mbits + ((size_t)b * T + t) * (MB_TILES * 4);
         const unsigned long long mbq = mbt[min(tid, MB_TILES * 4 - 1)];
         const int ho_q4 = min(tid & 31, 24);          // the pres stage's mapping: 32 lanes per row, lanes 0..24 own 4 columns of Ho2 each
@@ -1014,17 +992,14 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
         const u64x2_t mbo01 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4);
         const u64x2_t mbo23 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4 + 2);
-        WPre wpre;
-        wide_prefetch<4, 7>(a.wt[CW_OBJ1], wave, lane, wpre);     // first tile of the first data-gradient GEMM of this wavefront
-        // saved glimpse derivatives for this wave's 7 ENC0 tiles, in the row-major mapping of the epilogue's second half (lane -> row
-        // lane>>2, 4 consecutive elements): 7 coalesced 16-byte loads per lane (28 dword gathers in the MFMA output layout stalled the
-        // memory pipeline for ~1.5 us)
+        // saved glimpse derivatives for this wave's 7 ENC0 tiles in the (transposed) MFMA output layout itself -- row lane & 15, elements
+        // tile*16 + (lane>>4)*4 .. +3: one 16-byte load per tile, and the epilogue needs no transpose through LDS any more
         uint4 gxy_pf[7];
         {
-            const size_t grow = (size_t)row_r[min(lane >> 2, nc - 1)] * L.ld_gl;
+            const size_t grow = (size_t)row_r[min(lane & 15, nc - 1)] * L.ld_gl;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const int e0 = min((wave + NW * j) * 16 + (lane & 3) * 4, GLN - 4);
+                const int e0 = min((wave + NW * j) * 16 + (lane >> 4) * 4, GLN - 4);
                 gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
             }
         }
@@ -1054,7 +1029,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
         // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit) and, by the same lanes, the rank-1
         // data gradient of the obj net's output layer: dHo2 = dOo (x) W_out masked by relu -- every lane of a row evaluates the row's d logit
-        // (the reduction leaves the KL sum in all 32), lanes 0..24 produce 4 columns each from the sign-bit word they prefetched
+        // (the reduction leaves the KL sum in all 32), lanes 0..24 produce 4 columns each from the sign-bit words they prefetched
         {
             const int row = tid >> 5, l = tid & 31;
             float kl = 0.f;
@@ -1062,26 +1037,29 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float* bd = bundle_sh[row];
                 const float* st = bd + BD_ST;
                 for (int j = l; j < A_; j += 32)
-                    kl += kl_gauss(bd[BD_OE + j], bd[BD_SD + j], prior_sh[4], prior_sh[6 + 4]);
-                if (l < 4) kl += kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], prior_sh[l], prior_sh[6 + l]);
-                if (l == 4) kl += kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], prior_sh[5], prior_sh[6 + 5]);
+                    kl += ch_kl_gauss(bd[BD_OE + j], bd[BD_SD + j], prior_sh[4], prior_sh[12 + 4]);
+                if (l < 4) kl += ch_kl_gauss(st[ST_MU_BOX + l], st[ST_SD_BOX + l], prior_sh[l], prior_sh[12 + l]);
+                if (l == 4) kl += ch_kl_gauss(st[ST_MU_DEPTH], st[ST_SD_DEPTH], prior_sh[5], prior_sh[12 + 5]);
             }
             kl = dpp_add_<0xB1>(kl); kl = dpp_add_<0x4E>(kl); kl = dpp_add_<0x141>(kl); kl = dpp_add_<0x140>(kl);     // 16-lane rows (DPP)
             kl += __shfl_xor(kl, 16, 64);                                                                             // the two rows of a 32-lane group
             float d = 0.f;
             if (row < nc) {
                 const float* bd = bundle_sh[row];
-                d = pres_backward(grec[row][REC - 1] + bd[BD_GPR], zp_sh[row], bd[BD_ST + ST_PZ], kl, bd[BD_OO], ks, H);
+                // pres_backward (cell_math.h): d/dz of the Bernoulli KL term (models.py:223-226) + what arrives at z_pres, through the sigmoid
+                const float z = zp_sh[row], pz = bd[BD_ST + ST_PZ], e = 1e-9f;
+                const float dkl = ch_log(z + e) - ch_log(pz + e) + z * __builtin_amdgcn_rcpf(z + e) - ch_log(1.f - z + e) + ch_log(1.f - pz + e) -
+                                  (1.f - z) * __builtin_amdgcn_rcpf(1.f - z + e);
+                const float g = grec[row][REC - 1] + bd[BD_GPR] + ks * (kl + dkl);
+                d = g * z * (1.f - z) * in10(freeze_val(H.wheel, bd[BD_OO])) * (1.f - H.wheel);
                 if (l == 0) reinterpret_cast<__bf16*>(P.dOo)[(size_t)row_r[row] * L.ld_oo] = (__bf16)d;
             }
             if (l < 25) {
                 const float4 w = *reinterpret_cast<const float4*>(&wobj_sh[l * 4]);
                 const int hs = (l & 3) * 16 + row;                                                           // bit of (column group, row)
-                const unsigned int hb = (unsigned int)((mbo01[0] >> hs) & 1ull) | ((unsigned int)((mbo01[1] >> hs) & 1ull) << 1) |
-                                        ((unsigned int)((mbo23[0] >> hs) & 1ull) << 2) | ((unsigned int)((mbo23[1] >> hs) & 1ull) << 3);
                 bf16x4 o;
-                o[0] = (__bf16)((hb & 1u) ? d * w.x : 0.f); o[1] = (__bf16)((hb & 2u) ? d * w.y : 0.f);
-                o[2] = (__bf16)((hb & 4u) ? d * w.z : 0.f); o[3] = (__bf16)((hb & 8u) ? d * w.w : 0.f);
+                o[0] = (__bf16)(((mbo01[0] >> hs) & 1ull) ? d * w.x : 0.f); o[1] = (__bf16)(((mbo01[1] >> hs) & 1ull) ? d * w.y : 0.f);
+                o[2] = (__bf16)(((mbo23[0] >> hs) & 1ull) ? d * w.z : 0.f); o[3] = (__bf16)(((mbo23[1] >> hs) & 1ull) ? d * w.w : 0.f);
                 if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dHo2) + (size_t)row_r[row] * SP_LDH + l * 4) = o;
                 *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + l * 4]) = o;
             }
@@ -1090,30 +1068,29 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // 7-tile layers: the 8th wave has no tile; the layer-output gradient (bf16 in LDS) is copied to HBM by that wave one stage later
-        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_OBJ1], mb_sh + MB_HO1 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
-        wide_prefetch<4, 30>(a.wt[CW_OBJ0], wave, lane, wpre);
+        if (wave < 7) {
+            wg_gemm_wt<4, 7>(Aa, LD_H, a.wt[CW_OBJ1], pipe, wave, lane,
+                [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HO1 * 4, SP_H, Ab, nullptr, 0, row_r, nc, lane); },
+                [&]() { pipe_fill_w<4, 30>(a.wt[CW_OBJ0], pipe, wave, lane); });
+        } else {
+            pipe_fill_w<4, 30>(a.wt[CW_OBJ0], pipe, wave, lane);
+        }
         lds_barrier();
         CB_STAMP();
-        wg_gemm_wide<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], wave, lane, [&](int j, int nt, const f32x4& acc) {
-            const int n = nt * 16 + (lane & 15);
-            if (n >= F + CTX + KX) return;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = (lane >> 4) * 4 + rr;
-                if (n < F + CTX) slot[row][n] = acc[rr];
-                else tailO[row][n - (F + CTX)] = acc[rr];
-            }
-        }, wpre);
-        wide_prefetch<4, 7>(a.wt[CW_ZH], wave, lane, wpre);
+        wg_gemm_wt<4, 30>(Ab, LD_H, a.wt[CW_OBJ0], pipe, wave, lane, [&](int j, int nt, const f32x4& acc) {
+            const int n0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
+            if (nt >= 30) return;                                    // wave-uniform: clamped tiles past the layer
+            if (n0 < F + CTX) *reinterpret_cast<f32x4*>(&slot[row][n0]) = acc;
+            else *reinterpret_cast<f32x4*>(&tailO[row][n0 - (F + CTX)]) = acc;
+        }, [&]() { pipe_fill_w<4, 7>(a.wt[CW_ZH], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
-        if (wave == 7) copy_rows_b16<SP_H>(Ab, LD_H, P.dHo1, SP_LDH, row_r, nc, lane);      // OBJ1's output, untouched until the ZH stage
+        if (wave == 7) copy_rows_w<25, 8>(Ab, LD_H * 2, P.dHo1, (size_t)SP_LDH * 2, row_r, nc, lane);      // OBJ1's output, untouched until the ZH stage
         for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
             const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
             const float4 v = row < nc ? *reinterpret_cast<const float4*>(&tailO[row][i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            const bf16x4 o = pack4(v.x, v.y, v.z, v.w);
             *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + i]) = o;
             if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dOz) + (size_t)row_r[row] * L.ld_oz + i) = o;
         }
@@ -1123,9 +1100,17 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const size_t r = row_r[tid];
                 const float* bd = bundle_sh[tid];
                 const float* st = bd + BD_ST;
-                const float eps = bd[BD_EPSD];
+                const float eps = bd[BD_EPSD], mu = st[ST_MU_DEPTH], sd = st[ST_SD_DEPTH], ls = bd[BD_OZ1], zp = zp_sh[tid];
                 const float g_depth = grec[tid][4 + A_] + tailO[tid][NP + 4 + A_] + bd[BD_GDR];
-                depth_backward(g_depth, st[ST_MU_DEPTH], st[ST_SD_DEPTH], bd[BD_OZ1], eps, zp_sh[tid], ks, H, d_mu, d_ls);
+                // depth_backward (cell_math.h)
+                const float dl = mu + sd * eps;
+                const float sg = ch_sigmoid(clamp10(dl));
+                const float g_dl = g_depth * 4.f * sg * (1.f - sg) * in10(dl);
+                const float m = prior_sh[5], rs = prior_sh[12 + 5];
+                d_mu = (g_dl + ks * zp * (mu - m) * rs * rs) * (1.f - H.wheel);
+                const float g_sd = (g_dl * eps + ks * zp * (sd * rs * rs - __builtin_amdgcn_rcpf(sd))) * (1.f - H.wheel);
+                const float sl = ch_sigmoid(clamp10(ls));
+                d_ls = g_sd * 2.f * sl * (1.f - sl) * in10(ls);
                 reinterpret_cast<__bf16*>(P.dOz)[r * L.ld_oz + NP] = (__bf16)d_mu;
                 reinterpret_cast<__bf16*>(P.dOz)[r * L.ld_oz + NP + 1] = (__bf16)d_ls;
             }
@@ -1134,30 +1119,37 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_ZH], mb_sh + MB_HZ2 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
-        wide_prefetch<4, 7>(a.wt[CW_Z1], wave, lane, wpre);
+        if (wave < 7) {
+            wg_gemm_wt<4, 7>(Aa, LD_H, a.wt[CW_ZH], pipe, wave, lane,
+                [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HZ2 * 4, SP_H, Ab, nullptr, 0, row_r, nc, lane); },
+                [&]() { pipe_fill_w<4, 7>(a.wt[CW_Z1], pipe, wave, lane); });
+        }
         lds_barrier();
         CB_STAMP();
-        if (wave < 7) hidden_bwd<4, 7>(Ab, a.wt[CW_Z1], mb_sh + MB_HZ1 * 4, SP_LDH, nullptr, SP_H, Aa, row_r, nc, wave, lane, wpre);
-        else copy_rows_b16<SP_H>(Ab, LD_H, P.dHz2, SP_LDH, row_r, nc, lane);
-        wide_prefetch<4, 30>(a.wt[CW_Z0], wave, lane, wpre);
+        if (wave < 7) {
+            wg_gemm_wt<4, 7>(Ab, LD_H, a.wt[CW_Z1], pipe, wave, lane,
+                [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HZ1 * 4, SP_H, Aa, nullptr, 0, row_r, nc, lane); },
+                [&]() { pipe_fill_w<4, 30>(a.wt[CW_Z0], pipe, wave, lane); });
+        } else {
+            pipe_fill_w<4, 30>(a.wt[CW_Z0], pipe, wave, lane);
+            copy_rows_w<25, 8>(Ab, LD_H * 2, P.dHz2, (size_t)SP_LDH * 2, row_r, nc, lane);
+        }
         lds_barrier();
         CB_STAMP();
-        wg_gemm_wide<4, 30>(Aa, LD_H, a.wt[CW_Z0], wave, lane, [&](int j, int nt, const f32x4& acc) {
-            const int n = nt * 16 + (lane & 15);
-            if (n >= F + CTX + KX) return;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = (lane >> 4) * 4 + rr;
-                if (n < F + CTX) slot[row][n] += acc[rr];
-                else tailZ[row][n - (F + CTX)] = acc[rr];
+        wg_gemm_wt<4, 30>(Aa, LD_H, a.wt[CW_Z0], pipe, wave, lane, [&](int j, int nt, const f32x4& acc) {
+            const int n0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
+            if (nt >= 30) return;
+            if (n0 < F + CTX) {
+                f32x4* q = reinterpret_cast<f32x4*>(&slot[row][n0]);
+                *q = *q + acc;
+            } else {
+                *reinterpret_cast<f32x4*>(&tailZ[row][n0 - (F + CTX)]) = acc;
             }
-        }, wpre);
-        wide_prefetch<4, 8>(a.wt[CW_ENC2], wave, lane, wpre);
+        }, [&]() { pipe_fill_w<4, 8>(a.wt[CW_ENC2], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
         // ---- attributes -> gradient of the encoder output
-        if (wave == 7) copy_rows_b16<SP_H>(Aa, LD_H, P.dHz1, SP_LDH, row_r, nc, lane);      // Z1's output, untouched until the ENC2 stage
+        if (wave == 7) copy_rows_w<25, 8>(Aa, LD_H * 2, P.dHz1, (size_t)SP_LDH * 2, row_r, nc, lane);      // Z1's output, untouched until the ENC2 stage
         for (int idx = tid; idx < MT * A_; idx += NTH) {
             const int row = idx / A_, j = idx - row * A_;
             float d_mean = 0.f, d_ls = 0.f;
@@ -1165,7 +1157,13 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const size_t r = row_r[row];
                 const float* bd = bundle_sh[row];
                 const float g = grec[row][4 + j] + tailZ[row][NP + 4 + j] + tailO[row][NP + 4 + j] + bd[BD_GA + j];
-                attr_backward(g, bd[BD_OE + j], bd[BD_SD + j], bd[BD_OE + A_ + j], bd[BD_EA + j], zp_sh[row], ks, H, d_mean, d_ls);
+                // attr_backward (cell_math.h)
+                const float mu = bd[BD_OE + j], sd = bd[BD_SD + j], ls = bd[BD_OE + A_ + j], eps = bd[BD_EA + j], zp = zp_sh[row];
+                const float m = prior_sh[4], rs = prior_sh[12 + 4];
+                const float g_sd = g * eps + ks * zp * (sd * rs * rs - __builtin_amdgcn_rcpf(sd));
+                const float sl = ch_sigmoid(clamp10(ls));
+                d_mean = g + ks * zp * (mu - m) * rs * rs;
+                d_ls = g_sd * 2.f * sl * (1.f - sl) * in10(ls);
                 reinterpret_cast<__bf16*>(P.dOe)[r * L.ld_oe + j] = (__bf16)d_mean;
                 reinterpret_cast<__bf16*>(P.dOe)[r * L.ld_oe + A_ + j] = (__bf16)d_ls;
             }
@@ -1174,28 +1172,25 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 8>(Ab, a.wt[CW_ENC2], mb_sh + MB_HE2 * 4, SP_ENC_H2, P.dHe2, SP_ENC_H2, Aa, row_r, nc, wave, lane, wpre);
-        wide_prefetch<4, 16>(a.wt[CW_ENC1], wave, lane, wpre);
+        wg_gemm_wt<4, 8>(Ab, LD_H, a.wt[CW_ENC2], pipe, wave, lane,
+            [&](int j, int nt, const f32x4& acc) { hidden_epi<8>(nt, acc, mb_sh + MB_HE2 * 4, SP_ENC_H2, Aa, reinterpret_cast<__bf16*>(P.dHe2), SP_ENC_H2, row_r, nc, lane); },
+            [&]() { pipe_fill_w<4, 16>(a.wt[CW_ENC1], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
-        hidden_bwd<4, 16>(Aa, a.wt[CW_ENC1], mb_sh + MB_HE1 * 4, SP_ENC_H1, P.dHe1, SP_ENC_H1, Ab, row_r, nc, wave, lane, wpre);
-        wide_prefetch<8, 49>(a.wt[CW_ENC0], wave, lane, wpre);
+        wg_gemm_wt<4, 16>(Aa, LD_H, a.wt[CW_ENC1], pipe, wave, lane,
+            [&](int j, int nt, const f32x4& acc) { hidden_epi<16>(nt, acc, mb_sh + MB_HE1 * 4, SP_ENC_H1, Ab, reinterpret_cast<__bf16*>(P.dHe1), SP_ENC_H1, row_r, nc, lane); },
+            [&]() { pipe_fill_w<8, 49>(a.wt[CW_ENC0], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
         // ---- d glimpse -> d z_where inside the epilogue (stn backward, modules.py:216-273): the glimpse gradient is never stored;
-        // each element meets the (d val/d gx, d val/d gy) pair the forward kernel saved, lane sums are reduced once per layer
+        // each element meets the (d val/d gx, d val/d gy) pair the forward kernel saved -- prefetched in this very layout -- lane sums are
+        // reduced once per layer
         {
-            // the accumulator tile goes through a wave-private LDS tile so that each lane meets 4 consecutive elements of ONE row --
-            // exactly one prefetched uint4 of (d val/d gx, d val/d gy) pairs
             float gs[4] = {0.f, 0.f, 0.f, 0.f};
-            float (*tl)[17] = gtile[wave];
-            const int trow = lane >> 2, tc0 = (lane & 3) * 4;
-            wg_gemm_wide<8, 49>(Ab, LD_H, a.wt[CW_ENC0], wave, lane, [&](int j, int nt, const f32x4& acc) {
+            const bool live = (lane & 15) < nc;
+            wg_gemm_wt<8, 49>(Ab, LD_H, a.wt[CW_ENC0], pipe, wave, lane, [&](int j, int nt, const f32x4& acc) {
                 if (nt >= 49 || j >= 7) return;                           // wave-uniform: tiles past the glimpse
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) tl[(lane >> 4) * 4 + rr][lane & 15] = acc[rr];
-                wave_lds_sync();
-                const int e0 = nt * 16 + tc0;
+                const int e0 = nt * 16 + (lane >> 4) * 4;
                 const int gi = e0 / PG, gj0 = e0 - gi * PG;             // PG % 4 == 0: the 4 elements share the glimpse row gi
                 const float Y = pbase_sh[gi];
                 const unsigned int pkq[4] = {gxy_pf[j].x, gxy_pf[j].y, gxy_pf[j].z, gxy_pf[j].w};
@@ -1203,17 +1198,16 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 for (int q = 0; q < 4; ++q) {
                     union { unsigned int u; _Float16 h[2]; } pk;
                     pk.u = pkq[q];
-                    const float d = trow < nc ? tl[trow][tc0 + q] : 0.f;
+                    const float d = live ? acc[q] : 0.f;
                     const float gix = d * (float)pk.h[0], giy = d * (float)pk.h[1];
                     gs[0] += gix; gs[1] += giy; gs[2] = fmaf(gix, pbase_sh[gj0 + q], gs[2]); gs[3] = fmaf(giy, Y, gs[3]);
                 }
-                wave_lds_sync();
-            }, wpre);
-            wide_prefetch<4, 7>(a.wt[CW_BOXH], wave, lane, wpre);
+            }, [&]() { pipe_fill_w<4, 7>(a.wt[CW_BOXH], pipe, wave, lane); });
+            // the four column groups of a row: lanes l, l + 16, l + 32, l + 48 (fixed association)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { gs[k] = dpp_add_<0xB1>(gs[k]); gs[k] = dpp_add_<0x4E>(gs[k]); }      // the 4 lanes of a row
-            if ((lane & 3) == 0 && trow < nc)                                                                       // tx = 2*xt - 1
-                *reinterpret_cast<float4*>(&gnbw[wave][trow][0]) = make_float4(2.f * gs[0], 2.f * gs[1], gs[2], gs[3]);
+            for (int k = 0; k < 4; ++k) { gs[k] += __shfl_xor(gs[k], 16, 64); gs[k] += __shfl_xor(gs[k], 32, 64); }
+            if (lane < 16 && live)                                                                                   // tx = 2*xt - 1
+                *reinterpret_cast<float4*>(&gnbw[wave][lane][0]) = make_float4(2.f * gs[0], 2.f * gs[1], gs[2], gs[3]);
         }
         lds_barrier();
         CB_STAMP();
@@ -1221,8 +1215,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
             const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
             const float4 v = row < nc ? *reinterpret_cast<const float4*>(&tailZ[row][i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            const bf16x4 o = pack4(v.x, v.y, v.z, v.w);
             *reinterpret_cast<bf16x4*>(&Aa[row * LD_H + i]) = o;
             if (row < nc) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dOb) + (size_t)row_r[row] * L.ld_ob + i) = o;
         }
@@ -1243,12 +1236,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 const float mu = st[ST_MU_BOX + k], sd = st[ST_SD_BOX + k], eps = bd[BD_EB + k], lls = bd[BD_OBL + k], zp = zp_sh[row];
                 const float gq = k < 2 ? (gb + gn * H.cell_over_img) * (H.max_yx - H.min_yx) : (gb + gn * H.anchor / H.img) * (H.max_hw - H.min_hw);
                 const float z = mu + sd * eps;
-                const float sg = sigmoidf_(clamp10(z));
+                const float sg = ch_sigmoid(clamp10(z));
                 const float g_z = gq * sg * (1.f - sg) * in10(z);
-                const float m = prior_sh[k], ps = prior_sh[6 + k];
-                d_mu = (g_z + ks * zp * (mu - m) / (ps * ps)) * (1.f - H.wheel);
-                const float g_sd = (g_z * eps + ks * zp * (sd / (ps * ps) - 1.f / sd)) * (1.f - H.wheel);
-                const float sl = sigmoidf_(clamp10(lls));
+                const float m = prior_sh[k], rs = prior_sh[12 + k];
+                d_mu = (g_z + ks * zp * (mu - m) * rs * rs) * (1.f - H.wheel);
+                const float g_sd = (g_z * eps + ks * zp * (sd * rs * rs - __builtin_amdgcn_rcpf(sd))) * (1.f - H.wheel);
+                const float sl = ch_sigmoid(clamp10(lls));
                 d_ls = g_sd * 2.f * sl * (1.f - sl) * in10(lls);
                 reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + k] = (__bf16)d_mu;
                 reinterpret_cast<__bf16*>(P.dOb)[r * L.ld_ob + NP + 4 + k] = (__bf16)d_ls;
@@ -1258,33 +1251,40 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
-        if (wave < 7) hidden_bwd<4, 7>(Aa, a.wt[CW_BOXH], mb_sh + MB_HB2 * 4, SP_LDH, nullptr, SP_H, Ab, row_r, nc, wave, lane, wpre);
-        wide_prefetch<4, 7>(a.wt[CW_BOX1], wave, lane, wpre);
+        if (wave < 7) {
+            wg_gemm_wt<4, 7>(Aa, LD_H, a.wt[CW_BOXH], pipe, wave, lane,
+                [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HB2 * 4, SP_H, Ab, nullptr, 0, row_r, nc, lane); },
+                [&]() { pipe_fill_w<4, 7>(a.wt[CW_BOX1], pipe, wave, lane); });
+        }
         lds_barrier();
         CB_STAMP();
-        if (wave < 7) hidden_bwd<4, 7>(Ab, a.wt[CW_BOX1], mb_sh + MB_HB1 * 4, SP_LDH, nullptr, SP_H, Aa, row_r, nc, wave, lane, wpre);
-        else copy_rows_b16<SP_H>(Ab, LD_H, P.dHb2, SP_LDH, row_r, nc, lane);
-        wide_prefetch<4, 21>(a.wt[CW_BOX0], wave, lane, wpre);
+        if (wave < 7) {
+            wg_gemm_wt<4, 7>(Ab, LD_H, a.wt[CW_BOX1], pipe, wave, lane,
+                [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HB1 * 4, SP_H, Aa, nullptr, 0, row_r, nc, lane); },
+                [&]() { pipe_fill_w<4, 21>(a.wt[CW_BOX0], pipe, wave, lane); });
+        } else {
+            pipe_fill_w<4, 21>(a.wt[CW_BOX0], pipe, wave, lane);
+            copy_rows_w<25, 8>(Ab, LD_H * 2, P.dHb2, (size_t)SP_LDH * 2, row_r, nc, lane);
+        }
         lds_barrier();
         CB_STAMP();
-        wg_gemm_wide<4, 21>(Aa, LD_H, a.wt[CW_BOX0], wave, lane, [&](int j, int nt, const f32x4& acc) {
-            const int n = nt * 16 + (lane & 15);
-            if (n >= F + CTX) return;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) slot[(lane >> 4) * 4 + rr][n] += acc[rr];
-        }, wpre);
+        wg_gemm_wt<4, 21>(Aa, LD_H, a.wt[CW_BOX0], pipe, wave, lane, [&](int j, int nt, const f32x4& acc) {
+            const int n0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
+            if (nt < 21 && n0 < F + CTX) {
+                f32x4* q = reinterpret_cast<f32x4*>(&slot[row][n0]);
+                *q = *q + acc;
+            }
+        }, [&]() { pipe_fill_w<4, 7>(a.wt[CW_OBJ1], pipe, wave, lane); });      // the next wavefront's first GEMM
         lds_barrier();
         CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
-        if (wave == 7) copy_rows_b16<SP_H>(Aa, LD_H, P.dHb1, SP_LDH, row_r, nc, lane);      // BOX1's output
+        if (wave == 7) copy_rows_w<25, 8>(Aa, LD_H * 2, P.dHb1, (size_t)SP_LDH * 2, row_r, nc, lane);      // BOX1's output
         // four columns per thread (F and REC are multiples of 4: a quad never straddles the feature / neighbour-slot boundaries)
-        for (int idx = tid; idx < nc * ((F + CTX) / 4); idx += NTH) {
-            const int row = idx / ((F + CTX) / 4), n = (idx - row * ((F + CTX) / 4)) * 4;
+        for (int idx = tid; idx < nc * (F / 4); idx += NTH) {
+            const int row = idx / (F / 4), n = (idx - row * (F / 4)) * 4;
             const float4 v = *reinterpret_cast<const float4*>(&slot[row][n]);
-            if (n < F) {
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dfeat16) + ((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n) =
-                    pack4(v.x, v.y, v.z, v.w);                                                          // read by the 1x1 stack
-            }
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dfeat16) + ((size_t)(b * G + row_h[row]) * G + row_w[row]) * P.ld_feat + n) =
+                pack4(v.x, v.y, v.z, v.w);                                                          // read by the 1x1 stack
         }
         // out-of-grid context slots feed the edge element: thread (s, j) owns element j of neighbour slot s and adds the wavefront's rows
         // in row order into a REGISTER that lives across the wavefronts (LDS atomics from the quad loop above gave sums that differed in
@@ -1299,6 +1299,12 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             edge_reg += add;
         }
         bundle_park();                       // every reader of this wavefront's bundle is behind the BOX0 barrier
+        // every register a prefetch load of this wavefront wrote is consumed here on EVERY path: a load the compiler cannot prove complete at
+        // the loop's back edge makes it guard the next definition of that register with s_waitcnt vmcnt(0) -- at the top of the next
+        // wavefront that was a wait for the acknowledgement of every store of this stage (the 2.3 us "grec" stage of round 3's stamps)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) asm volatile("" :: "v"(gxy_pf[j].x), "v"(gxy_pf[j].y), "v"(gxy_pf[j].z), "v"(gxy_pf[j].w));
+        asm volatile("" :: "v"(mbq), "v"(mbo01), "v"(mbo23));
         lds_barrier();
         CB_STAMP();
     }
