@@ -68,11 +68,7 @@ __device__ __forceinline__ void ch_gstore_nt(float4* p, const float4& v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
 }
-#ifdef CH_ABL_NOSTORE
-#define CH_GSTORE(p, v) do { } while (0)
-#else
 #define CH_GSTORE(p, v) ch_gstore_nt((p), (v))
-#endif
 // the backward kernel's read-once row data (bundle, glimpse derivatives) is loaded non-temporally (chain bwd 0.852 -> 0.833 ms)
 __device__ __forceinline__ uint4 ch_gload16(const void* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -89,11 +85,7 @@ struct WPipe { uint4 q[RD]; };
 template <int KT, int NT, int NT0>
 __device__ __forceinline__ const uint4* tile_base(const uint4* __restrict__ Wp, int wave, int lane) {
     const int nt = min(NT0 + wave, NT - 1);
-#ifdef CH_ABL_WL1
-    return Wp + lane;                      // ablation: every fragment load hits the same 1 KiB (L1-resident)
-#else
     return Wp + (size_t)nt * KT * 64 + lane;
-#endif
 }
 
 template <int KT, int NT, int NT0 = 0>
@@ -101,13 +93,7 @@ __device__ __forceinline__ void pipe_fill(const uint4* __restrict__ Wp, WPipe& p
     const uint4* base = tile_base<KT, NT, NT0>(Wp, wave, lane);
 #pragma unroll
     for (int f = 0; f < RD; ++f)
-#ifdef CH_ABL_WL1
-        if (f < KT) p.q[f] = base[(f & 3) * 64];
-#elif defined(CH_ABL_NOW)
-        if (f < KT && f < 1) p.q[f] = base[f * 64];
-#else
         if (f < KT) p.q[f] = base[f * 64];
-#endif
 }
 
 // relu layers leave their sign bits as wave ballots (see wg_store_t): the backward kernel reads 2 KB of bits per wavefront instead of
@@ -123,44 +109,11 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
     return o;
 }
 
-template <int NCOL>
-__device__ __forceinline__ void copy_rows_bf16(const __bf16* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
-    constexpr int CH = NCOL / 4;
-    for (int t = lane; t < nc * CH; t += 64) {
-        const int row = t / CH, c = (t - row * CH) * 4;
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c);
-        CH_GSTORE(reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c), make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]));
-    }
-}
-template <int NCOL>
-__device__ __forceinline__ void copy_rows_b16(const __bf16* src, int lds_ld, float* __restrict__ dst_, int ldd, const int* row_r, int nc, int lane) {
-    constexpr int CH = NCOL / 4;
-    __bf16* __restrict__ dst = reinterpret_cast<__bf16*>(dst_);
-    for (int t = lane; t < nc * CH; t += 64) {
-        const int row = t / CH, c = (t - row * CH) * 4;
-        CH_GSTORE(reinterpret_cast<bf16x4*>(dst + (size_t)row_r[row] * ldd + c), *reinterpret_cast<const bf16x4*>(src + row * lds_ld + c));
-    }
-}
-template <int NCOL>
-__device__ __forceinline__ void copy_rows_f32(const float* src, int lds_ld, float* __restrict__ dst, int ldd, const int* row_r, int nc, int lane) {
-    constexpr int CH = NCOL / 4;
-    for (int t = lane; t < nc * CH; t += 64) {
-        const int row = t / CH, c = (t - row * CH) * 4;
-        CH_GSTORE(reinterpret_cast<float4*>(dst + (size_t)row_r[row] * ldd + c), *reinterpret_cast<const float4*>(src + row * lds_ld + c));
-    }
-}
-
-
 // ---- chain-local fast math.  The latent transforms sit on the critical path of a 46-step dependent chain as ~120-instruction sequences of
 // one or four waves (IEEE division = 10 instructions, expf = 12): here they are v_exp_f32 / v_rcp_f32 / v_log_f32 forms, ~1 ulp each --
 // far inside what the bf16 operands of the surrounding GEMMs do to the same values (the fp32 parity mode never runs these kernels).
-#ifdef CH_EXACT_MATH
-__device__ __forceinline__ float ch_sigmoid(float x) { return sigmoidf_(x); }
-__device__ __forceinline__ float ch_log(float x) { return logf(x); }
-#else
 __device__ __forceinline__ float ch_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
 __device__ __forceinline__ float ch_log(float x) { return 0.693147180559945f * __builtin_amdgcn_logf(x); }
-#endif
 
 // The store wave's row copier: PIECES pieces of PB (8 or 16) bytes per row, LDS -> HBM row buffer.  Eight lanes serve one row (a pass
 // covers 8 rows: every row of a wavefront on grids up to 16 x 16), so the row's base addresses are formed once and every further piece
@@ -576,11 +529,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         const float gmult = a.ac ? 0.5f * (float)(a.I - 1) : 0.5f * (float)a.I;      // d(source pixel coordinate) / d(normalised coordinate) where not clipped
-#ifdef CH_ABL_NOGL
-        for (int idx = tid; idx < 0; idx += NTH) {
-#else
         for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
-#endif
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
             const int i = e / PG, j0 = e - i * PG;              // P % 4 == 0: the 4 elements share the row i
             const uint2 ye = gtab[row][1][i];
