@@ -198,7 +198,7 @@ def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
     import numpy as np
     ns_, gl_, nb_ = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     L.check(L.lib().spair_chain_stamp_layout(ctypes.byref(ns_), ctypes.byref(gl_), ctypes.byref(nb_)), "stamp_layout")
-    T, NS, GL = 3 * d.G - 2, ns_.value, gl_.value       # stamps per wavefront; interval GL = glimpse sampling (tools/chain_stamps.py)
+    T, NS, GL = L.lib().spair_chain_stamp_wavefronts(ctypes.byref(d)), ns_.value, gl_.value       # stamps per wavefront; interval GL = glimpse sampling
     if T * NS > 2048:
         return None
     old = models.STEP_FLAGS
@@ -223,7 +223,7 @@ def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
     return dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, avg_ms=None, stage_ms=ms_, traffic=None,
                 share_of_chain_fwd=share,
                 note="fused stage of k_chain_fwd (no launch of its own): stage share from in-kernel s_memtime stamps of sample 0 x the kernel's "
-                     "event time; every workgroup runs this stage %d times, all %d workgroups concurrently" % (T, B))
+                     "event time; the stamping workgroup runs this stage %d times" % T)
 
 
 def _sha16(path):

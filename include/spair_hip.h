@@ -102,6 +102,12 @@ int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long 
 /* layout of that buffer: stamps per wavefront of the forward kernel (from offset 0; stage intervals = stamps - 1), the index of the glimpse
  * sampling interval (K4: modules.py:216-273 via models.py:387) among them, stamps per wavefront of the backward kernel (from offset 2048) */
 int spair_chain_stamp_layout(int* fwd_per_wavefront, int* fwd_glimpse_interval, int* bwd_per_wavefront);
+/* wavefronts walked by the workgroup that stamps (sample 0; with the band split of grids wider than 16 cells, its top band) */
+int spair_chain_stamp_wavefronts(const SpairDims* d);
+/* band split of the fused per-cell kernels (grids wider than 16 cells: two workgroups per sample hand the boundary row's records /
+ * context gradients to each other through `workspace`): writes 1 to *out (device int) if a bounded wait timed out in the latest
+ * spair_forward / spair_backward on this workspace, 0 if not, -1 where the kernels run unsplit */
+int spair_chain_sync_status(const SpairDims* d, const void* workspace, int* out, void* stream);
 int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
 
 /* Opt-in instrumentation for bench.py: HIP events on the caller's stream around regions of the step.

@@ -16,7 +16,19 @@ struct ChainArgs {
     unsigned long long* stamps;   // diagnostic: s_memtime after every stage of sample 0 (null in production)
     const float* x;
     int I, Pp, ac;
+    // Band split (grids wider than 16 cells): a sample's grid rows are cut into `nbands` horizontal bands, one workgroup each.  A band only
+    // ever READS from the band above it (a cell's context is (h-1, w-1), (h-1, w), (h-1, w+1), (h, w-1): models.py:297-304), so the bands of a
+    // sample run as a pipeline -- the upper band publishes its last row's records, the lower one consumes them one wavefront later; the
+    // backward kernel runs the same pipeline upwards with the context gradients.  `sync` (ints, zeroed before every launch): [0] start
+    // ticket, [2] time-out flag, [16 + b*nbands + band] wavefronts published; bnd_rec [B][nbands][G][REC], bnd_grad [B][nbands][G][3][REC].
+    int nbands;
+    int* sync;
+    float* bnd_rec;
+    float* bnd_grad;
 };
+#define CHAIN_MAX_BANDS 4
+#define CHAIN_SYNC_HDR 16
+int chain_bands(const SpairDims& d);          // 1 up to 16 x 16 cells; bands of 8 grid rows beyond (a wavefront then has <= 8 cells per band)
 
 // stage stamps (diagnostic, SpairStep.flags bit 1): stamps per wavefront; the forward kernel's intervals are
 // rows | S0 ctx | BOX0 | BOX1 | BOXH+box | glimpse | ENC0 | ENC1 | ENC2 | attr | Z0 | Z1 | ZH+depth | OBJ0 | OBJ1+obj2 | pres

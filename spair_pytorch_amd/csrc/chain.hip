@@ -59,6 +59,9 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
 // which serialises the whole stream (measured: ~4.5k cycles per stage regardless of its size).  The ring lives across layer
 // boundaries and barriers: pipe_fill() for layer l+1 is issued right after the MFMAs of layer l.
 constexpr int NW = 8;                     // waves per workgroup
+// band split: polls of the neighbouring band's counter before a wait is abandoned (~0.3 s; a legitimate wait is the other band's head start,
+// half a millisecond) -- a kernel of this library never spins without a bound
+constexpr int CHAIN_SPIN_LIMIT = 1 << 18;
 constexpr int NTH = NW * 64;
 constexpr int RD = 12;      // weight fragments in flight per wave (measured: 16 / 20 / 24 change nothing, 0.91 -> 0.93-0.95 ms)
 // the row-buffer stores are non-temporal: they stream past the L2 that holds the weights every workgroup re-reads each wavefront (chain fwd
@@ -285,6 +288,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 gtab[MT][2][PG];          // glimpse source coordinates per (row, axis, index)
     __shared__ int row_r[2][MT], row_hw[2][MT], row_cp[MT];                 // row tables of the current ([t & 1]) and the previous wavefront
     __shared__ int dstart_sh[3 * 32 + 2];
+    __shared__ int bc0_sh[3 * 32 + 2], bnc_sh[3 * 32 + 2];                  // this band's first cell / cell count on every wavefront
+    __shared__ __attribute__((aligned(16))) float brec_sh[4][REC];          // band split: the last records of the band above (ring over the grid column)
+    __shared__ int ticket_sh;
     __shared__ short nbr_sh[32 * 32 * 4];
     __shared__ __attribute__((aligned(16))) float w2_sh[7 * 16];            // obj_network.out.weight as the bf16 values the MFMA path would multiply by (0 past column 99)
     __shared__ __attribute__((aligned(16))) float opart[MT][28];            // partial presence logits: row x (wave, column group of its tile) (OBJ1's epilogue)
@@ -296,8 +302,21 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
+    // (sample, band) by START ORDER, not by blockIdx: the first B workgroups to start take the top bands, which wait for nobody; a workgroup
+    // that has to wait therefore only ever waits for workgroups that are already running -- no assumption about dispatch order or residency
+    const int NBn = a.nbands;
+    int band = 0, b = blockIdx.x;
+    if (NBn > 1) {
+        if (tid0 == 0) ticket_sh = atomicAdd(&a.sync[0], 1);
+        __syncthreads();
+        const int tk = ticket_sh;
+        band = tk / L.B;
+        b = tk - band * L.B;
+    }
+    const int HBd = (G + NBn - 1) / NBn, hb0 = band * HBd, hb1 = min(G, hb0 + HBd);
+    const int t_first = 2 * hb0, t_last = 2 * (hb1 - 1) + G - 1;
+    int* const flag_mine = a.sync ? a.sync + CHAIN_SYNC_HDR + b * NBn + band : nullptr;
     float* const sd_stage = &feat_sh[0][0];                    // [MT][52]
     float* const stat_stage = &feat_sh[0][0] + MT * 52;        // [MT][12]: mu_box 4 | sd_box 4 | mu_depth | sd_depth | 0 | 0
     constexpr int LD_SD = 52, LD_ST = 12;
@@ -309,7 +328,15 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     for (int i = tid; i < MT * LD_GL; i += NTH) Gl[i] = (__bf16)0.f;
     for (int i = tid; i < MT * LD_H; i += NTH) { Ha[i] = (__bf16)0.f; Hb[i] = (__bf16)0.f; }
     for (int i = tid; i < MT * LD_O; i += NTH) Ost[i] = 0.f;
-    for (int i = tid; i <= T; i += NTH) dstart_sh[i] = P.diag_start[i];
+    for (int i = tid; i <= T; i += NTH) {
+        const int ds = P.diag_start[i];
+        dstart_sh[i] = ds;
+        // cells of wavefront i are ordered by grid row: rows hlo .. hhi, of which this band owns [max(hlo, hb0), min(hhi, hb1 - 1)]
+        const int hlo = max(0, (i - G + 2) >> 1), hhi = min(G - 1, i >> 1);
+        const int hA = max(hlo, hb0), hB = min(hhi, hb1 - 1);
+        bc0_sh[i] = ds + (hA - hlo);
+        bnc_sh[i] = i < T ? max(0, hB - hA + 1) : 0;
+    }
     for (int i = tid; i < L.HW * 4; i += NTH) nbr_sh[i] = (short)P.nbr[i];
     for (int i = tid; i < L.HW; i += NTH) cell_hw[i] = (unsigned short)((P.cell_h[i] << 8) | P.cell_w[i]);
     for (int i = tid; i < REC; i += NTH) edge_sh[i] = P.edge[i];
@@ -353,7 +380,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     }
     auto prefetch = [&](int tn) {                 // branch-free (clamped indices): conditional loads would make every later wait on the
                                                   // weight ring a vmcnt(0), i.e. a wait for THESE loads
-        const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
+        const int c0n = bc0_sh[tn], ncn = bnc_sh[tn];
         {
             const int hw = cell_hw[c0n + min(pf_frow, ncn - 1)];
             pf_feat = *reinterpret_cast<const float4*>(P.feat + ((size_t)(b * G + (hw >> 8)) * G + (hw & 255)) * P.ld_feat + pf_fc4);
@@ -378,8 +405,49 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             if (i < MT * REC) noise_sh[i / REC][i % REC] = v;
         }
     };
-    prefetch(0);
+    prefetch(t_first);
     park(tid);
+
+    // ---- band split: the hand-off of the band above's last row (one record per wavefront).  Producer: the store wave writes the record
+    // with agent-scope (write-through) 8-byte stores, drains them, then publishes the wavefront count; consumer: one relaxed agent-scope
+    // poll, then agent-scope 8-byte loads into registers (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table: one storing wave
+    // signals for its own stores).  Every wait is bounded: on a time-out the error word is set and the kernel runs on (wrong, but it ends).
+    typedef unsigned long long u64_t;
+    int sync_dead = 0;
+    auto publish_row = [&](int tp, int ncp, int ln) {            // called by the store wave behind flush_records(tp)
+        if (NBn > 1 && band < NBn - 1) {
+            const int w = tp - 2 * (hb1 - 1);                    // the band's last row on wavefront tp, if that wavefront reaches it
+            if (w >= 0 && w < G && (tp >> 1) >= hb1 - 1) {
+                if (ln < REC / 2) {
+                    const u64_t v = *reinterpret_cast<const u64_t*>(&recs[tp & 3][ncp - 1][2 * ln]);
+                    __hip_atomic_store(reinterpret_cast<u64_t*>(a.bnd_rec + ((size_t)(b * NBn + band) * G + w) * REC) + ln, v, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ln == 0) __hip_atomic_store(flag_mine, tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto fetch_row = [&](int tq, int ln) {                       // the band above's record of wavefront tq -> brec_sh (whole wave)
+        const int w = tq - 2 * (hb0 - 1);
+        if (w < 0 || w >= G) return;                             // (wave-uniform)
+        const int* flag = a.sync + CHAIN_SYNC_HDR + b * NBn + (band - 1);
+        int ok = sync_dead;
+        for (int spin = 0; spin < CHAIN_SPIN_LIMIT && !ok; ++spin) {
+            ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tq + 1);
+            if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) { sync_dead = 1; if (ln == 0) a.sync[2] = 1; }      // time-out: never wait again, flag the launch as failed
+        if (ln < REC / 2) {
+            const u64_t v = __hip_atomic_load(reinterpret_cast<const u64_t*>(a.bnd_rec + ((size_t)(b * NBn + band - 1) * G + w) * REC) + ln,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<u64_t*>(&brec_sh[w & 3][2 * ln]) = v;
+        }
+    };
+    if (band > 0 && wave == 7) {                                 // the two records the band's first wavefront reads
+        fetch_row(t_first - 2, lane);
+        fetch_row(t_first - 1, lane);
+    }
 
     // The store wave's end-of-wavefront flush (one wavefront late, beside BOX0): the record rows, the box, the presence logit and the
     // two output maps of wavefront tp, whose row tables sit in slot tp & 1.  Everything a latent stage produces goes to LDS only.
@@ -397,22 +465,23 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             P.Oo[(size_t)rr[ln] * L.ld_oo] = logit_sh[ln];
             P.z_pres[((size_t)b * G + (hw >> 8)) * G + (hw & 255)] = recs[tp & 3][ln][REC - 1];
         }
+        publish_row(tp, ncp, ln);
     };
 
     WPipe pipe;
     pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);      // (all eight waves here: the ring registers must be defined on every path)
     int stamp_i = 0;
     int nc_prev = 0;
-#define CH_STAMP() do { if (a.stamps && b == 0 && tid == 0) a.stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int t = 0; t < T; ++t) {
+#define CH_STAMP() do { if (a.stamps && b == 0 && band == 0 && tid == 0) a.stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+    for (int t = t_first; t <= t_last; ++t) {
         // opaque per-iteration copies: keeps LICM from hoisting every layer's lane-dependent address arithmetic out of the
         // wavefront loop (that cost >100 VGPRs held across the whole loop and forced the weight ring to be shallow)
         tid = tid0;
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         CH_STAMP();
-        const int c0 = dstart_sh[t];
-        const int nc = dstart_sh[t + 1] - c0;
+        const int c0 = bc0_sh[t];
+        const int nc = bnc_sh[t];
         unsigned long long* const mbt = mbf_sh;                 // sign-bit ballots of this wavefront, flushed to HBM at its end
         float (*rec_cur)[REC] = recs[t & 3];
         int* const rr_cur = row_r[t & 1];
@@ -424,7 +493,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             hw_cur[tid] = cell_hw[cp];
         }
         lds_barrier();                       // also orders park() of the previous wavefront before S0's reads
-        prefetch(min(t + 1, T - 1));
+        prefetch(min(t + 1, t_last));
         CH_STAMP();
         // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread, LDS only (the store wave copies the finished rows to
         // the Xb row buffer beside BOX0)
@@ -439,7 +508,11 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const int s = (c4 - F) / REC, j = (c4 - F) - s * REC;
                 const int nbc = nbr_sh[row_cp[row] * 4 + s];
                 const int dt = (s == 0) ? 3 : (s == 1 ? 2 : 1);      // UL: t-3, U: t-2, UR and L: t-1
-                const float* src = nbc >= 0 ? &recs[(t - dt) & 3][nbc - dstart_sh[max(t - dt, 0)]][j] : &edge_sh[j];
+                const float* src = nbc >= 0 ? &recs[(t - dt) & 3][nbc - bc0_sh[max(t - dt, 0)]][j] : &edge_sh[j];
+                if (band > 0 && nbc >= 0) {                          // a neighbour in the band above: its record came through brec_sh
+                    const int nhw = cell_hw[nbc];
+                    if ((nhw >> 8) < hb0) src = &brec_sh[nhw & 3][j];
+                }
                 v = *reinterpret_cast<const float4*>(src);
             }
             *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = pack4(v.x, v.y, v.z, v.w);
@@ -455,7 +528,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         } else {
             // (every operand of the weight-gradient GEMMs is stored as bf16 by this kernel: same leading dimensions in elements, the buffers
             //  are sized for the per-wavefront path's fp32; the z / obj nets read these columns from Xb too)
-            if (t > 0) flush_records(t - 1, nc_prev, lane);
+            if (t > t_first) flush_records(t - 1, nc_prev, lane);
         }
         lds_barrier();
         CH_STAMP();
@@ -691,6 +764,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             copy_rows_w<25, 8>(Ha, LD_H * 2, P.Ho1, (size_t)SP_LDH * 2, rr_cur, nc, lane);
             copy_rows_w<3, 16>(stat_stage, LD_ST * 4, P.stat, (size_t)SP_LDSTAT * 4, rr_cur, nc, lane);
             copy_rows_w<39, 8>(XtO, LD_XT * 2, reinterpret_cast<__bf16*>(P.Xo) + L.x_pass, (size_t)L.ld_x * 2, rr_cur, nc, lane);
+            if (band > 0) fetch_row(t, lane);      // the band above's record of this wavefront: read by the next wavefront's S0
         }
         lds_barrier();
         CH_STAMP();
@@ -710,12 +784,12 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // (no barrier: nothing below reads what the pres threads write, and they no longer read noise_sh; the next wavefront's row-setup
         //  barrier orders all of it before S0)
         park(tid);                           // features / noise of the next wavefront (read after its row-setup barrier)
-        if (tid < MB_TILES * 4) P.mbits[((size_t)b * T + t) * (MB_TILES * 4) + tid] = mbf_sh[tid];     // one coalesced 2 KB store
+        if (tid < MB_TILES * 4) P.mbits[((size_t)(b * NBn + band) * T + t) * (MB_TILES * 4) + tid] = mbf_sh[tid];     // one coalesced 2 KB store
         nc_prev = nc;
         CH_STAMP();
     }
     lds_barrier();
-    if (wave == 7) flush_records(T - 1, nc_prev, tid0 & 63);
+    if (wave == 7) flush_records(t_last, nc_prev, tid0 & 63);
 }
 
 
@@ -823,6 +897,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float bundle_sh[MT][BD_W];
     __shared__ __attribute__((aligned(16))) int ibundle_sh[MT][8];           // consumers[4] | neighbours[4]
     __shared__ int dstart_sh[3 * 32 + 2];
+    __shared__ int bc0_sh[3 * 32 + 2], bnc_sh[3 * 32 + 2];                  // this band's first cell / cell count on every wavefront
+    __shared__ __attribute__((aligned(16))) float bgrad_sh[3][REC];         // band split: context-gradient pieces of the band below for this band's last row
+    __shared__ int ticket_sh;
     __shared__ __attribute__((aligned(16))) float wobj_sh[SP_H + 12];
     __shared__ float pbase_sh[32];          // base coordinate of glimpse index j (stn_base)
     __shared__ float prior_sh[18];          // prior mean[6] | std[6] | 1 / std[6]: a lane-indexed read of the kernel-argument struct would be a
@@ -834,8 +911,20 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int b = blockIdx.x;
     const int G = L.G, T = 3 * G - 2;
+    // (sample, band) by start order, the BOTTOM band first (see k_chain_fwd): the backward pipeline runs upwards
+    const int NBn = a.nbands;
+    int band = 0, b = blockIdx.x;
+    if (NBn > 1) {
+        if (tid0 == 0) ticket_sh = atomicAdd(&a.sync[1], 1);
+        __syncthreads();
+        const int tk = ticket_sh;
+        band = NBn - 1 - tk / L.B;
+        b = tk - (tk / L.B) * L.B;
+    }
+    const int HBd = (G + NBn - 1) / NBn, hb0 = band * HBd, hb1 = min(G, hb0 + HBd);
+    const int t_first = 2 * hb0, t_last = 2 * (hb1 - 1) + G - 1;
+    int* const flag_mine = a.sync ? a.sync + CHAIN_SYNC_HDR + L.B * NBn + b * NBn + band : nullptr;
     const float ks = H.kl_scale * (*P.gloss);
     if (tid < SP_H) wobj_sh[tid] = a.w_obj2[tid];
     if (tid < PG) pbase_sh[tid] = stn_base(tid, PG, a.ac);
@@ -847,7 +936,14 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     for (int i = tid; i < MT * LD_H; i += NTH) { Aa[i] = (__bf16)0.f; Ab[i] = (__bf16)0.f; }
     for (int i = tid; i < 4 * MT * LD_R; i += NTH) (&ring[0][0][0])[i] = 0.f;
     for (int i = tid; i < MT * KX; i += NTH) { (&tailO[0][0])[i] = 0.f; (&tailZ[0][0])[i] = 0.f; }
-    for (int i = tid; i <= T; i += NTH) dstart_sh[i] = P.diag_start[i];
+    for (int i = tid; i <= T; i += NTH) {
+        const int ds = P.diag_start[i];
+        dstart_sh[i] = ds;
+        const int hlo = max(0, (i - G + 2) >> 1), hhi = min(G - 1, i >> 1);
+        const int hA = max(hlo, hb0), hB = min(hhi, hb1 - 1);
+        bc0_sh[i] = ds + (hA - hlo);
+        bnc_sh[i] = i < T ? max(0, hB - hA + 1) : 0;
+    }
     float edge_reg = 0.f;                    // threads NTH/2 .. NTH/2 + 4*REC: running sum of one (neighbour slot, record element) of the edge gradient
     __syncthreads();
 
@@ -881,9 +977,9 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     float pf_s0, pf_s1;
     auto hlo_of = [&](int tt) { return max(0, (tt - G + 2) >> 1); };       // first grid row on diagonal tt (cells ordered by h)
     auto bundle_fetch = [&](int tn) {
-        const int c0n = dstart_sh[tn], ncn = dstart_sh[tn + 1] - c0n;
+        const int c0n = bc0_sh[tn], ncn = bnc_sh[tn];
         const int k = min(brow, ncn - 1);
-        const int cpn = c0n + k, h = hlo_of(tn) + k, w = tn - 2 * h;
+        const int cpn = c0n + k, h = max(hlo_of(tn), hb0) + k, w = tn - 2 * h;
         const size_t rn = (size_t)cpn * L.B + b, cell = (size_t)h * G + w;
         pf_v0 = CH_GLOADF4(v0_base + rn * v0_ld);
         pf_v1 = CH_GLOADF4(v1_base + (v1_cp ? (size_t)cpn : rn) * v1_ld);
@@ -897,25 +993,67 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         bundle_sh[brow][s0_dst] = pf_s0;
         if (bl < 29) bundle_sh[brow][s1_dst] = pf_s1;
     };
-    bundle_fetch(T - 1);
+    bundle_fetch(t_last);
     bundle_park();
+    __syncthreads();
+
+    // ---- band split (see k_chain_fwd): the band BELOW publishes, for each cell of its first row, the context-gradient pieces of its UL / U /
+    // UR slots -- the record gradients of three cells of this band's last row -- as soon as its BOX0 stage has completed the sums; this band
+    // gathers the three pieces of its last-row cell one wavefront ahead.  Counter: wavefronts finished, counted from the last one.
+    typedef unsigned long long u64_t;
+    int sync_dead = 0;
+    auto publish_grad = [&](int tq, const float (*sl)[LD_R], int ln) {       // store wave, behind the BOX0 barrier of wavefront tq
+        if (NBn > 1 && band > 0) {
+            const int w = tq - 2 * hb0;                                      // this band's first row on wavefront tq (its tile row 0), if present
+            if (w >= 0 && w < G && hlo_of(tq) <= hb0) {
+                for (int i = ln; i < 3 * REC / 2; i += 64) {
+                    const int sidx = i / (REC / 2), jj = (i - sidx * (REC / 2)) * 2, wt = w - 1 + sidx;      // slot UL -> cell w-1, U -> w, UR -> w+1
+                    if (wt >= 0 && wt < G) {
+                        const u64_t v = *reinterpret_cast<const u64_t*>(&sl[0][F + sidx * REC + jj]);
+                        __hip_atomic_store(reinterpret_cast<u64_t*>(a.bnd_grad + (((size_t)(b * NBn + band) * G + wt) * 3 + sidx) * REC + jj), v,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ln == 0) __hip_atomic_store(flag_mine, T - tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto fetch_grad = [&](int tq, int ln) {                                  // pieces for this band's last-row cell of wavefront tq -> bgrad_sh (whole wave)
+        const int w = tq - 2 * (hb1 - 1);
+        if (w < 0 || w >= G) return;                                         // (wave-uniform)
+        const int need = T - max(tq + 1, 2 * hb1);                           // the band below has finished wavefront max(tq + 1, its first)
+        const int* flag = a.sync + CHAIN_SYNC_HDR + L.B * NBn + b * NBn + (band + 1);
+        int ok = sync_dead;
+        for (int spin = 0; spin < CHAIN_SPIN_LIMIT && !ok; ++spin) {
+            ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need);
+            if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) { sync_dead = 1; if (ln == 0) a.sync[2] = 1; }
+        for (int i = ln; i < 3 * REC / 2; i += 64) {
+            const u64_t v = __hip_atomic_load(reinterpret_cast<const u64_t*>(a.bnd_grad + ((size_t)(b * NBn + band + 1) * G + w) * 3 * REC) + i,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<u64_t*>(&bgrad_sh[0][0] + 2 * i) = v;
+        }
+    };
+    if (band < NBn - 1 && wave == 7) fetch_grad(t_last, lane);
     __syncthreads();
 
     WPipe pipe;
     pipe_fill_w<4, 7>(a.wt[CW_OBJ1], pipe, wave, lane);      // the first data-gradient GEMM of the first wavefront
     int stamp_j = 2048;
-#define CB_STAMP() do { if (a.stamps && b == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int t = T - 1; t >= 0; --t) {
+#define CB_STAMP() do { if (a.stamps && b == 0 && band == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
+    for (int t = t_last; t >= t_first; --t) {
         CB_STAMP();
         tid = tid0;   // opaque per-iteration copy: no LICM of lane-dependent address arithmetic (see k_chain_fwd)
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
-        const int c0 = dstart_sh[t];
-        const int nc = dstart_sh[t + 1] - c0;
+        const int c0 = bc0_sh[t];
+        const int nc = bnc_sh[t];
         float (*slot)[LD_R] = ring[t & 3];
         if (tid < MT) {
             const int k = min(tid, nc - 1);
-            const int cp = c0 + k, h = hlo_of(t) + k;
+            const int cp = c0 + k, h = max(hlo_of(t), hb0) + k;
             row_r[tid] = cp * L.B + b;
             row_h[tid] = h;
             row_w[tid] = t - 2 * h;
@@ -928,13 +1066,13 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         lds_barrier();
-        bundle_fetch(max(t - 1, 0));         // next wavefront's bundle: in flight for the whole step, parked in the last stage
+        bundle_fetch(max(t - 1, t_first));   // next wavefront's bundle: in flight for the whole step, parked in the last stage
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
         // relu sign bits of this wavefront: one word per thread to park (threads 0..263), plus the four words that hold this thread's four
         // Ho2 elements for the rank-1 product of the presence stage
-        const unsigned long long* const mbt = P.mbits + ((size_t)b * T + t) * (MB_TILES * 4);
+        const unsigned long long* const mbt = P.mbits + ((size_t)(b * NBn + band) * T + t) * (MB_TILES * 4);
         const unsigned long long mbq = mbt[min(tid, MB_TILES * 4 - 1)];
         const int ho_q4 = min(tid & 31, 24);          // the pres stage's mapping: 32 lanes per row, lanes 0..24 own 4 columns of Ho2 each
         // the four sign-bit words of this thread's columns 4*l .. 4*l+3 (tile l>>2, column group l&3: one word per column)
@@ -956,16 +1094,18 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         // (branch-free: the four consumer slots are read side by side -- with a `continue` per slot the loop was twelve dependent LDS
         // round trips, 1.2 us per wavefront)
         {
-            const int d1 = dstart_sh[min(t + 1, T)], d2 = dstart_sh[min(t + 2, T)], d3 = dstart_sh[min(t + 3, T)];
+            const int d1 = bc0_sh[min(t + 1, T)], d2 = bc0_sh[min(t + 2, T)], d3 = bc0_sh[min(t + 3, T)];
+            const int hlast = band < NBn - 1 ? hb1 - 1 : -1;      // the grid row whose UL / U / UR consumers live in the band below
             const float (*r1)[LD_R] = ring[(t + 1) & 3];
             const float (*r2)[LD_R] = ring[(t + 2) & 3];
             const float (*r3)[LD_R] = ring[(t + 3) & 3];
             for (int idx = tid; idx < nc * REC; idx += NTH) {
                 const int row = idx / REC, j = idx - row * REC;
                 const int4 q = *reinterpret_cast<const int4*>(cons_sh[row]);
-                const float v0 = r3[min(max(q.x - d3, 0), MT - 1)][F + j];
-                const float v1 = r2[min(max(q.y - d2, 0), MT - 1)][F + REC + j];
-                const float v2 = r1[min(max(q.z - d1, 0), MT - 1)][F + 2 * REC + j];
+                const bool far = row_h[row] == hlast;
+                const float v0 = far ? bgrad_sh[0][j] : r3[min(max(q.x - d3, 0), MT - 1)][F + j];
+                const float v1 = far ? bgrad_sh[1][j] : r2[min(max(q.y - d2, 0), MT - 1)][F + REC + j];
+                const float v2 = far ? bgrad_sh[2][j] : r1[min(max(q.z - d1, 0), MT - 1)][F + 2 * REC + j];
                 const float v3 = r1[min(max(q.w - d1, 0), MT - 1)][F + 3 * REC + j];
                 float g = q.x >= 0 ? v0 : 0.f;
                 g += q.y >= 0 ? v1 : 0.f;
@@ -1072,6 +1212,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             wg_gemm_wt<4, 7>(Aa, LD_H, a.wt[CW_ZH], pipe, wave, lane,
                 [&](int j, int nt, const f32x4& acc) { hidden_epi<7>(nt, acc, mb_sh + MB_HZ2 * 4, SP_H, Ab, nullptr, 0, row_r, nc, lane); },
                 [&]() { pipe_fill_w<4, 7>(a.wt[CW_Z1], pipe, wave, lane); });
+        } else if (band < NBn - 1 && t > t_first) {
+            fetch_grad(t - 1, lane);          // (bgrad_sh's readers of this wavefront are behind the grec barrier)
         }
         lds_barrier();
         CB_STAMP();
@@ -1227,7 +1369,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // ---- d feat out; out-of-grid context slots feed the learned edge element
-        if (wave == 7) copy_rows_w<25, 8>(Aa, LD_H * 2, P.dHb1, (size_t)SP_LDH * 2, row_r, nc, lane);      // BOX1's output
+        if (wave == 7) {
+            copy_rows_w<25, 8>(Aa, LD_H * 2, P.dHb1, (size_t)SP_LDH * 2, row_r, nc, lane);      // BOX1's output
+            publish_grad(t, slot, lane);
+        }
         // four columns per thread (F and REC are multiples of 4: a quad never straddles the feature / neighbour-slot boundaries)
         for (int idx = tid; idx < nc * (F / 4); idx += NTH) {
             const int row = idx / (F / 4), n = (idx - row * (F / 4)) * 4;
@@ -1258,7 +1403,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         CB_STAMP();
     }
     // per-(sample, neighbour slot) partials of the edge element's gradient; chain_edge_reduce adds them in a fixed order
-    if (tid >= NTH / 2 && tid < NTH / 2 + 4 * REC) a.gedge_part[(size_t)b * 4 * REC + (tid - NTH / 2)] = edge_reg;
+    if (tid >= NTH / 2 && tid < NTH / 2 + 4 * REC) a.gedge_part[(size_t)(b * NBn + band) * 4 * REC + (tid - NTH / 2)] = edge_reg;
 }
 
 // gedge[j] += sum_b sum_s part[b][s][j]: 16 row groups of one workgroup sum contiguous chunks in row order (8 loads in flight each), then the
@@ -1290,14 +1435,24 @@ __global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ 
     }
 }
 
+int chain_bands(const SpairDims& d) { return d.G > 16 ? (d.G + 7) / 8 : 1; }      // G <= 32 (chain_fwd_supported): at most CHAIN_MAX_BANDS
+
+static int chain_sync_reset(const ChainArgs& a, hipStream_t s) {
+    if (a.nbands <= 1) return SPAIR_OK;
+    if (!a.sync || !a.bnd_rec || !a.bnd_grad) return SPAIR_ERR_SHAPE;
+    const size_t n = (size_t)CHAIN_SYNC_HDR + 2 * (size_t)a.L.B * a.nbands;
+    return hipMemsetAsync(a.sync, 0, n * sizeof(int), s) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
+}
+
 int chain_bwd(const ChainArgs& a, hipStream_t s) {
     if (!a.gedge_part) return SPAIR_ERR_SHAPE;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(a.L.B), dim3(NTH), 0, s, a);
+    if (chain_sync_reset(a, s) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_chain_bwd, dim3(a.L.B * a.nbands), dim3(NTH), 0, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
 int chain_edge_reduce(const ChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(1024), 0, s, a.gedge_part, a.L.B, a.gedge);
+    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(1024), 0, s, a.gedge_part, a.L.B * a.nbands, a.gedge);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
@@ -1310,8 +1465,9 @@ int chain_fwd_supported(const SpairDims& d) {
 int chain_image_fp16(const SpairDims& d) { return chain_fwd_supported(d) && d.I <= IMG_MAX && (d.I * d.I) % 4 == 0; }
 
 int chain_fwd(const ChainArgs& a, hipStream_t s) {
-    if (a.I <= IMG_MAX && (a.I * a.I) % 4 == 0) hipLaunchKernelGGL(k_chain_fwd<true>, dim3(a.L.B), dim3(NTH), 0, s, a);
-    else hipLaunchKernelGGL(k_chain_fwd<false>, dim3(a.L.B), dim3(NTH), 0, s, a);
+    if (chain_sync_reset(a, s) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
+    if (a.I <= IMG_MAX && (a.I * a.I) % 4 == 0) hipLaunchKernelGGL(k_chain_fwd<true>, dim3(a.L.B * a.nbands), dim3(NTH), 0, s, a);
+    else hipLaunchKernelGGL(k_chain_fwd<false>, dim3(a.L.B * a.nbands), dim3(NTH), 0, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

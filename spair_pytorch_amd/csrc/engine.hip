@@ -141,6 +141,8 @@ struct Ws {
     void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
     float *tn_part, *tn_part2;                          // split-K partial tiles of the weight-gradient GEMMs (caller's / helper stream)
     float *aux, *bce_partial, *kl_partial, *klp, *gedge_part;
+    int* chain_sync;                  // band split of the fused chain (chain.h): start tickets, time-out word, per-(sample, band) counters
+    float *bnd_rec, *bnd_grad;        // ... and the boundary rows handed from band to band
     unsigned long long* stamps;
     int ld_feat, ld_s;
     size_t total;
@@ -233,7 +235,8 @@ static Ws carve(const SpairDims& d, void* base) {
     w.Za = c.take<float>(N * L.ld_rec);
     b.Za = w.Za;
     b.gxy = chain_fwd_supported(d) ? c.take<unsigned int>(N * L.ld_gl) : nullptr;
-    b.mbits = chain_fwd_supported(d) ? c.take<unsigned long long>((size_t)d.B * (3 * d.G - 2) * 66 * 4) : nullptr;
+    const int nbands = chain_fwd_supported(d) ? chain_bands(d) : 1;
+    b.mbits = chain_fwd_supported(d) ? c.take<unsigned long long>((size_t)d.B * nbands * (3 * d.G - 2) * 66 * 4) : nullptr;
     w.Hd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es)); w.Hd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es));
     w.S = c.take<float>(N * w.ld_s);
     w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
@@ -246,7 +249,10 @@ static Ws carve(const SpairDims& d, void* base) {
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
-    w.gedge_part = c.take<float>((size_t)d.B * 4 * L.REC);
+    w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);
+    w.chain_sync = nbands > 1 ? c.take<int>((size_t)CHAIN_SYNC_HDR + 2 * (size_t)d.B * nbands) : nullptr;
+    w.bnd_rec = nbands > 1 ? c.take<float>((size_t)d.B * nbands * d.G * L.REC) : nullptr;
+    w.bnd_grad = nbands > 1 ? c.take<float>((size_t)d.B * nbands * d.G * 3 * L.REC) : nullptr;
     w.stamps = c.take<unsigned long long>(4096);
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
@@ -865,6 +871,7 @@ static int cells_fwd(Ctx& c) {
         a.bias[CW_OBJ0] = pr + PL.lin[LIN_OBJ0].b; a.bias[CW_OBJ1] = pr + PL.lin[LIN_OBJ1].b; a.bias[CW_OBJ2] = pr + PL.lin[LIN_OBJ2].b;
         a.x = c.x; a.I = c.d.I; a.Pp = c.d.P; a.ac = c.d.align_corners;
         a.w_obj2 = pr + PL.lin[LIN_OBJ2].w; a.gedge = nullptr; a.stamps = (c.st.flags & 2) ? c.w.stamps : nullptr;
+        a.nbands = chain_bands(c.d); a.sync = c.w.chain_sync; a.bnd_rec = c.w.bnd_rec; a.bnd_grad = c.w.bnd_grad;
         for (int i = 0; i < CW_COUNT; ++i) a.wt[i] = nullptr;
         return chain_fwd(a, c.s);
     }
@@ -1199,6 +1206,7 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         a.gedge = grads + PL.edge; a.gedge_part = c.w.gedge_part;
         a.x = x; a.I = d->I; a.Pp = d->P; a.ac = d->align_corners;
         a.stamps = (st->flags & 2) ? c.w.stamps : nullptr;
+        a.nbands = chain_bands(*d); a.sync = c.w.chain_sync; a.bnd_rec = c.w.bnd_rec; a.bnd_grad = c.w.bnd_grad;
         TRY(chain_bwd(a, c.s));
         chain_args = a;
     } else {
@@ -1269,6 +1277,23 @@ extern "C" int spair_chain_stamps(const SpairDims* d, const void* workspace, uns
     const Ws w = carve(*d, const_cast<void*>(workspace));
     if (hipMemcpyAsync(out, w.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return SPAIR_ERR_LAUNCH;
     return SPAIR_OK;
+}
+
+// band split of the fused chain kernels: 1 if a wait for the neighbouring band timed out in the latest launch on this workspace (results
+// are then wrong; never seen -- the test suite asserts 0), else 0; -1 where the chain runs unsplit.  Copies one int to `out` (device).
+extern "C" int spair_chain_sync_status(const SpairDims* d, const void* workspace, int* out, void* stream) {
+    if (!d || !workspace || !out) return SPAIR_ERR_SHAPE;
+    TRY(validate(*d));
+    const Ws w = carve(*d, const_cast<void*>(workspace));
+    if (!w.chain_sync) return hipMemsetAsync(out, 0xff, sizeof(int), (hipStream_t)stream) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
+    return hipMemcpyAsync(out, w.chain_sync + 2, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
+}
+// number of wavefronts the stamping workgroup (sample 0, top band) walks: 3G-2 unsplit, its band's share otherwise
+extern "C" int spair_chain_stamp_wavefronts(const SpairDims* d) {
+    if (!d) return SPAIR_ERR_SHAPE;
+    const int nb = chain_fwd_supported(*d) ? chain_bands(*d) : 1;
+    const int hb = (d->G + nb - 1) / nb;
+    return 2 * (hb - 1) + d->G;
 }
 
 // diagnostic: how the stamp buffer is laid out -- stamps per wavefront of the forward kernel (at offset 0), index of the glimpse-sampling

@@ -76,3 +76,50 @@ def test_helper_stream_off_gives_the_same_step():
     assert a["terms"][0].item() == b["terms"][0].item()
     ga, gb = a["grads"].double(), b["grads"].double()
     assert (ga - gb).norm().item() <= 1e-5 * gb.norm().item()      # (bit-equal in practice: the bf16 step sums in a fixed order on either stream layout)
+
+
+def _sync_status(m):
+    import ctypes
+    from spair_pytorch_amd import _lib as L
+    e = m._last["engine"]
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.check(L.lib().spair_chain_sync_status(ctypes.byref(e["dims"]), L.ptr(e["workspace"]), L.ptr(out), L.stream()), "sync_status")
+    return int(out.item())
+
+
+@pytest.mark.parametrize("I,B", [(256, 3), (256, 64), (128, 5)])
+def test_band_split_hand_off_never_times_out(I, B):
+    """Grids wider than 16 cells run TWO workgroups per sample (upper / lower half of the grid rows) that hand the boundary row's records
+    (forward) and context gradients (backward) to each other through the workspace behind agent-scope counters.  Every wait is bounded; a
+    time-out sets a status word.  It must read 0 after a forward and after a backward at 32 x 32 (B = 3: fewer workgroups than CUs; B = 64:
+    BASELINE configs[3]), and -1 (unsplit) at 16 x 16; the step itself must equal the per-wavefront launches (no split there)."""
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd import models
+    from spair_pytorch_amd.data import scattered_digits
+    strides = (2, 2, 2, 1, 1, 1)
+    cfg.set_grid(I, strides)
+    G = gi.grid_side(I, strides)
+    torch.manual_seed(11)
+    x = torch.from_numpy(scattered_digits(3 + B, B, I, 9)[0]).cuda()
+    noise = {k: torch.from_numpy(v).cuda() for k, v in gi.make_noise(5 + B, B, G).items()}
+    res = {}
+    try:
+        for flags in (0, 1):
+            models.STEP_FLAGS = flags
+            torch.manual_seed(3)
+            m = models.SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype="bf16").to("cuda")
+            m.zero_grad()
+            loss, recon, z_where, z_pres = m(x, 2500, noise=noise)
+            st_f = _sync_status(m) if flags == 0 else None
+            loss.backward()
+            st_b = _sync_status(m) if flags == 0 else None
+            res[flags] = (loss.item(), z_where.clone(), z_pres.clone(), m.flat_gradients().clone(), st_f, st_b)
+    finally:
+        models.STEP_FLAGS = 0
+    want = 0 if G > 16 else -1
+    assert res[0][4] == want and res[0][5] == want, (res[0][4], res[0][5])
+    la, zwa, zpa, ga = res[0][:4]
+    lb, zwb, zpb, gb = res[1][:4]
+    assert abs(la - lb) <= 2e-4 * abs(lb)
+    assert (zwa - zwb).abs().max().item() <= 2e-3 and (zpa - zpb).abs().max().item() <= 2e-3
+    assert (ga.double() - gb.double()).norm().item() <= 2e-2 * gb.double().norm().item()
