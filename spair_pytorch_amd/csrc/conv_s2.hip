@@ -29,6 +29,7 @@ constexpr int CP_LDC = CP_C + 16;                // epilogue staging row (bf16 e
 struct ConvPatchArgs {
     const u16* in; const u16* wf; const float* bias; u16* out;
     int B, Hin, Hout, M, K;                      // M = B * Hout * Hout, K = 16 * 128
+    int tpi;                                     // 0: tiles of 256 consecutive rows of the whole batch; > 0: tiles per image (a tile never crosses an image)
 };
 
 template <int W>
@@ -41,12 +42,22 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r16 = lane & 15;
     const int Hout = a.Hout, Ws = Hout + 1, Hs = Hout + 1;
-    const int m0 = blockIdx.x * CP_BM;
-    const int mlast = min(m0 + CP_BM, a.M) - 1;
-    // extended sub-lattice row of output row g = (b, y): E = g + b (every image owns Hout + 1 sub-lattice rows); the tile needs E0 .. E1
+    int m0, mend;
+    if (a.tpi) {
+        const int img = blockIdx.x / a.tpi, HH = Hout * Hout;
+        m0 = img * HH + (blockIdx.x - img * a.tpi) * CP_BM;
+        mend = min(m0 + CP_BM, (img + 1) * HH);
+    } else {
+        m0 = blockIdx.x * CP_BM;
+        mend = min(m0 + CP_BM, a.M);
+    }
+    const int mlast = mend - 1;
+    // extended sub-lattice row of output row g = (b, y): E = g + b (every image owns Hout + 1 sub-lattice rows).  The patch is the LINEAR
+    // window of sub-lattice pixels from the first tile pixel's tap (0, 0) to the last tile pixel's tap (1, 1) -- not whole rows E0 .. E1:
+    // 256 + Ws + 1 pixels plus one row per image boundary crossed, whatever the image side (whole rows refused conv_1 at 256 x 256)
     const int g0 = m0 / Hout, g1 = mlast / Hout;
-    const int E0 = g0 + g0 / Hout, E1 = g1 + g1 / Hout + 1;
-    const int npx = (E1 - E0 + 1) * Ws;          // <= CP_PPX (checked by the launcher)
+    const int L0 = (g0 + g0 / Hout) * Ws + (m0 - g0 * Hout);
+    const int npx = (g1 + g1 / Hout + 1) * Ws + (mlast - g1 * Hout) + 1 - L0 + 1;          // <= CP_PPX (checked by the launcher)
 
     // ---- roles.  Waves 0..7 are CONSUMERS (4 x 2, a 64 x 64 output tile each; two per SIMD, so that one's LDS round trip at the top of a K step
     // meets the other's MFMAs), waves 8..11 are LOADERS (one per SIMD): they issue every LDS-DMA of the workgroup and nothing else.  A DMA instruction costs its issuing wave ~100-200 cycles of queue back-pressure (the CU takes in
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
         for (int e = 0; e < CP_NPIECE_W; ++e) {
             const int piece = (part * 4 + lw) * CP_NPIECE_W + e;       // 0 .. 59, the patch has <= 49
             const int pp = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (pp & 7);
-            const int er = pp / Ws, xx = pp - er * Ws, E = E0 + er;
+            const int pg = L0 + pp, E = pg / Ws, xx = pg - E * Ws;
             const int b = E / Hs, yy = E - b * Hs;
             const bool ok = st < 8 && pp < npx && b < a.B;
             const unsigned off = (((unsigned)(b * a.Hin + 2 * yy + py) * (unsigned)a.Hin + (unsigned)(2 * xx + px)) * CP_C + half * 64 + c * 8) * 2u;
@@ -116,9 +127,9 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
         int pbase[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = min(m0 + wm * 64 + i * 16 + r16, a.M - 1);
+            const int m = min(m0 + wm * 64 + i * 16 + r16, mlast);
             const int g = m / Hout, x = m - g * Hout;
-            pbase[i] = (g + g / Hout - E0) * Ws + x;
+            pbase[i] = (g + g / Hout) * Ws + x - L0;
         }
         for (int st = 0; st < 8; ++st) {
             const char* pb = patch + (st & 1) * CP_PATCH_B;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
         for (int it = 0; it < CP_BM / 32; ++it) {
             const int row = it * 32 + (tid >> 4), ch = (tid & 15) * 8;
             const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
-            buf_store16(rout, (m0 + row) < a.M ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
+            buf_store16(rout, (m0 + row) < mend ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
         }
     }
 }
@@ -189,20 +200,27 @@ int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, voi
     if (cin != CP_C || cout != CP_C || k != 4 || s_ != 2 || Hin != 2 * Hout + 2 || B <= 0 || Hout <= 0) return SPAIR_ERR_UNSUPPORTED;
     const long long M = (long long)B * Hout * Hout;
     if (M * CP_C >= (1ll << 31) || (long long)B * Hin * Hin * CP_C >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
-    // the largest patch of any tile must fit the buffer (tiles start at multiples of 256 rows; the pattern repeats with lcm(256, Hout * Hout))
-    const int tiles = (int)((M + CP_BM - 1) / CP_BM);
-    int worst = 0;
-    for (int t = 0; t < tiles && t < 4096; ++t) {
-        const long long m0 = (long long)t * CP_BM, ml = std::min<long long>(m0 + CP_BM, M) - 1;
-        const int g0 = (int)(m0 / Hout), g1 = (int)(ml / Hout);
-        worst = std::max(worst, ((g1 + g1 / Hout + 1) - (g0 + g0 / Hout) + 1) * (Hout + 1));
+    // the largest patch window of any tile must fit the buffer: tiles of 256 consecutive rows of the whole batch if they do (the pattern repeats
+    // with lcm(256, Hout * Hout)), else tiles that restart at every image (the last tile of an image is partial), else not this kernel
+    auto window = [&](long long m0, long long ml) {
+        const long long g0 = m0 / Hout, g1 = ml / Hout;
+        return (int)((g1 + g1 / Hout + 1) * (Hout + 1) + (ml - g1 * Hout) + 1 - ((g0 + g0 / Hout) * (Hout + 1) + (m0 - g0 * Hout)) + 1);
+    };
+    int tiles = (int)((M + CP_BM - 1) / CP_BM), tpi = 0, worst = 0;
+    for (int t = 0; t < tiles && t < 4096; ++t) worst = std::max(worst, window((long long)t * CP_BM, std::min<long long>((long long)(t + 1) * CP_BM, M) - 1));
+    if (worst > CP_PPX) {
+        const int HH = Hout * Hout;
+        tpi = (HH + CP_BM - 1) / CP_BM;
+        worst = 0;
+        for (int t = 0; t < tpi; ++t) worst = std::max(worst, window((long long)t * CP_BM, std::min<long long>((long long)(t + 1) * CP_BM, HH) - 1));
+        if (worst > CP_PPX) return SPAIR_ERR_UNSUPPORTED;
+        tiles = B * tpi;
     }
-    if (worst > CP_PPX) return SPAIR_ERR_UNSUPPORTED;
     static std::atomic<unsigned long long> attr_done{0};
     if (spair_dyn_lds_once(reinterpret_cast<const void*>(&k_conv_s2k4_patch), CP_LDS, attr_done) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     ConvPatchArgs a;
     a.in = reinterpret_cast<const u16*>(in); a.wf = reinterpret_cast<const u16*>(wf); a.bias = bias; a.out = reinterpret_cast<u16*>(out);
-    a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C;
+    a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C; a.tpi = tpi;
     hipLaunchKernelGGL(k_conv_s2k4_patch, dim3(tiles), dim3(768), CP_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;

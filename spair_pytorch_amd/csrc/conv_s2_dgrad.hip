@@ -32,6 +32,7 @@ constexpr int DG_STEM_FLOATS = 128 * 17;
 struct ConvDgradArgs {
     const u16* dout; const u16* Bz[4]; const u16* gate; u16* out;
     int B, Ho, Hc, Hi, M;                        // d_out side, class-grid side Ho + 1, input side 2 Hc, M = B * Hc * Hc
+    int tpi;                                     // 0: tiles of 128 consecutive class pixels of the whole batch; > 0: tiles per image
     // STEM (conv_1): xp = zero-padded fp32 stem input [B][stem_hin][stem_hin], stride stem_s; one [128][17] partial per workgroup
     const float* stem_xp; float* stem_part; int stem_hin, stem_s;
 };
@@ -68,16 +69,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     // PERSISTENT: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (a tile is short-lived -- 32 K steps -- against
     // the 3-4 us a 160-KB workgroup takes to launch and fill its first patch; the loaders start the next tile's patch and weight tiles
     // behind barrier(32), under the computing waves' last class epilogue)
-    const int ntiles = (a.M + DG_BM - 1) / DG_BM;
-    int m0 = 0, E0 = 0, npx = 0;
+    const int ntiles = a.tpi ? a.B * a.tpi : (a.M + DG_BM - 1) / DG_BM;
+    int m0 = 0, mend = 0, L0 = 0, npx = 0;
     // class pixel m = (b, y, x) on the Hc x Hc class grid; g = b * Hc + y.  d_out rows with a zero border: extended row E = b * Hp + yd + 1;
-    // tap ty of class row g reads E = g + b + 1 - ty.  The tile needs E0 .. E1, every row Wp = Ho + 2 pixels (xd + 1 = x + 1 - tx).
+    // tap (ty, tx) of class pixel (g, x) reads extended pixel (g + b + 1 - ty) * Wp + x + 1 - tx, Wp = Ho + 2.  The patch is the LINEAR window
+    // of extended pixels from the first tile pixel's tap (1, 1) to the last tile pixel's tap (0, 0): 128 + Wp + 1 pixels plus a row per
+    // image boundary crossed (whole rows E0 .. E1 refused conv_1 at 256 x 256: 4-5 rows of 68).
     auto set_tile = [&](int tile) {
-        m0 = tile * DG_BM;
-        const int mlast = min(m0 + DG_BM, a.M) - 1;
+        if (a.tpi) {
+            const int img = tile / a.tpi, HH = Hc * Hc;
+            m0 = img * HH + (tile - img * a.tpi) * DG_BM;
+            mend = min(m0 + DG_BM, (img + 1) * HH);
+        } else {
+            m0 = tile * DG_BM;
+            mend = min(m0 + DG_BM, a.M);
+        }
+        const int mlast = mend - 1;
         const int g0 = m0 / Hc, g1 = mlast / Hc;
-        E0 = g0 + g0 / Hc;
-        npx = (g1 + g1 / Hc + 1 - E0 + 1) * Wp;  // <= DG_PPX (checked by the launcher)
+        L0 = (g0 + g0 / Hc) * Wp + (m0 - g0 * Hc);
+        npx = (g1 + g1 / Hc + 1) * Wp + (mlast - g1 * Hc) + 1 - L0 + 1;      // <= DG_PPX (checked by the launcher)
     };
     const bool loader = wave >= 4;
     const int lw = wave & 3;
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             for (int e = 0; e < npieces; ++e) {
                 const int piece = (part * 4 + lw) * npieces + e;
                 const int pp = piece * 8 + (lane >> 3), pos = lane & 7, c = pos ^ (pp & 7);
-                const int er = pp / Wp, xp = pp - er * Wp, E = E0 + er;
+                const int pg = L0 + pp, E = pg / Wp, xp = pg - E * Wp;
                 const int b = E / Hp, yd = E - b * Hp - 1, xd = xp - 1;
                 const bool ok = pp < npx && b < a.B && yd >= 0 && yd < Ho && xd >= 0 && xd < Ho;
                 const unsigned off = (((unsigned)(b * Ho + yd) * (unsigned)Ho + (unsigned)xd) * DG_C + half * 64 + c * 8) * 2u;
@@ -156,10 +166,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wm * 64 + j * 16 + r16;
-            ook[j] = m < a.M;
-            const int mc = min(m, a.M - 1);
+            ook[j] = m < mend;
+            const int mc = min(m, mend - 1);
             const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
-            pbase[j] = (g + b + 1 - E0) * Wp + x + 1;
+            pbase[j] = (g + b + 1) * Wp + x + 1 - L0;
             orow[j] = (unsigned)((b * a.Hi + 2 * y) * a.Hi + 2 * x);
         }
     };
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         if (STEM) {
             const int prow = tid >> 1, hf = tid & 1;
             const int m = m0 + prow;
-            sp_ok = m < a.M;
-            const int mc = min(m, a.M - 1);
+            sp_ok = m < mend;
+            const int mc = min(m, mend - 1);
             const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
             const int yy = 2 * y + py, xx = 2 * x + px;
             const float* src = a.stem_xp + ((size_t)b * a.stem_hin + yy * a.stem_s + 2 * hf) * a.stem_hin + xx * a.stem_s;
@@ -341,21 +351,27 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
     if (cin != DG_C || cout != DG_C || k != 4 || s_ != 2 || hin != 2 * Hc || B <= 0 || Ho <= 0) return SPAIR_ERR_UNSUPPORTED;
     const long long M = (long long)B * Hc * Hc;
     if ((long long)B * hin * hin * DG_C >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
-    const int tiles = (int)((M + DG_BM - 1) / DG_BM);
-    int worst = 0;
-    for (int t = 0; t < tiles && t < 8192; ++t) {
-        const long long m0 = (long long)t * DG_BM, ml = std::min<long long>(m0 + DG_BM, M) - 1;
-        const int g0 = (int)(m0 / Hc), g1 = (int)(ml / Hc);
-        worst = std::max(worst, ((g1 + g1 / Hc + 1) - (g0 + g0 / Hc) + 1) * (Ho + 2));
+    auto window = [&](long long m0, long long ml) {
+        const long long g0 = m0 / Hc, g1 = ml / Hc;
+        return (int)((g1 + g1 / Hc + 1) * (Ho + 2) + (ml - g1 * Hc) + 1 - ((g0 + g0 / Hc) * (Ho + 2) + (m0 - g0 * Hc)) + 1);
+    };
+    int tiles = (int)((M + DG_BM - 1) / DG_BM), tpi = 0, worst = 0;
+    for (int t = 0; t < tiles && t < 8192; ++t) worst = std::max(worst, window((long long)t * DG_BM, std::min<long long>((long long)(t + 1) * DG_BM, M) - 1));
+    if (worst > DG_PPX) {      // tiles that restart at every image (its last tile partial)
+        const int HH = Hc * Hc;
+        tpi = (HH + DG_BM - 1) / DG_BM;
+        worst = 0;
+        for (int t = 0; t < tpi; ++t) worst = std::max(worst, window((long long)t * DG_BM, std::min<long long>((long long)(t + 1) * DG_BM, HH) - 1));
+        if (worst > DG_PPX) return SPAIR_ERR_UNSUPPORTED;
+        tiles = B * tpi;
     }
-    if (worst > DG_PPX) return SPAIR_ERR_UNSUPPORTED;
     const bool stem = stem_part != nullptr;
     if (stem && (!stem_xp || !stem_dw || (long long)(tiles + 64) * DG_STEM_FLOATS > stem_part_cap || (stem_hin & 1) || (stem_s & 1))) return SPAIR_ERR_UNSUPPORTED;
     ConvDgradArgs a;
     a.dout = reinterpret_cast<const u16*>(dout);
     for (int q = 0; q < 4; ++q) a.Bz[q] = reinterpret_cast<const u16*>(wd[q]);
     a.gate = reinterpret_cast<const u16*>(gate); a.out = reinterpret_cast<u16*>(out);
-    a.B = B; a.Ho = Ho; a.Hc = Hc; a.Hi = hin; a.M = (int)M;
+    a.B = B; a.Ho = Ho; a.Hc = Hc; a.Hi = hin; a.M = (int)M; a.tpi = tpi;
     a.stem_xp = stem_xp; a.stem_part = stem_part; a.stem_hin = stem_hin; a.stem_s = stem_s;
     static std::atomic<unsigned long long> attr_done[2];
     {
