@@ -8,6 +8,7 @@ struct ChainArgs {
     CellBufs P;
     CellHyper H;
     const uint4* w[CW_COUNT];     // fragment-packed bf16 weights (k_prep mode 4 / 5)
+    const uint4* wlo[3];          // forward only: the LOW parts w - bf16(w) of the box network's three layers (split-bf16 products, chain.hip)
     const float* bias[CW_COUNT];
     const uint4* wt[CW_COUNT];    // data-gradient packs (k_prep mode 5): B[k=out][n=in]
     const float* w_obj2;          // obj_network.out.weight [1,100] fp32 (rank-1 data-gradient)

@@ -220,12 +220,61 @@ __device__ __forceinline__ void wg_gemm_t2(const __bf16* in, int ld, const uint4
     }
 }
 
+// SPLIT-bf16 stage (the box network, models.py:76-79): both operands as hi + lo bf16 pairs, three products per k-step (hi.hi + lo.hi + hi.lo;
+// what is dropped is < 2^-16 of the term), fp32 accumulate -- the layer at nearly fp32 precision for twice the weight bytes of three small
+// layers.  Why: the box places the glimpse and the sprite on the pixel grid; with plain bf16 operands the reconstruction moved by up to 0.05
+// against the reference and the gradients of the box / encoder weights turned to cos 0.92 on the small fixtures (0.995 with this).
+// Ring order: (k-step, {hi, lo}) pairs, as pipe_fill2 / wg_gemm_t2 with the two tiles replaced by the two packs of ONE tile.
+template <int KT, int NT>
+__device__ __forceinline__ void pipe_fill_s(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo, WPipe& p, int wave, int lane) {
+    const size_t o = (size_t)min(wave, NT - 1) * KT * 64 + lane;
+#pragma unroll
+    for (int s_ = 0; s_ < RD; ++s_)
+        if ((s_ >> 1) < KT) p.q[s_] = ((s_ & 1) ? Wlo : Whi)[o + (s_ >> 1) * 64];
+}
+template <int KT, int NT, int CH>
+__device__ __forceinline__ void wg_gemm_s(const __bf16* inHi, const __bf16* inLo, int ld, const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                          WPipe& p, const float* bias_l, f32x4& acc, int wave, int lane) {
+    constexpr int NCH = (KT + CH - 1) / CH, AH = RD / 2;
+    const int nt = min(wave, NT - 1);
+    const size_t o = (size_t)nt * KT * 64 + lane;
+    const int eoff = (lane & 15) * ld + (lane >> 4) * 8;
+    bf16x8 xh[2][CH], xl[2][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+        if (j < KT) { xh[0][j] = *reinterpret_cast<const bf16x8*>(inHi + eoff + j * 32); xl[0][j] = *reinterpret_cast<const bf16x8*>(inLo + eoff + j * 32); }
+    acc = *reinterpret_cast<const f32x4*>(bias_l + nt * 16 + (lane >> 4) * 4);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if ((c + 1) * CH + j < KT) {
+                    xh[(c + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(inHi + eoff + ((c + 1) * CH + j) * 32);
+                    xl[(c + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(inLo + eoff + ((c + 1) * CH + j) * 32);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int f = c * CH + j;
+            if (f < KT) {
+                const bf16x8 wh = as_frag(p.q[(2 * f) % RD]), wl = as_frag(p.q[(2 * f + 1) % RD]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[c & 1][j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[c & 1][j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c & 1][j], acc, 0, 0, 0);
+                if (f + AH < KT) { p.q[(2 * f) % RD] = Whi[o + (size_t)(f + AH) * 64]; p.q[(2 * f + 1) % RD] = Wlo[o + (size_t)(f + AH) * 64]; }
+            }
+        }
+    }
+}
+
 // epilogue of a lean stage.  ncol4 = number of output columns rounded up to 4 (quads past it are padding: not written); nbf = columns that
 // get the bf16 LDS copy (the next layer's input tile); hbm16 = bf16 row buffer written straight from the epilogue (8 bytes per lane).
 template <int NT, bool RELU, int NT0 = 0>
 __device__ __forceinline__ void wg_store_t(const f32x4& acc, int ncol4, __bf16* lds_bf, int ld_bf, int nbf, float* lds_f, int ld_f,
                                            __bf16* __restrict__ hbm16, int ld_hbm, const int* row_r, int nc, int wave, int lane,
-                                           unsigned long long* __restrict__ mb = nullptr) {
+                                           unsigned long long* __restrict__ mb = nullptr, __bf16* lds_lo = nullptr) {
     const int nt = NT0 + wave;
     if (nt >= NT) return;                                        // wave-uniform
     const int col0 = nt * 16 + (lane >> 4) * 4, row = lane & 15;
@@ -248,6 +297,8 @@ __device__ __forceinline__ void wg_store_t(const f32x4& acc, int ncol4, __bf16* 
     if (lds_bf || hbm16) {
         const bf16x4 o = pack4(v[0], v[1], v[2], v[3]);
         if (lds_bf && col0 < nbf) *reinterpret_cast<bf16x4*>(lds_bf + row * ld_bf + col0) = o;
+        if (lds_lo && col0 < nbf)      // the LOW part of the next split stage's operand: what the bf16 rounding of `o` dropped
+            *reinterpret_cast<bf16x4*>(lds_lo + row * ld_bf + col0) = pack4(v[0] - (float)o[0], v[1] - (float)o[1], v[2] - (float)o[2], v[3] - (float)o[3]);
         if (hbm16 && row < nc) CH_GSTORE(reinterpret_cast<bf16x4*>(hbm16 + (size_t)row_r[row] * ld_hbm + col0), o);
     }
 }
@@ -317,6 +368,12 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     const int HBd = (G + NBn - 1) / NBn, hb0 = band * HBd, hb1 = min(G, hb0 + HBd);
     const int t_first = 2 * hb0, t_last = 2 * (hb1 - 1) + G - 1;
     int* const flag_mine = a.sync ? a.sync + CHAIN_SYNC_HDR + b * NBn + band : nullptr;
+    // the LOW halves of the box network's split-bf16 operands live in the glimpse tile, which is idle until the box is known:
+    // [feat | ctx] low (dead after BOX0; BOX1's output low part re-uses it) and BOX0's output low part behind it
+    __bf16* const XcLo = Gl;
+    __bf16* const HaLo = Gl + MT * LD_XC;
+    __bf16* const HbLo = Gl;
+    static_assert(MT * LD_XC + MT * LD_H <= MT * LD_GL, "low tiles fit the glimpse tile");
     float* const sd_stage = &feat_sh[0][0];                    // [MT][52]
     float* const stat_stage = &feat_sh[0][0] + MT * 52;        // [MT][12]: mu_box 4 | sd_box 4 | mu_depth | sd_depth | 0 | 0
     constexpr int LD_SD = 52, LD_ST = 12;
@@ -469,7 +526,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     };
 
     WPipe pipe;
-    pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);      // (all eight waves here: the ring registers must be defined on every path)
+    pipe_fill_s<11, 7>(a.w[CW_BOX0], a.wlo[CW_BOX0], pipe, wave, lane);      // (all eight waves here: the ring registers must be defined on every path)
     int stamp_i = 0;
     int nc_prev = 0;
 #define CH_STAMP() do { if (a.stamps && b == 0 && band == 0 && tid == 0) a.stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -515,16 +572,18 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 }
                 v = *reinterpret_cast<const float4*>(src);
             }
-            *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = pack4(v.x, v.y, v.z, v.w);
+            const bf16x4 hi = pack4(v.x, v.y, v.z, v.w);
+            *reinterpret_cast<bf16x4*>(&Xc[row * LD_XC + c4]) = hi;
+            *reinterpret_cast<bf16x4*>(&XcLo[row * LD_XC + c4]) = pack4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
         }
         lds_barrier();
         CH_STAMP();
         // ---- z_where: box MLP (models.py:76-77)
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm_t<11, 0, 7>(Xc, LD_XC, nullptr, 0, a.w[CW_BOX0], pipe, bias_sh + BIAS_OFF[CW_BOX0], acc, wave, lane);
-            pipe_fill<4, 7>(a.w[CW_BOX1], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB1 * 4);
+            wg_gemm_s<11, 7, 4>(Xc, XcLo, LD_XC, a.w[CW_BOX0], a.wlo[CW_BOX0], pipe, bias_sh + BIAS_OFF[CW_BOX0], acc, wave, lane);
+            pipe_fill_s<4, 7>(a.w[CW_BOX1], a.wlo[CW_BOX1], pipe, wave, lane);
+            wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB1 * 4, HaLo);
         } else {
             // (every operand of the weight-gradient GEMMs is stored as bf16 by this kernel: same leading dimensions in elements, the buffers
             //  are sized for the per-wavefront path's fp32; the z / obj nets read these columns from Xb too)
@@ -534,9 +593,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_BOX1], pipe, bias_sh + BIAS_OFF[CW_BOX1], acc, wave, lane);
-            pipe_fill<4, 7>(a.w[CW_BOXH], pipe, wave, lane);
-            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB2 * 4);
+            wg_gemm_s<4, 7, 4>(Ha, HaLo, LD_H, a.w[CW_BOX1], a.wlo[CW_BOX1], pipe, bias_sh + BIAS_OFF[CW_BOX1], acc, wave, lane);
+            pipe_fill_s<4, 7>(a.w[CW_BOXH], a.wlo[CW_BOXH], pipe, wave, lane);
+            wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HB2 * 4, HbLo);
         } else {
             copy_rows_w<25, 8>(Ha, LD_H * 2, P.Hb1, (size_t)SP_LDH * 2, rr_cur, nc, lane);
         }
@@ -547,7 +606,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // a 16-thread latent pass) of its own.
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_BOXH], pipe, bias_sh + BIAS_OFF[CW_BOXH], acc, wave, lane);
+            wg_gemm_s<4, 7, 4>(Hb, HbLo, LD_H, a.w[CW_BOXH], a.wlo[CW_BOXH], pipe, bias_sh + BIAS_OFF[CW_BOXH], acc, wave, lane);
             wg_store_t<7, false>(acc, NP + 8, XtZ, LD_XT, NP, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         } else {
             copy_rows_w<25, 8>(Hb, LD_H * 2, P.Hb2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
@@ -753,7 +812,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Ha, LD_H, nullptr, 0, a.w[CW_OBJ1], pipe, bias_sh + BIAS_OFF[CW_OBJ1], acc, wave, lane);
-            pipe_fill<11, 7>(a.w[CW_BOX0], pipe, wave, lane);
+            pipe_fill_s<11, 7>(a.w[CW_BOX0], a.wlo[CW_BOX0], pipe, wave, lane);
             wg_store_t<7, true>(acc, 100, Hb, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HO2 * 4);
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2_sh + wave * 16 + (lane >> 4) * 4);
             float pz = 0.f;

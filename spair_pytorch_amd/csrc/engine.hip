@@ -131,6 +131,7 @@ struct Ws {
     void* lin_wt[LIN_COUNT];
     float *bias_boxh, *bias_zh;
     void* chain_w[CW_COUNT];      // fragment-packed weights for the fused chain (bf16)
+    void* chain_wlo[3];           // low parts of the box network's packs (split-bf16 forward)
     void* chain_wt[CW_COUNT];     // ... and their data-gradient packs
     void* dec_stream;             // fused decoder forward: fragment stream of its three weight matrices (bf16 mode)
     float* xpad;
@@ -198,6 +199,7 @@ static Ws carve(const SpairDims& d, void* base) {
         const int nt[CW_COUNT] = {7, 7, 7, 16, 8, 7, 7, 7, 7, 7, 7, 1};
         const int kt[CW_COUNT] = {11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4, 4};
         for (int i = 0; i < CW_COUNT; ++i) w.chain_w[i] = c.take_bytes((size_t)nt[i] * kt[i] * 1024);
+        for (int i = 0; i < 3; ++i) w.chain_wlo[i] = c.take_bytes((size_t)nt[i] * kt[i] * 1024);
         const int ntb[CW_COUNT] = {21, 7, 7, 49, 16, 8, 30, 7, 7, 30, 7, 0};
         const int ktb[CW_COUNT] = {4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0};
         for (int i = 0; i < CW_COUNT; ++i) w.chain_wt[i] = ntb[i] ? c.take_bytes((size_t)ntb[i] * ktb[i] * 1024) : nullptr;
@@ -548,6 +550,13 @@ static int prep_weights(Ctx& c, bool need_dgrad, int part) {
             es.push_back(e);
         };
         const int fc = c.L.F + c.L.CTX;   // 324
+        auto pack_lo = [&](int cw, int lin_id, int KT, int ksplit, int kpad0, int n_off) {      // same pack, low parts (bf16 = 2)
+            pack(cw, lin_id, KT, ksplit, kpad0, n_off);
+            es.back().dst = c.w.chain_wlo[cw]; es.back().bf16 = 2;
+        };
+        pack_lo(CW_BOX0, LIN_BOX0, 11, fc, 352, 0);
+        pack_lo(CW_BOX1, LIN_BOX1, 4, SP_H, 128, 0);
+        pack_lo(CW_BOXH, LIN_BOXH1, 4, SP_H, 128, 0); pack_lo(CW_BOXH, LIN_BOXH0, 4, SP_H, 128, c.L.NP);
         pack(CW_BOX0, LIN_BOX0, 11, fc, 352, 0);
         pack(CW_BOX1, LIN_BOX1, 4, SP_H, 128, 0);
         pack(CW_BOXH, LIN_BOXH1, 4, SP_H, 128, 0); pack(CW_BOXH, LIN_BOXH0, 4, SP_H, 128, c.L.NP);
@@ -856,6 +865,19 @@ static int fwd_lin(Ctx& c, int id, const float* A, int lda, float* C, int ldc, i
     return nt(c, A + (size_t)r0 * lda, lda, c.w.lin_wf[id], K, C + (size_t)r0 * ldc, ldc, R, N, K, bias, nullptr, 0, relu);
 }
 
+// The box network's forward in the bf16 step runs at (nearly) fp32 precision -- split-bf16 products in the fused kernel (chain.hip), the raw
+// fp32 parameters here in the per-wavefront reference path: its outputs place the glimpse and the sprite on the pixel grid, and bf16 operands
+// there move the reconstruction by up to 0.05 and the box / encoder gradients' direction to cos 0.92 against the reference
+// (tools/exp/f32nets_table.py; models.py:76-79,322-381).
+static int fwd_lin_f32(Ctx& c, int id, const float* A, int lda, float* C, int ldc, int c0, int r0, int R, int relu) {
+    const LinSpec& l = c.PL.lin[id];
+    GemmNT g;
+    memset(&g, 0, sizeof(g));
+    g.A = A + (size_t)r0 * lda; g.lda = lda; g.B = c.params + l.w; g.ldb = l.in; g.C = C + (size_t)r0 * ldc + c0; g.ldc = ldc;
+    g.M = R; g.N = l.out; g.K = l.in; g.bias = c.params + l.b; g.relu = relu;
+    return spair_gemm_nt_impl(g, false, SPAIR_F32, c.s);
+}
+
 static int cells_fwd(Ctx& c) {
     const CellLayout& L = c.L;
     CellBufs& P = c.w.cb;
@@ -865,6 +887,7 @@ static int cells_fwd(Ctx& c) {
         ChainArgs a;
         a.L = L; a.P = P; a.H = c.H;
         for (int i = 0; i < CW_COUNT; ++i) a.w[i] = reinterpret_cast<const uint4*>(c.w.chain_w[i]);
+        for (int i = 0; i < 3; ++i) a.wlo[i] = reinterpret_cast<const uint4*>(c.w.chain_wlo[i]);
         a.bias[CW_BOX0] = pr + PL.lin[LIN_BOX0].b; a.bias[CW_BOX1] = pr + PL.lin[LIN_BOX1].b; a.bias[CW_BOXH] = c.w.bias_boxh;
         a.bias[CW_ENC0] = pr + PL.lin[LIN_ENC0].b; a.bias[CW_ENC1] = pr + PL.lin[LIN_ENC1].b; a.bias[CW_ENC2] = pr + PL.lin[LIN_ENC2].b;
         a.bias[CW_Z0] = pr + PL.lin[LIN_Z0].b; a.bias[CW_Z1] = pr + PL.lin[LIN_Z1].b; a.bias[CW_ZH] = c.w.bias_zh;
@@ -879,9 +902,16 @@ static int cells_fwd(Ctx& c) {
         const int r0 = c.dstart[t] * L.B, R = (c.dstart[t + 1] - c.dstart[t]) * L.B;
         TRY(cells_ctx_gather(L, P, r0, R, c.s));
         // z_where
+        if (c.d.dtype == SPAIR_BF16 && (PL.lin[LIN_BOX0].in & 3) == 0) {
+            TRY(fwd_lin_f32(c, LIN_BOX0, P.Xb, L.ld_xb, P.Hb1, SP_LDH, 0, r0, R, 1));
+            TRY(fwd_lin_f32(c, LIN_BOX1, P.Hb1, SP_LDH, P.Hb2, SP_LDH, 0, r0, R, 1));
+            TRY(fwd_lin_f32(c, LIN_BOXH1, P.Hb2, SP_LDH, P.Ob, L.ld_ob, 0, r0, R, 0));
+            TRY(fwd_lin_f32(c, LIN_BOXH0, P.Hb2, SP_LDH, P.Ob, L.ld_ob, L.ob_lat, r0, R, 0));
+        } else {
         TRY(fwd_lin(c, LIN_BOX0, P.Xb, L.ld_xb, P.Hb1, SP_LDH, r0, R, pr + PL.lin[LIN_BOX0].b, SP_H, 1));
         TRY(fwd_lin(c, LIN_BOX1, P.Hb1, SP_LDH, P.Hb2, SP_LDH, r0, R, pr + PL.lin[LIN_BOX1].b, SP_H, 1));
         TRY(fwd_lin(c, LIN_BOXH1, P.Hb2, SP_LDH, P.Ob, L.ld_ob, r0, R, c.w.bias_boxh, L.NP + 8, 0));
+        }
         TRY(cells_box_sample(L, P, c.H, r0, R, c.s));
         // z_what
         { ProfScope ps(PS_STN_FWD, c.s); TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, chain_image_fp16(c.d), c.s)); }

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_prep(PrepTable T) {
             const int r = (int)(idx / KP), kk = (int)(idx - (long long)r * KP);
             int col = (kk < e.kpad0) ? (kk < e.ksplit ? kk : -1) : e.ksplit + (kk - e.kpad0);
             if (col >= e.cols) col = -1;
-            const float v = col >= 0 ? e.src[(size_t)r * e.cols + col] : 0.f;
+            float v = col >= 0 ? e.src[(size_t)r * e.cols + col] : 0.f;
+            if (e.bf16 == 2) v -= (float)(__bf16)v;              // the LOW part of a split-bf16 operand (chain.hip, box network)
             const int nn = e.n_off + r, nt = nn >> 4, li = nn & 15, kt = kk >> 5, g = (kk & 31) >> 3, j = kk & 7;
             reinterpret_cast<__bf16*>(e.dst)[(((size_t)nt * e.KT + kt) * 64 + g * 16 + li) * 8 + j] = (__bf16)v;
         }

@@ -72,23 +72,24 @@ def test_fp32_step_matches_reference(name):
     assert not bad, bad
 
 
-# Per-case bounds of the bf16 step against the reference's fixtures.  Evidence: profiles/r03_bf16_parity_table.txt (tools/bf16_parity_table.py,
-# every tensor of every case; the step has no atomics any more, so the table repeats bit for bit and the bounds sit close above it).
-# loss: BASELINE.json asks for 1e-3 relative; with fp16 sprites 1.3e-5 .. 1.2e-4 is observed.  recon: absolute, on a [0, 1] image.
-# Gradients: |g| / |g_ref| - 1 and the cosine, per tensor.  The backbone / z / obj / decoder / encoder-output tensors sit at cos >= 0.99
-# everywhere; the box network and the encoder's first layers are the sensitive ones (their gradient is a sum over few rows -- B*G*G =
-# 242 .. 576 in the small cases -- of terms that pass through the STN's image gradients and 3G-2 dependent bf16 stages): 0.937 with the
-# 2x weight scale and the sharp count prior of step 7001, 0.918 on the reference's default 11x11 grid with batch 2, >= 0.992 from 512 rows up.
+# Per-case bounds of the bf16 step against the reference's fixtures.  Evidence: profiles/r04_bf16_parity_table.txt (tools/bf16_parity_table.py,
+# every tensor of every case; the step has no atomics, so the table repeats bit for bit).
+# loss: BASELINE.json asks for 1e-3 relative; 3e-5 .. 1.6e-4 is observed.  recon: absolute, on a [0, 1] image.
+# Gradients: |g| / |g_ref| - 1 and the cosine, per tensor.
+# Round 4: the box network's forward runs as split-bf16 products (hi + lo operands, chain.hip) -- its outputs place the glimpse and the sprite on
+# the pixel grid.  z_where now agrees to 1e-6 .. 3e-5 (2e-4 before), the reconstruction to 3e-4 .. 6e-3 (2e-3 .. 5e-2), and the gradient direction of
+# every tensor of five fixtures is >= 0.995 (0.918 on the 11 x 11 grid before); the sharp-count-prior fixture with doubled weights, whose
+# encoder also needs the precision (tools/exp/f32nets_table.py: 0.995 with box AND encoder on fp32 operands), is at 0.957 (0.937).
+# The bounds leave room for the re-roll every later bf16 rounding gets from a last-bit change upstream (two builds that differ in one
+# sigmoid's last bit land 0.9963 / 0.9946 on c1_b16_step1's encoder.dense0).
 BF16_BOUNDS = {
-    #                          loss    recon   z_where  norm    cos        observed (r03 table): recon / z_where / norm / cos
-    # (round 4: 0.9946 -- two builds of the SAME kernels that differ only in the last bit of a sigmoid land 0.9963 and 0.9946 on this tensor and
-    #  are 0.9987 from each other: a bf16 rounding that flips early in the 3G-2 dependent steps re-rolls every later one; the bound leaves that band)
-    "c1_b16_step1":            (2.0e-4, 0.008,  0.001,   0.03,   0.992),    # 0.0044 / 2.4e-4 / -     / 0.9946  (training wheel: encoder + decoder only)
-    "c1_b8_step1001":          (2.0e-4, 0.006,  0.001,   0.02,   0.995),    # 0.0024 / 2.0e-4 / 0.012 / 0.9963
-    "c1_b8_step7001":          (2.0e-4, 0.070,  0.004,   0.15,   0.93),     # 0.054  / 2.3e-3 / 0.135 / 0.937   (sharp count prior, weights x2: the hardest fixture)
-    "c2_b2_step1001":          (2.0e-4, 0.010,  0.001,   0.02,   0.99),     # 0.0064 / 1.2e-4 / 0.010 / 0.9926  (the bench geometry: 128x128, 16x16 grid)
-    "ref_default_b2_step1001": (2.0e-4, 0.055,  0.001,   0.05,   0.91),     # 0.044  / 4.2e-4 / 0.042 / 0.918
-    "c4_b1_step1001":          (2.0e-4, 0.006,  0.001,   0.015,  0.99),     # 0.0028 / 4.6e-5 / 0.008 / 0.9946  (256x256, 32x32 grid)
+    #                          loss    recon   z_where  norm    cos        observed (r04 table): recon / z_where / norm / cos
+    "c1_b16_step1":            (2.0e-4, 0.002,  1.0e-4,  0.03,   0.990),    # 4.4e-4 / 9.6e-6 / -     / 0.9950  (training wheel: encoder + decoder only)
+    "c1_b8_step1001":          (2.0e-4, 0.002,  1.0e-4,  0.02,   0.990),    # 4.5e-4 / 6.8e-6 / 0.004 / 0.9979
+    "c1_b8_step7001":          (2.0e-4, 0.020,  3.0e-3,  0.08,   0.940),    # 6.1e-3 / 8.6e-4 / 0.049 / 0.9569  (sharp count prior, weights x2: the hardest fixture)
+    "c2_b2_step1001":          (2.0e-4, 0.002,  5.0e-5,  0.02,   0.990),    # 3.6e-4 / 3.2e-6 / 0.008 / 0.9978  (the bench geometry: 128x128, 16x16 grid)
+    "ref_default_b2_step1001": (2.5e-4, 0.012,  2.0e-4,  0.04,   0.985),    # 3.8e-3 / 2.6e-5 / 0.018 / 0.9957  (the reference's default 11 x 11 grid)
+    "c4_b1_step1001":          (2.0e-4, 0.002,  5.0e-5,  0.02,   0.990),    # 3.1e-4 / 1.2e-6 / 0.009 / 0.9985  (256x256, 32x32 grid)
 }
 
 
