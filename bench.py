@@ -379,7 +379,9 @@ def main():
     torch.manual_seed(3)                                   # train.py:39
     model = SPAIR([1, args.image, args.image], None, dev, compute_dtype=args.dtype).to(dev)
     # SPAIR_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of the three bucketed, overlapped ones
-    ddp.attach(model, world, overlap=os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0")
+    # (timing: the buckets' all-reduce issue -> complete times go into the N > 1 line's `ddp` record)
+    ddp.attach(model, world, overlap=os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0", timing=world > 1)
+    bwd_end = torch.cuda.Event(enable_timing=True) if world > 1 else None
     if world > 1:
         ddp.broadcast_parameters(model.flat_parameters())
     opt = FusedAdam(model, lr=1e-4)
@@ -395,6 +397,7 @@ def main():
         last["z_pres"] = z_pres
         loss.backward()
         if world > 1:
+            bwd_end.record()
             ddp.allreduce_gradients(model)       # three buckets behind the backward's readiness events, on a communication stream
         opt.step()
         gstep[0] += 1
@@ -434,8 +437,17 @@ def main():
     L.check(lib.spair_prof_read(ms, cnt, nslots), "prof_read")
     lib.spair_prof_enable(0)
     terms = model.loss_terms().clone()
+    ddp_rec = None
     if world > 1:
         terms = ddp.global_loss(terms)
+        # the LAST timed step's buckets (rank 0's view): does the window each bucket opens before the end of the backward hide its collective?
+        bt = ddp.bucket_timings(model, bwd_end)
+        if bt is not None:
+            ddp_rec = dict(backend=backend, overlap=True, buckets=bt,
+                           note="last timed step, rank 0: allreduce_ms = range final -> collective complete on the communication stream; "
+                                "done_after_backward_end_ms > 0 is the exposed part of that bucket")
+        else:
+            ddp_rec = dict(backend=backend, overlap=False, note="one all-reduce of the whole flat gradient behind the backward (SPAIR_DDP_OVERLAP=0)")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -471,6 +483,8 @@ def main():
                repeat=len(rep_dt), ms_per_step_repeats=[v / K * 1e3 for v in rep_dt],
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
+    if ddp_rec is not None:
+        out["ddp"] = ddp_rec
     default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16"
     if world == 1 and not args.no_sweep and (args.sweep or default_workload):
         # BASELINE configs[4] on one GPU: the count-prior schedule (config.py:65-69, models.py:186-188) changes z_pres and with it the

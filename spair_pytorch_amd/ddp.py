@@ -42,6 +42,10 @@ class GradBuckets:
             for e in self.events:
                 e.record()                 # materialises the hipEvent_t behind the torch object
             self.comm = torch.cuda.Stream(device=dev)
+            # timing: per bucket, when its all-reduce could start (its range was final) and when it had completed, on the communication stream
+            self.t_start = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
+            self.t_done = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
+        self.timing = bool(timing)
         self.pending = False
 
     def handles(self):
@@ -76,12 +80,35 @@ def allreduce_gradients(target):
     gb.pending = False
     works = []
     with torch.cuda.stream(gb.comm):
-        for ev, (lo, hi) in zip(gb.events, gb.ranges):
+        for i, (ev, (lo, hi)) in enumerate(zip(gb.events, gb.ranges)):
             gb.comm.wait_event(ev)                       # this range's gradients are final
-            works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if gb.timing:
+                gb.t_start[i].record(gb.comm)
+            w = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            if gb.timing:
+                w.wait()                                 # the communication stream waits for the collective: `t_done` is its completion
+                gb.t_done[i].record(gb.comm)
+            works.append(w)
     for w in works:
         w.wait()                                         # the CALLER's stream (Adam) waits for the collectives
     torch.cuda.current_stream().wait_stream(gb.comm)
+
+
+def bucket_timings(model, backward_end=None):
+    """After a synchronised step of a model attached with ``timing=True``: per gradient bucket, the bytes, the time from "range final" to
+    "all-reduce complete" on the communication stream and (given the event recorded behind ``loss.backward()``) how long before the end of the
+    backward the range was final -- whether the window hides the collective is then one comparison."""
+    gb = getattr(model, "_grad_buckets", None)
+    if gb is None or not gb.timing:
+        return None
+    out = []
+    for i, (lo, hi) in enumerate(gb.ranges):
+        rec = dict(bucket=BUCKET_NAMES[i], bytes=4 * (hi - lo), allreduce_ms=gb.t_start[i].elapsed_time(gb.t_done[i]))
+        if backward_end is not None:
+            rec["ready_before_backward_end_ms"] = gb.events[i].elapsed_time(backward_end)
+            rec["done_after_backward_end_ms"] = backward_end.elapsed_time(gb.t_done[i])
+        out.append(rec)
+    return out
 
 
 def global_loss(loss_terms):

@@ -108,3 +108,9 @@ def test_bench_runs_under_torchrun_with_two_ranks():
     assert rec["config"]["global_batch"] == 64 and rec["value"] > 0 and np.isfinite(rec["elbo"])
     assert abs(rec["value"] - 64 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]          # whole-job images/s = world * B * K / time
     assert "stn_fwd" in rec["kernels"] and rec["roofline"]["kernel"] in rec["kernels"]
+    # the per-bucket all-reduce record the first real scaling run is read by: three buckets in readiness order, each with its bytes, the
+    # range-final -> collective-complete time and its position against the end of the backward
+    d = rec["ddp"]
+    assert d["overlap"] and [b["bucket"] for b in d["buckets"]] == ["decoder", "cell_nets", "backbone+edge"]
+    assert sum(b["bytes"] for b in d["buckets"]) > 5.8e6 and all(b["allreduce_ms"] > 0 for b in d["buckets"])
+    assert d["buckets"][0]["ready_before_backward_end_ms"] >= d["buckets"][1]["ready_before_backward_end_ms"] >= 0.0
