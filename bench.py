@@ -105,7 +105,9 @@ def hbm_copy_rates(dev, mb=1024):
 
 
 # fragment packs the chain kernels stream from L2 on EVERY wavefront (engine.hip carve(): tiles x k-steps x 1 KiB per layer)
-CHAIN_PACK_KIB = dict(fwd=sum(a * b for a, b in zip((7, 7, 7, 16, 8, 7, 7, 7, 7, 7, 7, 1), (11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4, 4))),
+# (forward: the box network's three layers stream a hi AND a lo pack -- split-bf16 products --, the one-column obj output layer none: it is
+#  folded into OBJ1's epilogue)
+CHAIN_PACK_KIB = dict(fwd=sum(a * b for a, b in zip((14, 14, 14, 16, 8, 7, 7, 7, 7, 7, 7), (11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4))),
                       bwd=sum(a * b for a, b in zip((21, 7, 7, 49, 16, 8, 30, 7, 7, 30, 7, 0), (4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0))))
 L2_GATHER_PEAK_TBS = 17.8      # MI355X_MICROARCH.md "Indexed rows: gather into LDS": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2
 
@@ -157,10 +159,15 @@ def kernel_table(d, B, dtype, ms, cnt, n_sampled):
         if slot not in avg or avg[slot] <= 0:
             return {}
         t = avg[slot] * 1e-3
-        l2_bytes = float(B) * T * pack_kib * 1024            # every workgroup (= sample) re-streams the whole pack on each of its T wavefronts
+        # every workgroup re-streams the whole pack on each wavefront it walks: one workgroup per sample and 3G-2 wavefronts up to 16 x 16
+        # cells; beyond, ceil(G/8) bands per sample (one workgroup each), a band of hb grid rows walking 2(hb-1)+G wavefronts
+        nb = 1 if d.G <= 16 else (d.G + 7) // 8
+        hb = (d.G + nb - 1) // nb
+        l2_bytes = float(B) * nb * (2 * (hb - 1) + d.G) * pack_kib * 1024
         return dict(l2_stream=dict(bytes=l2_bytes, achieved_TBs=l2_bytes / t / 1e12, peak_TBs=L2_GATHER_PEAK_TBS,
                                    frac=l2_bytes / t / 1e12 / L2_GATHER_PEAK_TBS,
-                                   note="weight fragments L2 -> registers: B workgroups x (3G-2) wavefronts x pack; the bound these kernels sit closest to"),
+                                   note="weight fragments L2 -> registers: workgroups x wavefronts walked x pack (a companion figure: round-4 ablations put the "
+                                        "weight loads at ~12 % of the kernel, the dependent stage chain at ~70 %)"),
                     hbm_row_model=dict(bytes=float(N) * row_bytes, achieved_GBs=N * row_bytes / t / 1e9, frac_of_8TBs=N * row_bytes / t / 1e9 / HBM_PEAK_GBS,
                                        note="builder's byte model of the row buffers (DESIGN.md section 4), not SURVEY 8(d)'s figure"))
 
