@@ -366,7 +366,10 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
         tiles = B * tpi;
     }
     const bool stem = stem_part != nullptr;
-    if (stem && (!stem_xp || !stem_dw || (long long)(tiles + 64) * DG_STEM_FLOATS > stem_part_cap || (stem_hin & 1) || (stem_s & 1))) return SPAIR_ERR_UNSUPPORTED;
+    const int n_cu = spair_num_cus();
+    const int grid = std::min(tiles, n_cu);      // persistent: one 160-KB workgroup per CU walks the tiles
+    // one [128][17] partial per workgroup; the caller retries without the stem fusion when this is refused
+    if (stem && (!stem_xp || !stem_dw || (long long)grid * DG_STEM_FLOATS > stem_part_cap || (stem_hin & 1) || (stem_s & 1))) return SPAIR_ERR_UNSUPPORTED;
     ConvDgradArgs a;
     a.dout = reinterpret_cast<const u16*>(dout);
     for (int q = 0; q < 4; ++q) a.Bz[q] = reinterpret_cast<const u16*>(wd[q]);
@@ -378,12 +381,10 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
         const void* fn = stem ? reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true>) : reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false>);
         if (spair_dyn_lds_once(fn, DG_LDS, attr_done[stem ? 1 : 0]) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     }
-    const int n_cu = spair_num_cus();
-    const int grid = std::min(tiles, n_cu);      // persistent: one 160-KB workgroup per CU walks the tiles
     if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(grid), dim3(512), DG_LDS, s, a);
     else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(grid), dim3(512), DG_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
-    if (stem) return spair_stem_fused_reduce(stem_part, grid, stem_dw, stem_db, s);      // one [128][17] partial per workgroup
+    if (stem) return spair_stem_fused_reduce(stem_part, grid, stem_dw, stem_db, s);
     return SPAIR_OK;
 }
 

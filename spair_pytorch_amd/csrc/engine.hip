@@ -741,10 +741,15 @@ static int backbone_bwd16(Ctx& c, float* grads) {
                 const ConvSpec& c0 = c.PL.conv[0];
                 const bool want_stem = i == 1 && c0.cin == 1 && c0.k == 4 && c0.cout == 128 && c0.hout == cs.hin && !(c.st.flags & 8);
                 const void* wd4[4] = {c.w.conv_wd[i][0], c.w.conv_wd[i][1], c.w.conv_wd[i][2], c.w.conv_wd[i][3]};
-                const int rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s,
-                                                       want_stem ? c.w.xpad : nullptr, c0.hin, c0.s, want_stem ? c.w.tn_part : nullptr,
-                                                       SPAIR_TN_PART_FLOATS, grads + c0.w, grads + c0.b, c.s);
+                int rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s,
+                                                 want_stem ? c.w.xpad : nullptr, c0.hin, c0.s, want_stem ? c.w.tn_part : nullptr,
+                                                 SPAIR_TN_PART_FLOATS, grads + c0.w, grads + c0.b, c.s);
                 if (rc == SPAIR_OK) { if (want_stem) stem_fused = true; continue; }
+                if (rc == SPAIR_ERR_UNSUPPORTED && want_stem) {      // the stem fusion alone was refused: same kernel, d act0 to HBM, stem wgrad below
+                    rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s, nullptr, 0, 0,
+                                                 nullptr, 0, nullptr, nullptr, c.s);
+                    if (rc == SPAIR_OK) continue;
+                }
                 if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
             }
             if (cs.hin % cs.s == 0 && cs.s * cs.s <= 4) {
