@@ -18,7 +18,7 @@ def step(i):
         with torch.no_grad():
             m(x, 2000 + i)
     else:
-        opt.zero_grad(); loss = m(x, 2000 + i)[0]; loss.backward(); opt.step()
+        opt.zero_grad(); loss = m(x, 2000 + i)[0]; loss.backward()      # no optimizer step: every build sees the seed-3 boxes
 for i in range(10): step(i)
 lib.spair_prof_select(ctypes.c_ulonglong(0xFFFFFFFFFFFFFFFF)); lib.spair_prof_enable(1); lib.spair_prof_enable(0)
 torch.cuda.synchronize()
