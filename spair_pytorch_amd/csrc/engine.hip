@@ -1089,7 +1089,8 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     add(LIN_BOX1, P.dHb2, SP_LDH, 0, P.Hb1, SP_LDH);
     add(LIN_BOXH1, P.dOb, L.ld_ob, 0, P.Hb2, SP_LDH);
     add(LIN_BOXH0, P.dOb, L.ld_ob, L.ob_lat, P.Hb2, SP_LDH);
-    add(LIN_ENC0, P.dHe1, SP_ENC_H1, 0, P.glimpse, L.ld_gl);
+    // (LIN_ENC0 is not in the group: 14 of its 128 x 128 tiles re-read the 107-MB glimpse rows twice and d He1 seven times; on its own it runs
+    //  as 2 x 4 tiles of 128 x 256 with 32 row splits, 4 per XCD -- see below)
     add(LIN_ENC1, P.dHe2, SP_ENC_H2, 0, P.He1, SP_ENC_H1);
     add(LIN_ENC2, P.dOe, L.ld_oe, 0, P.He2, SP_ENC_H2);
     add_cols(LIN_Z0, P.dHz1, SP_LDH, 0, P.Xb, L.ld_xb, 0, 0, nfc, true);
@@ -1104,7 +1105,9 @@ static int cells_wgrad_grouped(Ctx& c, float* grads) {
     if (!fits) return SPAIR_ERR_UNSUPPORTED;
     g.ngroup = nt; g.R = L.N;
     g.part = c.tn_scratch ? c.tn_scratch : c.w.tn_part; g.part_cap = SPAIR_TN_PART_FLOATS;
-    return spair_gemm_tn16_impl(g, false, true, c.s);      // A and B both bf16 rows
+    TRY(spair_gemm_tn16_impl(g, false, true, c.s));      // A and B both bf16 rows
+    const LinSpec& e0 = c.PL.lin[LIN_ENC0];
+    return tn16(c, P.dHe1, SP_ENC_H1, e0.out, P.glimpse, L.ld_gl, e0.in, true, grads + e0.w, e0.in, (int)L.N, grads + e0.b);
 }
 
 // The decoder's two small weight gradients (dense1: 256 x 128, dense0: 128 x A) as ONE grouped split-K launch + one reduce pass: as launches of

@@ -227,7 +227,7 @@ int spair_gemm_tn_ring(GemmTN g, bool conv, hipStream_t s) {
     if (stages < 4) return SPAIR_ERR_UNSUPPORTED;
     // one workgroup per CU (96 / 144 KB of LDS): one round of 256, every split at least 2 stages
     int nsplit = std::max(1, std::min(stages / 2, 256 / std::max(1, tiles)));
-    if (nsplit >= 16) nsplit = nsplit / 8 * 8;
+    if (nsplit >= 8) nsplit = nsplit / 8 * 8;       // a multiple of 8: the kernel then keeps every tile of a row split on one XCD (shared operand slabs hit its L2)
     int sps = ceil_div(stages, nsplit);
     nsplit = ceil_div(stages, sps);
     g.rows_per_split = sps * TR_BK; g.nsplit = nsplit; g.tiles_m = tiles_m; g.tiles_n = tiles_n;
