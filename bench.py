@@ -106,8 +106,9 @@ def hbm_copy_rates(dev, mb=1024):
 
 # fragment packs the chain kernels stream from L2 on EVERY wavefront (engine.hip carve(): tiles x k-steps x 1 KiB per layer)
 # (forward: the box network's three layers stream a hi AND a lo pack -- split-bf16 products --, the one-column obj output layer none: it is
-#  folded into OBJ1's epilogue)
-CHAIN_PACK_KIB = dict(fwd=sum(a * b for a, b in zip((14, 14, 14, 16, 8, 7, 7, 7, 7, 7, 7), (11, 4, 4, 25, 8, 4, 16, 4, 4, 16, 4))),
+#  folded into OBJ1's epilogue; 7 of encoder layer 0's 25 k-steps are register-resident for the whole kernel (chain.hip ENC0_RES) and are
+#  not streamed per wavefront.  backward: real tiles only -- surplus waves of a layer's last round stream nothing)
+CHAIN_PACK_KIB = dict(fwd=sum(a * b for a, b in zip((14, 14, 14, 16, 8, 7, 7, 7, 7, 7, 7), (11, 4, 4, 25 - 7, 8, 4, 16, 4, 4, 16, 4))),
                       bwd=sum(a * b for a, b in zip((21, 7, 7, 49, 16, 8, 30, 7, 7, 30, 7, 0), (4, 4, 4, 8, 4, 4, 4, 4, 4, 4, 4, 0))))
 L2_GATHER_PEAK_TBS = 17.8      # MI355X_MICROARCH.md "Indexed rows: gather into LDS": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2
 

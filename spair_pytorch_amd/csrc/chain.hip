@@ -63,6 +63,7 @@ constexpr int NW = 8;                     // waves per workgroup
 // half a millisecond) -- a kernel of this library never spins without a bound
 constexpr int CHAIN_SPIN_LIMIT = 1 << 18;
 constexpr int NTH = NW * 64;
+constexpr int ENC0_RES = 7;   // k-steps of encoder layer 0 (of 25) whose fragments are resident in the forward kernel's registers
 constexpr int RD = 12;      // weight fragments in flight per wave (measured: 16 / 20 / 24 change nothing, 0.91 -> 0.93-0.95 ms)
 // the row-buffer stores are non-temporal: they stream past the L2 that holds the weights every workgroup re-reads each wavefront (chain fwd
 // 0.854 -> 0.836 ms, bwd 0.861 -> 0.851)
@@ -189,11 +190,14 @@ __device__ __forceinline__ void pipe_fill2(const uint4* __restrict__ Wp, WPipe& 
 #pragma unroll
     for (int s = 0; s < RD; ++s) p.q[s] = ((s & 1) ? b1 : b0)[(s >> 1) * 64];
 }
-template <int KT, int CH>
-__device__ __forceinline__ void wg_gemm_t2(const __bf16* in, int ld, const uint4* __restrict__ Wp, WPipe& p, const float* bias_l, f32x4& acc0,
-                                           f32x4& acc1, int wave, int lane) {
+// NRES: the last NRES k-steps of both tiles are RESIDENT -- 2 * NRES fragments this wave loaded once per kernel (`res`, the forward kernel's
+// spare registers): they are not streamed again on any wavefront (the stage takes its pack bytes through the CU's L1 fill port).
+template <int KT, int CH, int NRES>
+__device__ __forceinline__ void wg_gemm_t2(const __bf16* in, int ld, const uint4* __restrict__ Wp, WPipe& p, const uint4 (&res)[2 * NRES + 1],
+                                           const float* bias_l, f32x4& acc0, f32x4& acc1, int wave, int lane) {
     static_assert(KT % CH == 0 && RD % 2 == 0, "whole chunks; ring slots alternate between the two tiles");
     constexpr int NCH = KT / CH, AH = RD / 2;          // AH: k-steps the ring runs ahead
+    constexpr int KS = KT - NRES;                      // k-steps that stream
     const uint4* b0 = Wp + (size_t)wave * KT * 64 + lane;
     const uint4* b1 = Wp + (size_t)(wave + 8) * KT * 64 + lane;
     const __bf16* pa = in + (lane & 15) * ld + (lane >> 4) * 8;
@@ -212,10 +216,15 @@ __device__ __forceinline__ void wg_gemm_t2(const __bf16* in, int ld, const uint4
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int f = c * CH + j;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f) % RD]), x[c & 1][j], acc0, 0, 0, 0);
-            if (f + AH < KT) p.q[(2 * f) % RD] = b0[(size_t)(f + AH) * 64];
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f + 1) % RD]), x[c & 1][j], acc1, 0, 0, 0);
-            if (f + AH < KT) p.q[(2 * f + 1) % RD] = b1[(size_t)(f + AH) * 64];
+            if (f < KS) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f) % RD]), x[c & 1][j], acc0, 0, 0, 0);
+                if (f + AH < KS) p.q[(2 * f) % RD] = b0[(size_t)(f + AH) * 64];
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[(2 * f + 1) % RD]), x[c & 1][j], acc1, 0, 0, 0);
+                if (f + AH < KS) p.q[(2 * f + 1) % RD] = b1[(size_t)(f + AH) * 64];
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(res[2 * (f - KS)]), x[c & 1][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(res[2 * (f - KS) + 1]), x[c & 1][j], acc1, 0, 0, 0);
+            }
         }
     }
 }
@@ -526,6 +535,15 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     };
 
     WPipe pipe;
+    // encoder layer 0's last ENC0_RES k-steps of this wave's two column tiles stay in registers for the whole kernel (see wg_gemm_t2)
+    uint4 enc0_res[2 * ENC0_RES + 1];
+    {
+        const uint4* b0 = a.w[CW_ENC0] + (size_t)wave * 25 * 64 + lane;
+        const uint4* b1 = a.w[CW_ENC0] + (size_t)(wave + 8) * 25 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < ENC0_RES; ++i) { enc0_res[2 * i] = b0[(size_t)(25 - ENC0_RES + i) * 64]; enc0_res[2 * i + 1] = b1[(size_t)(25 - ENC0_RES + i) * 64]; }
+        enc0_res[2 * ENC0_RES] = make_uint4(0u, 0u, 0u, 0u);
+    }
     pipe_fill_s<11, 7>(a.w[CW_BOX0], a.wlo[CW_BOX0], pipe, wave, lane);      // (all eight waves here: the ring registers must be defined on every path)
     int stamp_i = 0;
     int nc_prev = 0;
@@ -706,7 +724,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         CH_STAMP();
         {   // 256 outputs = 16 tiles, two per wave sharing every glimpse fragment
             f32x4 acc0, acc1;
-            wg_gemm_t2<25, 5>(Gl, LD_GL, a.w[CW_ENC0], pipe, bias_sh + BIAS_OFF[CW_ENC0], acc0, acc1, wave, lane);
+            wg_gemm_t2<25, 5, ENC0_RES>(Gl, LD_GL, a.w[CW_ENC0], pipe, enc0_res, bias_sh + BIAS_OFF[CW_ENC0], acc0, acc1, wave, lane);
             pipe_fill<8, 8>(a.w[CW_ENC1], pipe, wave, lane);
             wg_store_t<16, true, 0>(acc0, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, rr_cur, nc, wave, lane, mbt + MB_HE1 * 4);
             wg_store_t<16, true, 8>(acc1, 256, Ha, LD_H, 256, nullptr, 0, reinterpret_cast<__bf16*>(P.He1), SP_ENC_H1, rr_cur, nc, wave, lane, mbt + MB_HE1 * 4);
@@ -874,16 +892,27 @@ constexpr int LD_R = 328;      // ring row: [feat 100 | ctx 224] fp32
 // (tile, k-step) order, refilled behind each MFMA; `mid()` is called once behind the stage's last MFMA and before its last epilogue -- the
 // place where the NEXT layer's first ring fill is issued (round 3 issued it behind the epilogue, at the barrier: every small stage then began
 // by waiting out an L2 round trip).  `epi(j, nt, acc)`: lane holds columns nt*16 + (lane>>4)*4 .. +3 of row lane & 15.
+// The backward kernel's ring is RDB = 8 deep.  Measured at 4 / 6 / 8 / 10 / 12 (same box, tools/exp/chain_ablate.py): 0.80 / 0.761 / 0.746 /
+// 0.757 / 0.775 ms -- at 12 the kernel holds 246 of 256 registers and its one-tile-per-wave stages run 0.9 us instead of 0.6-0.7; below 8 the
+// wide stages (encoder layer 0, the 30-tile first layers) starve.  Per-layer depths (6 for the narrow, 12 for the wide stages) were tried:
+// the register count, not the depth, is what the narrow stages feel (17.6 us per wavefront against 17.0).
+constexpr int RDB = 8;
+struct WPipeB { uint4 q[RDB]; };
+// A wave only streams (and multiplies) the tiles it owns: with NT not a multiple of the 8 waves the last round's surplus waves used to run a
+// clamped duplicate of tile NT - 1 whose result was dropped -- 7 of encoder layer 0's 56 tile slots, one of 8 in every 7-tile layer: 104 KiB
+// of the ~1.1 MB a wavefront streams.  The test is wave-uniform (a scalar branch).
 template <int KT, int NT>
-__device__ __forceinline__ void pipe_fill_w(const uint4* __restrict__ Wt, WPipe& p, int wave, int lane) {
+__device__ __forceinline__ void pipe_fill_w(const uint4* __restrict__ Wt, WPipeB& p, int wave, int lane) {
     constexpr int MY = (NT + NW - 1) / NW, TOT = MY * KT;
 #pragma unroll
-    for (int s_ = 0; s_ < RD; ++s_)
-        if (s_ < TOT) p.q[s_] = Wt[((size_t)min(wave + NW * (s_ / KT), NT - 1) * KT + (s_ % KT)) * 64 + lane];
+    for (int s_ = 0; s_ < RDB; ++s_)
+        if (s_ < TOT && wave + NW * (s_ / KT) < NT) p.q[s_] = Wt[((size_t)(wave + NW * (s_ / KT)) * KT + (s_ % KT)) * 64 + lane];
 }
 template <int KT, int NT, class Epi, class Mid>
-__device__ __forceinline__ void wg_gemm_wt(const __bf16* in, int ld, const uint4* __restrict__ Wt, WPipe& p, int wave, int lane, Epi epi, Mid mid) {
+__device__ __forceinline__ void wg_gemm_wt(const __bf16* in, int ld, const uint4* __restrict__ Wt, WPipeB& p, int wave, int lane, Epi epi, Mid mid) {
     constexpr int MY = (NT + NW - 1) / NW, TOT = MY * KT;
+    // every wave owns its tiles of the first MY - 1 rounds; the last round's tile only if it exists (wave-uniform: one scalar branch)
+    const bool last_own = (NT % NW) == 0 || wave + NW * (MY - 1) < NT;
     const __bf16* pa = in + (lane & 15) * ld + (lane >> 4) * 8;
     bf16x8 x[KT];
 #pragma unroll
@@ -892,15 +921,20 @@ __device__ __forceinline__ void wg_gemm_wt(const __bf16* in, int ld, const uint4
 #pragma unroll
     for (int j = 0; j < MY; ++j) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool own = j < MY - 1 || last_own;
+        if (own) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int s_ = j * KT + kt;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[s_ % RD]), x[kt], acc, 0, 0, 0);
-            if (s_ + RD < TOT)
-                p.q[s_ % RD] = Wt[((size_t)min(wave + NW * ((s_ + RD) / KT), NT - 1) * KT + ((s_ + RD) % KT)) * 64 + lane];
+            for (int kt = 0; kt < KT; ++kt) {
+                const int s_ = j * KT + kt;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[s_ % RDB]), x[kt], acc, 0, 0, 0);
+                if (s_ + RDB < TOT && ((s_ + RDB) / KT < MY - 1 || last_own))
+                    p.q[s_ % RDB] = Wt[((size_t)(wave + NW * ((s_ + RDB) / KT)) * KT + ((s_ + RDB) % KT)) * 64 + lane];
+            }
         }
-        if (j == MY - 1) mid();
-        epi(j, wave + NW * j, acc);
+        // mid(): once, behind this wave's last MFMA
+        if (MY >= 2 && j == MY - 2 && !last_own) mid();
+        if (j == MY - 1 && (last_own || MY == 1)) mid();
+        if (own) epi(j, wave + NW * j, acc);
     }
 }
 
@@ -1098,7 +1132,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
     if (band < NBn - 1 && wave == 7) fetch_grad(t_last, lane);
     __syncthreads();
 
-    WPipe pipe;
+    WPipeB pipe;
     pipe_fill_w<4, 7>(a.wt[CW_OBJ1], pipe, wave, lane);      // the first data-gradient GEMM of the first wavefront
     int stamp_j = 2048;
 #define CB_STAMP() do { if (a.stamps && b == 0 && band == 0 && tid0 == 0) a.stamps[stamp_j++] = __builtin_amdgcn_s_memtime(); } while (0)
