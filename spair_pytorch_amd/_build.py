@@ -11,6 +11,8 @@ LIB = os.path.join(HERE, "libspair_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result", "-Wno-pass-failed"]
+# per-file additions.  render3.hip: MFMA results in VGPRs (they feed VALU at once: the AGPR form costs a v_accvgpr_read per element)
+FILE_FLAGS = {"render3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -38,7 +40,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))

@@ -21,6 +21,8 @@ int stn_glimpse_bwd(const float* x, const float* nbox, int B, const float* dgl, 
 int render_sprite_act(float* S, int ld, int N, int per, int CH, float obj_scale, float alpha_scale, float alpha_bias, hipStream_t s);
 int render_num_blocks(int B, int I);
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s);
+int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac, hipStream_t s);
+int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, hipStream_t s);
 int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s);
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
@@ -142,6 +144,7 @@ struct Ws {
     void *Za16, *dfeat16;                               // bf16 copies of the decoder input / d feat (bf16 mode)
     float *tn_part, *tn_part2;                          // split-K partial tiles of the weight-gradient GEMMs (caller's / helper stream)
     float *aux, *bce_partial, *kl_partial, *klp, *gedge_part;
+    void* rrec;
     int* chain_sync;                  // band split of the fused chain (chain.h): start tickets, time-out word, per-(sample, band) counters
     float *bnd_rec, *bnd_grad;        // ... and the boundary rows handed from band to band
     unsigned long long* stamps;
@@ -249,6 +252,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
+    w.rrec = c.take_bytes((size_t)N * 32);                  // the renderer's per-object records (render3.hip)
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
     w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);
@@ -1025,8 +1029,18 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     // KL + render + loss
     {
         ProfScope ps(PS_RENDER_FWD, c.s);
-        TRY(render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
-                       c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16, c.s));
+        // bf16 step: the sampling on the matrix cores from per-object records (render3.hip); every other case on the tap kernels
+        int rc = SPAIR_ERR_UNSUPPORTED;
+        if (d->dtype == SPAIR_BF16 && d->C == 1) {
+            rc = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, c.s);
+            if (rc == SPAIR_OK)
+                rc = render_fwd_mma(c.w.S, c.w.ld_s, c.w.rrec, x, recon, st->train ? c.w.aux : nullptr, c.w.bce_partial, d->B, L.HW, d->I,
+                                    d->P, d->align_corners, c.s);
+        }
+        if (rc == SPAIR_ERR_UNSUPPORTED)
+            rc = render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
+                            c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16, c.s);
+        TRY(rc);
     }
     if (side && hipStreamWaitEvent(c.s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
     ProfScope psl(PS_LOSS, c.s);

@@ -436,6 +436,10 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                 const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
                 int ac, float obj_scale, float alpha_scale, hipStream_t s);
+int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac,
+                hipStream_t s);
+int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW,
+                   int I, int P, int ac, hipStream_t s);
 // s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type.  aux: B*I*I float2 (dBCE/dpre / D, pre).
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
                float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s) {
@@ -509,4 +513,18 @@ extern "C" int spair_render_bwd16(const void* sprites_f16, int ld_s, const float
     return render_bwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, aux, grad_loss,
                       reinterpret_cast<float*>(dlogits_bf16), dnbox, dpres, ddepth, ld_s, B, HW, C, I, P, align_corners, obj_scale,
                       alpha_scale, 1, 1, (hipStream_t)stream);
+}
+// The matrix-core forward renderer of the bf16 step (render3.hip): spair_render_prep writes the per-object records (32 bytes each,
+// B * HW of them, caller-owned), spair_render_fwd16m composites from them.  SPAIR_ERR_UNSUPPORTED (P != 28, align_corners, HW > 1024):
+// use spair_render_fwd16.
+extern "C" int spair_render_prep(const float* nbox, const float* pres, const float* depth, void* records, int B, int HW, int I, int P,
+                                 int align_corners, void* stream) {
+    if (B <= 0 || HW <= 0 || I <= 0) return SPAIR_ERR_SHAPE;
+    return render_prep(nbox, pres, depth, 1, records, B, HW, I, P, align_corners, (hipStream_t)stream);
+}
+extern "C" int spair_render_fwd16m(const void* sprites_f16, int ld_s, const void* records, const float* x, float* recon, float* aux,
+                                   float* bce_partial, int B, int HW, int C, int I, int P, int align_corners, void* stream) {
+    if (C != 1) return SPAIR_ERR_UNSUPPORTED;
+    if (B <= 0 || HW <= 0 || I <= 0) return SPAIR_ERR_SHAPE;
+    return render_fwd_mma(sprites_f16, ld_s, records, x, recon, aux, bce_partial, B, HW, I, P, align_corners, (hipStream_t)stream);
 }

@@ -42,14 +42,6 @@ __device__ __forceinline__ bool rf_axis(float s, int P, int& i0, float& w0, floa
     return cov;
 }
 
-// stn_base() for the renderer kernels: with an image side that is a power of two (IP2) the division by n is a multiplication by the
-// exactly representable 1/n -- bit-identical to stn_base(), ~10 instructions cheaper per call.
-template <int AC, int IP2>
-__device__ __forceinline__ float rf_base(int j, int n, float inv_n) {
-    if constexpr (IP2 && !AC) return (2.f * (float)j + 1.f) * inv_n - 1.f;
-    else return stn_base(j, n, AC);
-}
-
 __device__ __forceinline__ int rf_scan_incl(int v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -341,21 +333,6 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
 #define RB2_ADJ_BYTES (3 * RB2_ROWS * RB2_ADJ_LD * 2)
 
 __host__ __device__ inline int rb2_lds_bytes(int P) { return (P + 2) * (P + 2) * 8 + RB2_ADJ_BYTES + 32 * 16 + RB2_ROWS * 16 + 32 * 4 + RB2_ROWS * 4; }
-
-// first / last index in [0, I-1] whose source coordinate lies in (-1, P); exact w.r.t. the forward's own coordinate formula
-template <int AC, int IP2>
-__device__ __forceinline__ void rb2_range(float a, float b, float c0, float inv, int I, float inv_I, int P, int& lo, int& hi) {
-    float g;
-    // src(j) ~ c0 + j / inv: the boundary index is within one of the estimate, two exact tests settle it
-    lo = max((int)floorf((-1.f - c0) * inv), 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (lo < I && src_from_base(a, b, rf_base<AC, IP2>(lo, I, inv_I), P, AC, g) <= -1.f) ++lo;
-    hi = min((int)ceilf(((float)P - c0) * inv), I - 1);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (hi >= 0 && src_from_base(a, b, rf_base<AC, IP2>(hi, I, inv_I), P, AC, g) >= (float)P) --hi;
-}
 
 __device__ __forceinline__ float rb2_hat(float s, float c) { return fmaxf(1.f - fabsf(s - c), 0.f); }
 // 8 hat weights max(0, 1 - |s_j - c|) as a bf16 MFMA fragment

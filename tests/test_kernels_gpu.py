@@ -154,6 +154,70 @@ def test_render16_fwd_bwd_vs_oracle(B, G, I, smin, srange):
     assert (ddp.cpu() - depth.grad).abs().max().item() <= 1e-2 * depth.grad.abs().max().item() + 1e-7
 
 
+@pytest.mark.parametrize("B,G,I,smin,srange", [(8, 4, 64, 0.08, 0.5), (4, 8, 128, 0.12, 0.12),      # the bench geometry's object sizes
+                                                (8, 16, 128, 0.1, 0.2),                               # B % 8 == 0: the XCD-aware tile order
+                                                (1, 2, 128, 0.7, 0.5),                                # magnified: one 16-row tile per pair
+                                                (2, 4, 96, 0.02, 0.1),                                # minified: both tiles
+                                                (3, 5, 72, 0.05, 0.6)])                               # image side not a multiple of 16
+def test_render16m_fwd_vs_oracle(B, G, I, smin, srange):
+    """The matrix-core forward renderer of the bf16 step (render3.hip: spair_render_prep + spair_render_fwd16m) against the oracle on the
+    SAME fp16 sprites, and against the tap kernel (spair_render_fwd16).  Its sampling is not fp32: source coordinates are rounded to
+    2^-11 texel (so that the hat weights are exact fp16 pairs summing to 1), the x-interpolated rows are rounded to fp16 once (2^-12
+    relative, nearest-even) and the importance is formed in fp16 (three 2^-12 roundings: where many objects overlap they move the
+    importance WEIGHTS between objects) -- per pixel <= 1.5e-3 (observed <= 9e-4), rms <= 1.5e-4, and WITHOUT bias: the mean signed error
+    stays below 3e-6 and the BCE sum within 2e-5 (observed 2e-7).  The backward (k_render_bwd2) reads this kernel's aux record, so the
+    record of the tap kernel and of this one must agree to the same bound."""
+    L = _L()
+    P, HW = 28, G * G
+    N = B * HW
+    g = torch.Generator().manual_seed(B + G + I + 2)
+    logits = torch.randn(N, P, P, 2, generator=g)
+    logits[..., 1] += 1.0
+    S = torch.sigmoid(logits).half().float()
+    nbox = torch.stack([torch.rand(N, generator=g) * 1.2 - 0.1, torch.rand(N, generator=g) * 1.2 - 0.1,
+                        torch.rand(N, generator=g) * srange + smin, torch.rand(N, generator=g) * srange + smin], 1)
+    pres = torch.rand(N, generator=g)
+    depth = torch.rand(N, generator=g) * 4
+    if N > 4:       # degenerate objects: off-screen, vanishing, absent -- culled or drawn with weight ~0, never NaN
+        nbox[0] = torch.tensor([5.0, 5.0, 0.2, 0.2]); nbox[1] = torch.tensor([0.5, 0.5, 1e-12, 0.3]); pres[2] = 0.0
+        nbox[3] = torch.tensor([-0.2, 0.98, 0.5, 0.5])
+    x = (torch.rand(B, 1, I, I, generator=g) > 0.7).float() * torch.rand(B, 1, I, I, generator=g)
+    rec_o, bce_o = _render_oracle(S, nbox, pres, depth, x, B, HW, I, P)
+    Sd = S.reshape(N, -1).half().contiguous().cuda()
+    nb, pr, dp, xd = nbox.cuda(), pres.cuda(), depth.cuda(), x.cuda()
+    ld = P * P * 2
+    nblk = B * ((I + 15) // 16) ** 2
+    out = {}
+    for name in ("taps", "mma"):
+        recon = torch.zeros(B, 1, I, I, device="cuda")
+        aux = torch.zeros(B, I, I, 2, device="cuda")
+        part = torch.zeros(nblk, device="cuda")
+        if name == "taps":
+            L.check(L.lib().spair_render_fwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
+                                               B, HW, 1, I, P, 0, L.stream()), "render fwd16")
+        else:
+            recs = torch.zeros(N * 8, device="cuda", dtype=torch.int32)
+            L.check(L.lib().spair_render_prep(L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(recs), B, HW, I, P, 0, L.stream()), "render prep")
+            L.check(L.lib().spair_render_fwd16m(L.ptr(Sd), ld, L.ptr(recs), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
+                                                B, HW, 1, I, P, 0, L.stream()), "render fwd16m")
+        torch.cuda.synchronize()
+        out[name] = (recon.cpu(), aux.cpu(), part.sum().item())
+    rec_m, aux_m, bce_m = out["mma"]
+    rec_t, aux_t, bce_t = out["taps"]
+    assert torch.isfinite(rec_m).all() and torch.isfinite(aux_m).all()
+    err = rec_m - rec_o
+    rms = err.double().pow(2).mean().sqrt().item()
+    print("mma vs oracle: max %.3g rms %.3g mean %.3g | taps vs oracle: max %.3g | bce rel %.3g" %
+          (err.abs().max(), rms, err.mean(), (rec_t - rec_o).abs().max(), abs(bce_m - bce_o.item()) / bce_o.item()))
+    assert err.abs().max() < 1.5e-3
+    assert rms < 1.5e-4
+    assert abs(err.mean().item()) < 3e-6
+    assert abs(bce_m - bce_o.item()) <= 2e-5 * bce_o.item()
+    assert (aux_m[..., 1] - aux_t[..., 1]).abs().max() < 1.5e-3         # pre (unclamped)
+    d0 = (aux_m[..., 0] - aux_t[..., 0]).abs()                         # dBCE/dpre / D
+    assert (d0 <= 1e-2 * aux_t[..., 0].abs() + 1e-3 * aux_t[..., 0].abs().max()).all()
+
+
 @pytest.mark.parametrize("B,I,pre,post", [(3, 128, 7, 7), (2, 48, 3, 5), (1, 32, 0, 2)])
 def test_stem_conv_mfma_vs_torch(B, I, pre, post):
     """The bf16-mode stem (k_conv0_fwd_c1k4_mfma: split-bf16 operands on the matrix cores) against torch's fp32 conv on the CPU: before
