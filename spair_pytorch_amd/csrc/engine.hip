@@ -252,7 +252,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
-    w.rrec = c.take_bytes((size_t)N * 32);                  // the renderer's per-object records (render3.hip)
+    w.rrec = c.take_bytes((size_t)N * 48);                  // the renderer's per-object records (render3.hip)
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
     w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);

@@ -18,21 +18,25 @@
 //     (the hat weights Wy are built in the same order);
 //   * the hat weights are exact in fp16: the source coordinate is rounded to a multiple of 2^-11 texel, so 1 - f and f have 11
 //     significant bits and the pair still sums to exactly 1;
-//   * per-object parameters (exact inverse affine, presence, presence * depth, pixel footprint) come from a 32-byte per-object record
-//     written once per step by k_render_prep: the tile cull is four integer compares, and a wave fetches the record of the object it
-//     works on with scalar loads.
+//   * per-object parameters come from two per-object records written once per step by k_render_prep (48 bytes together): the cull
+//     record (pixel footprint + the row coefficients: the tile cull is four integer compares) and the object record (source-coordinate
+//     coefficients with the rounding constant folded in, presence, importance scale and floor); a wave keeps the records of its
+//     objects one per lane and broadcasts a field with v_readlane;
+//   * importance max(alpha * pd, 0.01) = pd * max(alpha, 0.01 / pd): one v_pk_max_f16 per two texels, pd applied to the sampled tile
+//     in fp32 (pd <= 0.01: the importance is the constant 0.01 = 0.01 * max(alpha, 1)).
 // Work split: one workgroup (4 waves) per (sample, 16 x 16 tile); the tile's surviving objects are dealt round-robin to the waves, each
 // wave composites whole objects into its own (num, den) tile in registers, and the four partial tiles meet in LDS at the end.
 //
 // Numerics (fp16 sprites in both kernels, so this is about the sampling only): the coordinate rounding moves a sample by <= 2^-12 texel,
-// T is rounded to fp16 once (RNE, 2^-12 relative), the importance max(alpha * pres * depth, 0.01) is formed in fp16; the products are exact
-// and accumulate in fp32.  Measured against the oracle on the same fp16 sprites: tests/test_kernels_gpu.py::test_render16m_fwd_vs_oracle.
+// T is rounded to fp16 once (RNE, 2^-12 relative), the importance floor 0.01 / pd is an fp16 number; the products are exact and accumulate
+// in fp32.  Measured against the oracle on the same fp16 sprites: tests/test_kernels_gpu.py::test_render16m_fwd_vs_oracle.
 #include <stdlib.h>
 #include "render_common.h"
 
 typedef _Float16 r3_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 r3_h2 __attribute__((ext_vector_type(2)));
 typedef float r3_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short r3_u2 __attribute__((ext_vector_type(2)));
 
 #define R3_P 28                     // sprite side this kernel is built for (row = 112 B = 7 x 16 B)
 #define R3_ROWB (R3_P * 4)
@@ -41,49 +45,69 @@ typedef float r3_f2 __attribute__((ext_vector_type(2)));
 #define R3_EMPTY 0x7fffu            // first index of an empty footprint
 #define R3_QMAGIC 6144.0f           // 1.5 * 2^12: (s + M) - M rounds s to a multiple of 2^-11 for |s| < 2^11
 
-// 32 bytes per object, sample-major [b][k]
-struct __attribute__((aligned(16))) RenderRec {
-    float ax, bx, pres;
-    unsigned pdh;                   // presence * depth as an fp16 pair (both halves)
-    float ay, by;
+// Per object, sample-major [b][k]: B * HW object records, then B * HW cull records.
+// Source coordinate of output index j on either axis: s = A * base(j) + Bc with A = a * P / 2, Bc = (b + 1) * P / 2 - 1 / 2 (the reference's
+// affine_grid + unnormalise sequence (g + 1) * P / 2 - 1 / 2, g = a * base + b, re-associated: <= 1e-5 texel from the sequence the backward
+// evaluates, far inside the 2^-12 texel of the rounding below).
+struct __attribute__((aligned(16))) RenderObjRec {
+    float Ax, BxM, Ay, ByM;         // BxM = Bc + R3_QMAGIC: fma(A, base, BxM) - R3_QMAGIC is s rounded to a multiple of 2^-11
+    float pres, mscale;             // importance = mscale * max(alpha, mfloor)
+    unsigned mfloor;                // fp16 pair
+    unsigned pad;
+};
+struct __attribute__((aligned(16))) RenderCullRec {
+    float Ay, By;                   // By = Bc (no rounding constant): the sprite-row window of a tile comes from floor(s)
     unsigned xr, yr;                // pixel footprint: first | last << 16 (first = R3_EMPTY: nothing to draw)
 };
+#define R3_REC_BYTES 48
 
 template <int AC, int IP2>
 __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ nbox, const float* __restrict__ pres,
-                                                     const float* __restrict__ depth, int ld_pd, RenderRec* __restrict__ rec, int B, int HW,
-                                                     int I, int P) {
+                                                     const float* __restrict__ depth, int ld_pd, RenderObjRec* __restrict__ orec,
+                                                     RenderCullRec* __restrict__ crec, int B, int HW, int I, int P) {
     const int idx = blockIdx.x * 256 + threadIdx.x;          // = b * HW + k
     if (idx >= B * HW) return;
     const int b = idx / HW, k = idx - b * HW;
     const int r = k * B + b;
     const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
     const float pr = pres[(size_t)r * ld_pd], pd = pr * depth[(size_t)r * ld_pd];
-    // the same expressions as the backward kernels: forward and backward must agree on the coordinates to the bit
+    // the same expressions as the backward kernels for the footprint: exact w.r.t. the coordinates the gradients are taken at
     const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
-    RenderRec o;
-    o.ax = 1.f / nb.z; o.bx = -tx / nb.z; o.ay = 1.f / nb.w; o.by = -ty / nb.w;
-    o.pres = pr;
-    const r3_h2 ph = {(_Float16)pd, (_Float16)pd};
-    o.pdh = __builtin_bit_cast(unsigned, ph);
+    float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
     const float inv_I = 1.f / (float)I;
     int x0 = R3_EMPTY, x1 = 0, y0 = R3_EMPTY, y1 = 0;
     const float big = 1e30f;
-    if (fabsf(o.ax) < big && fabsf(o.bx) < big && fabsf(o.ay) < big && fabsf(o.by) < big && o.ax > 0.f && o.ay > 0.f) {
+    if (fabsf(ax) < big && fabsf(bx) < big && fabsf(ay) < big && fabsf(by) < big && ax > 0.f && ay > 0.f) {
         float sx0, sxa, sy0, sya;
-        src_affine(o.ax, o.bx, I, P, AC, sx0, sxa);
-        src_affine(o.ay, o.by, I, P, AC, sy0, sya);
+        src_affine(ax, bx, I, P, AC, sx0, sxa);
+        src_affine(ay, by, I, P, AC, sy0, sya);
         int lo, hi;
-        rb2_range<AC, IP2>(o.ax, o.bx, sx0, __builtin_amdgcn_rcpf(sxa), I, inv_I, P, lo, hi);
+        rb2_range<AC, IP2>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, inv_I, P, lo, hi);
         if (lo <= hi) { x0 = lo; x1 = hi; }
-        rb2_range<AC, IP2>(o.ay, o.by, sy0, __builtin_amdgcn_rcpf(sya), I, inv_I, P, lo, hi);
+        rb2_range<AC, IP2>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, inv_I, P, lo, hi);
         if (lo <= hi) { y0 = lo; y1 = hi; }
     } else {
-        o.ax = o.bx = o.ay = o.by = 0.f;
+        ax = bx = ay = by = 0.f;
     }
-    o.xr = (unsigned)x0 | ((unsigned)x1 << 16);
-    o.yr = (unsigned)y0 | ((unsigned)y1 << 16);
-    rec[idx] = o;
+    const float hp = 0.5f * (float)P;
+    RenderObjRec o;
+    o.Ax = ax * hp; o.Ay = ay * hp;
+    const float bcx = fmaf(bx + 1.f, hp, -0.5f), bcy = fmaf(by + 1.f, hp, -0.5f);
+    o.BxM = bcx + R3_QMAGIC; o.ByM = bcy + R3_QMAGIC;
+    o.pres = pr;
+    // max(alpha * pd, 0.01) = mscale * max(alpha, mfloor)
+    const bool flat = !(pd > 0.01f);                          // alpha <= 1: the importance is 0.01 everywhere on the sprite
+    o.mscale = flat ? 0.01f : pd;
+    const _Float16 fl = flat ? (_Float16)1.f : (_Float16)fmaxf(0.01f / pd, 6.2e-5f);
+    const r3_h2 fl2 = {fl, fl};
+    o.mfloor = __builtin_bit_cast(unsigned, fl2);
+    o.pad = 0;
+    RenderCullRec c;
+    c.Ay = o.Ay; c.By = bcy;
+    c.xr = (unsigned)x0 | ((unsigned)x1 << 16);
+    c.yr = (unsigned)y0 | ((unsigned)y1 << 16);
+    orec[idx] = o;
+    crec[idx] = c;
 }
 
 // 8 hat weights max(0, 1 - |s - u_j|) of a coordinate that is a multiple of 2^-11, as an fp16 MFMA fragment.  c[jp] = -(u_2jp, u_2jp+1)
@@ -95,28 +119,28 @@ __device__ __forceinline__ r3_h8 r3_hat8(float s, const r3_f2 (&c)[4]) {
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
         const r3_f2 d = s2 + c[jp];
-        const r3_h2 dh = __builtin_bit_cast(r3_h2, __builtin_amdgcn_cvt_pkrtz(d.x, d.y));
-        const r3_h2 ad = __builtin_elementwise_max(dh, -dh);
-        w[jp] = __builtin_elementwise_max(one - ad, zero);
+        // three instructions per pair: v_pk_add_f32, v_cvt_pkrtz_f16_f32 |d|, v_pk_add_f16 ... clamp
+        const r3_h2 ad = __builtin_bit_cast(r3_h2, __builtin_amdgcn_cvt_pkrtz(__builtin_fabsf(d.x), __builtin_fabsf(d.y)));
+        w[jp] = __builtin_elementwise_min(__builtin_elementwise_max(one - ad, zero), one);
     }
     return r3_h8{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
 }
 
 struct R3Frag { u32x4_t lo, hi; };      // 8 texels (grey, alpha) of one sprite row
 
-// fl: the importance floor 0.01 as an fp16 pair -- 0 for a sprite row beyond the sprite, whose texels read as zeros: the PADDING's importance
+// fl: the importance floor as an fp16 pair -- 0 for a sprite row beyond the sprite, whose texels read as zeros: the PADDING's importance
 // is 0, not the floor (the reference clamps the importance sprite, then grid_sample pads it with zeros)
-__device__ __forceinline__ void r3_split(const R3Frag& f, unsigned pdh, unsigned fl, r3_h8& g, r3_h8& a, r3_h8& m) {
+__device__ __forceinline__ void r3_split(const R3Frag& f, unsigned fl, r3_h8& g, r3_h8& a, r3_h8& m) {
     const unsigned d[8] = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
-    const r3_h2 pd2 = __builtin_bit_cast(r3_h2, pdh);
-    const r3_h2 floor2 = __builtin_bit_cast(r3_h2, fl);
+    const r3_u2 floor2 = __builtin_bit_cast(r3_u2, fl);
     unsigned gg[4], aa[4], mm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         gg[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
         aa[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
-        const r3_h2 im = __builtin_elementwise_max(__builtin_bit_cast(r3_h2, aa[i]) * pd2, floor2);     // importance, models.py:497-499
-        mm[i] = __builtin_bit_cast(unsigned, im);
+        // importance / mscale, models.py:497-499: max(alpha, floor) on the BIT patterns (both >= 0: fp16 order = unsigned order; the
+        // float form costs a second v_pk_max_f16 per pair, the compiler's canonicalisation of a loaded value)
+        mm[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(r3_u2, aa[i]), floor2));
     }
     g = __builtin_bit_cast(r3_h8, u32x4_t{gg[0], gg[1], gg[2], gg[3]});
     a = __builtin_bit_cast(r3_h8, u32x4_t{aa[0], aa[1], aa[2], aa[3]});
@@ -128,59 +152,75 @@ __device__ __forceinline__ unsigned r3_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// 1 / d: v_rcp_f32 + one Newton step (<= 1 ulp for normal d; the IEEE division sequence is ~10 instructions)
+__device__ __forceinline__ float r3_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+
 struct R3Obj {                      // everything of one (object, tile) pair that is in flight before its arithmetic
     R3Frag t0, t1;
-    uint4 ra, rb;                   // the record (wave-uniform)
+    float Ax, BxM, Ay, ByM, pres, mscale;       // the object record (wave-uniform)
+    unsigned mfloor;
     unsigned e;                     // list entry: k | v0 << 16 | two << 24
 };
 
-template <int IP2>
-__global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__ S, unsigned s_bytes, const RenderRec* __restrict__ rec,
-                                                        const float* __restrict__ x, float* __restrict__ recon, float2* __restrict__ aux,
+template <int IP2, int NT>
+__global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__ S, unsigned s_bytes, const RenderObjRec* __restrict__ orec,
+                                                        const RenderCullRec* __restrict__ crec, const float* __restrict__ x,
+                                                        float* __restrict__ recon, float2* __restrict__ aux,
                                                         float* __restrict__ bce_partial, int B, int HW, int I) {
     __shared__ unsigned list[4][R3_MAXHW / 4];
     __shared__ int cnt[4];
-    __shared__ float red[4][8][64];
+    __shared__ float red[4][NT][8][64];
     __shared__ float red4[4];
     constexpr int P = R3_P;
+    constexpr int RH = RT * NT;                 // pixel rows of the region
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv_I = 1.f / (float)I;
-    const int tiles_x = (I + RT - 1) / RT, tiles = tiles_x * tiles_x;
-    int b, tile;
-    if ((B & 7) == 0) {   // XCD-aware: blocks id, id+8, ... share an XCD (round-robin dispatch)
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        b = (j / tiles) * 8 + xcd;
-        tile = j % tiles;
-    } else {
-        b = blockIdx.x / tiles;
-        tile = blockIdx.x % tiles;
-    }
-    const int tx0 = (tile % tiles_x) * RT, ty0 = (tile / tiles_x) * RT;
-    const int tx1 = min(tx0 + RT, I) - 1, ty1 = min(ty0 + RT, I) - 1;
+    // grid (nx, columns * regions, B / nx), nx = 8 when B % 8 == 0: workgroups are dealt round-robin over the 8 XCDs in linear order (x
+    // fastest), so every region of sample b = z * nx + x runs on XCD x -- its sprites are fetched from HBM once and then hit that XCD's L2
+    const int tiles_x = (I + RT - 1) / RT;
+    const int b = blockIdx.z * gridDim.x + blockIdx.x, reg = blockIdx.y;
+    const int ryi = IP2 ? reg >> (31 - __builtin_clz(tiles_x)) : reg / tiles_x;
+    const int tx0 = (reg - ryi * tiles_x) * RT, ty0 = ryi * RH;
+    const int tx1 = min(tx0 + RT, I) - 1, ty1 = min(ty0 + RH, I) - 1;
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int l15 = lane & 15, q = lane >> 4;
-    // this thread's pixel in the epilogue (accumulator layout of the second product: column px, rows 4q .. 4q+3; wave w finishes row 4q+w)
+    // this thread's pixels in the epilogue (accumulator layout of the second product: column px, rows 4q .. 4q+3; wave w finishes row 4q+w
+    // of each of the region's NT tiles)
     const int px = tx0 + l15, py = ty0 + 4 * q + wave;
-    const bool inside = px < I && py < I;
-    const size_t pi = ((size_t)b * I + min(py, I - 1)) * I + min(px, I - 1);
-    const float xv = x[pi];
-    const RenderRec* recb = rec + (size_t)b * HW;
+    size_t pi[NT];
+    float xv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        pi[t] = ((size_t)b * I + min(py + RT * t, I - 1)) * I + min(px, I - 1);
+        xv[t] = x[pi[t]];
+    }
+    const RenderObjRec* orecb = orec + (size_t)b * HW;
+    const RenderCullRec* crecb = crec + (size_t)b * HW;
 
-    // ---- 1. cull: footprint against the tile, the sprite-row window of the hits
+    // ---- 1. cull: footprint against the region; which of its NT tiles a hit reaches; the sprite-row window [v0, v1] of the hit (its
+    // first 16-row tile starts at min(v0, P - 16), so that tile never runs past the sprite; the second one is needed when the window is
+    // longer than 16 rows)
     int nw = 0;
     for (int k0 = 0; k0 < HW; k0 += 256) {
         const int k = k0 + tid;
         bool hit = false;
         unsigned e = 0;
         if (k < HW) {
-            const uint4 rb = reinterpret_cast<const uint4*>(recb + k)[1];
-            const int x0 = rb.z & 0xffff, x1 = rb.z >> 16, y0 = rb.w & 0xffff, y1 = rb.w >> 16;
+            const uint4 rc = *reinterpret_cast<const uint4*>(crecb + k);
+            const int x0 = rc.z & 0xffff, x1 = rc.z >> 16, y0 = rc.w & 0xffff, y1 = rc.w >> 16;
             hit = x0 <= tx1 && x1 >= tx0 && y0 <= ty1 && y1 >= ty0;
-            float g;
-            const float ay = __uint_as_float(rb.x), by = __uint_as_float(rb.y);
-            const float s0 = src_from_base(ay, by, rf_base<0, IP2>(max(ty0, y0), I, inv_I), P, 0, g);
-            const float s1 = src_from_base(ay, by, rf_base<0, IP2>(min(ty1, y1), I, inv_I), P, 0, g);
-            const int v0 = min(max((int)floorf(s0), 0), P - 1), v1 = max(min((int)floorf(s1) + 1, P - 1), v0);
-            e = (unsigned)k | ((unsigned)v0 << 16) | ((v1 - v0) >= 16 ? (1u << 24) : 0u);
+            const float ay = __uint_as_float(rc.x), by = __uint_as_float(rc.y);
+            const float s0 = fmaf(ay, rf_base<0, IP2>(max(ty0, y0), I, inv_I), by);
+            const float s1 = fmaf(ay, rf_base<0, IP2>(min(ty1, y1), I, inv_I), by);
+            // (the rounding to 2^-11 can only move a coordinate ONTO the next integer, never past it: the taps stay inside [floor, floor + 1])
+            const int v0 = min(max((int)floorf(s0), 0), P - 16), v1 = max(min((int)floorf(s1) + 1, P - 1), v0);
+            unsigned ym = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ym |= (y0 <= ty0 + RT * t + RT - 1 && y1 >= ty0 + RT * t) ? (1u << t) : 0u;
+            e = (unsigned)k | ((unsigned)v0 << 16) | ((v1 - v0) >= 16 ? (1u << 24) : 0u) | (ym << 25);
         }
         const unsigned long long bal = __ballot(hit);
         if (hit) list[wave][nw + __popcll(bal & ((1ull << lane) - 1ull))] = e;
@@ -202,15 +242,17 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
         cy[jp] = r3_f2{-(float)v, -(float)(v + 1)};
     }
     const float basex = rf_base<0, IP2>(min(tx0 + l15, I - 1), I, inv_I);
-    const float basey = rf_base<0, IP2>(min(ty0 + l15, I - 1), I, inv_I);
+    float basey[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) basey[t] = rf_base<0, IP2>(min(ty0 + RT * t + l15, I - 1), I, inv_I);
     // first product, A operand: lane (sprite row l15 of the 16-row tile, k-group q): bytes 32q .. 32q+31 of the row
     // (the last k-group's second half would be texels 28 .. 31: it re-reads the first half, its weights are empty)
     const unsigned voff = (unsigned)(l15 * R3_ROWB + 32 * q), voffh = voff + (q == 3 ? 0u : 16u);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(S), (short)0, (int)s_bytes, 0x00020000);
 
-    const r3_h2 floor_v = {(_Float16)0.01f, (_Float16)0.01f};
-    const unsigned floor_h2 = __builtin_bit_cast(unsigned, floor_v);
-    f32x4 num = {0.f, 0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f, 0.f};
+    f32x4 num[NT], den[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { num[t] = f32x4{0.f, 0.f, 0.f, 0.f}; den[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     // this wave's objects: entries wave, wave + 4, ... of the concatenated lists; 64 of them at a time, one per lane
     for (int i0 = wave; i0 < nall; i0 += 256) {
         const int i = i0 + 4 * lane;
@@ -221,46 +263,46 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
             mine = list[seg][i - base];
         }
         const int n = min(64, (nall - i0 + 3) >> 2);
+        // lane j holds the record of this wave's j-th object (one vector load per 64 objects; a record fetched by scalar loads inside the
+        // object loop put their latency on every object)
+        const uint4 myra = reinterpret_cast<const uint4*>(orecb + (mine & 0xffff))[0];
+        const uint4 myrb = reinterpret_cast<const uint4*>(orecb + (mine & 0xffff))[1];
+        auto rl = [&](unsigned v, int j) { return (unsigned)__builtin_amdgcn_readlane((int)v, j); };
         auto fetch = [&](int j) {
             R3Obj o;
-            o.e = (unsigned)__builtin_amdgcn_readlane((int)mine, min(j, n - 1));
+            const int jj = min(j, n - 1);
+            o.e = rl(mine, jj);
+            o.Ax = __uint_as_float(rl(myra.x, jj)); o.BxM = __uint_as_float(rl(myra.y, jj));
+            o.Ay = __uint_as_float(rl(myra.z, jj)); o.ByM = __uint_as_float(rl(myra.w, jj));
+            o.pres = __uint_as_float(rl(myrb.x, jj)); o.mscale = __uint_as_float(rl(myrb.y, jj));
+            o.mfloor = rl(myrb.z, jj);
             const int k = o.e & 0xffff;
             const unsigned v0 = (o.e >> 16) & 0xff;
-            const uint4* rp = reinterpret_cast<const uint4*>(recb + k);
-            o.ra = rp[0]; o.rb = rp[1];
             const unsigned ob = (unsigned)(k * B + b) * (unsigned)R3_SPRB + v0 * (unsigned)R3_ROWB;
-            const unsigned row0 = v0 + (unsigned)l15;
-            const bool ok0 = row0 < (unsigned)P, ok1 = (row0 + 16u < (unsigned)P) & ((o.e >> 24) != 0);
-            // masked lanes read zeros through the descriptor's range check (rows >= P carry weight, so they must BE zero)
-            const unsigned o0l = ok0 ? ob + voff : BUF_OOB, o0h = ok0 ? ob + voffh : BUF_OOB;
+            // rows of the second tile beyond the sprite read zeros through the descriptor's range check (they carry weight: they must BE zero)
+            const bool ok1 = (v0 + (unsigned)l15 + 16u < (unsigned)P) & (((o.e >> 24) & 1u) != 0);
             const unsigned o1l = ok1 ? ob + voff + 16u * R3_ROWB : BUF_OOB, o1h = ok1 ? ob + voffh + 16u * R3_ROWB : BUF_OOB;
-            o.t0.lo = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)o0l, 0, 0);
-            o.t0.hi = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)o0h, 0, 0);
+            o.t0.lo = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(ob + voff), 0, 0);
+            o.t0.hi = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(ob + voffh), 0, 0);
             o.t1.lo = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)o1l, 0, 0);
             o.t1.hi = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)o1h, 0, 0);
             return o;
         };
         auto composite = [&](const R3Obj& o) {
-            const float ax = __uint_as_float(o.ra.x), bx = __uint_as_float(o.ra.y), pr = __uint_as_float(o.ra.z);
-            const float ay = __uint_as_float(o.rb.x), by = __uint_as_float(o.rb.y);
-            const unsigned pdh = o.ra.w;
-            const float v0f = (float)((o.e >> 16) & 0xff);
-            float g;
-            const float sx = (src_from_base(ax, bx, basex, P, 0, g) + R3_QMAGIC) - R3_QMAGIC;
-            const float sy = ((src_from_base(ay, by, basey, P, 0, g) + R3_QMAGIC) - R3_QMAGIC) - v0f;
-            const r3_h8 wx = r3_hat8(sx, cx), wy = r3_hat8(sy, cy);
+            const unsigned v0 = (o.e >> 16) & 0xff;
+            const float sx = fmaf(o.Ax, basex, o.BxM) - R3_QMAGIC;                       // multiples of 2^-11 texel
+            const r3_h8 wx = r3_hat8(sx, cx);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             r3_h8 sg, sa, sm;
-            const unsigned row0 = ((o.e >> 16) & 0xff) + (unsigned)l15;
-            r3_split(o.t0, pdh, row0 < (unsigned)P ? floor_h2 : 0u, sg, sa, sm);
+            r3_split(o.t0, o.mfloor, sg, sa, sm);
             const f32x4 tg0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sg, wx, z, 0, 0, 0);
             const f32x4 ta0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa, wx, z, 0, 0, 0);
             const f32x4 tm0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sm, wx, z, 0, 0, 0);
             u32x4_t hg = {r3_pk(tg0[0], tg0[1]), r3_pk(tg0[2], tg0[3]), 0u, 0u};
             u32x4_t ha = {r3_pk(ta0[0], ta0[1]), r3_pk(ta0[2], ta0[3]), 0u, 0u};
             u32x4_t hm = {r3_pk(tm0[0], tm0[1]), r3_pk(tm0[2], tm0[3]), 0u, 0u};
-            if (o.e >> 24) {
-                r3_split(o.t1, pdh, row0 + 16u < (unsigned)P ? floor_h2 : 0u, sg, sa, sm);
+            if ((o.e >> 24) & 1u) {
+                r3_split(o.t1, v0 + (unsigned)l15 + 16u < (unsigned)P ? o.mfloor : 0u, sg, sa, sm);
                 const f32x4 tg1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sg, wx, z, 0, 0, 0);
                 const f32x4 ta1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa, wx, z, 0, 0, 0);
                 const f32x4 tm1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sm, wx, z, 0, 0, 0);
@@ -268,14 +310,22 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
                 ha[2] = r3_pk(ta1[0], ta1[1]); ha[3] = r3_pk(ta1[2], ta1[3]);
                 hm[2] = r3_pk(tm1[0], tm1[1]); hm[3] = r3_pk(tm1[2], tm1[3]);
             }
-            const f32x4 og = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, hg), z, 0, 0, 0);
-            const f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, ha), z, 0, 0, 0);
-            const f32x4 om = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, hm), z, 0, 0, 0);
+            const float yoff = R3_QMAGIC + (float)v0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = oa[r] * pr;
-                num[r] = fmaf(og[r] * a, om[r] + 1e-9f, num[r]);
-                den[r] += om[r];
+            for (int t = 0; t < NT; ++t) {
+                if (NT == 1 || ((o.e >> (25 + t)) & 1u)) {
+                    const float sy = fmaf(o.Ay, basey[t], o.ByM) - yoff;                 // ... relative to the window's first row
+                    const r3_h8 wy = r3_hat8(sy, cy);
+                    const f32x4 og = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, hg), z, 0, 0, 0);
+                    const f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, ha), z, 0, 0, 0);
+                    const f32x4 om = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, hm), z, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = oa[r] * o.pres, m = om[r] * o.mscale;
+                        num[t][r] = fmaf(og[r] * a, m + 1e-9f, num[t][r]);
+                        den[t][r] += m;
+                    }
+                }
             }
         };
         R3Obj oa_ = fetch(0);
@@ -288,57 +338,73 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
     }
     // ---- the four waves' partial tiles
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { red[wave][r][lane] = num[r]; red[wave][4 + r][lane] = den[r]; }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[wave][t][r][lane] = num[t][r]; red[wave][t][4 + r][lane] = den[t][r]; }
     __syncthreads();
-    const float nsum = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
-    const float dsum = (red[0][4 + wave][lane] + red[1][4 + wave][lane]) + (red[2][4 + wave][lane] + red[3][4 + wave][lane]);
     float bce = 0.f;
-    if (inside) {
-        const float D = dsum + (float)HW * 1e-9f;   // every object adds 1e-9 (models.py:527)
-        const float invD = 1.f / D;
-        const float pre = nsum * invD;
-        const float r = fminf(fmaxf(pre, 0.f), 1.f);
-        recon[pi] = r;
-        // torch BCE: log clamped at -100; backward denominator max(r(1-r), 1e-12)
-        bce = -(xv * fmaxf(logf(r), -100.f) + (1.f - xv) * fmaxf(logf(1.f - r), -100.f));
-        if (aux) {
-            const float gr = (pre >= 0.f && pre <= 1.f) ? (r - xv) / fmaxf(r * (1.f - r), 1e-12f) : 0.f;
-            aux[pi] = make_float2(gr * invD, pre);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float nsum = (red[0][t][wave][lane] + red[1][t][wave][lane]) + (red[2][t][wave][lane] + red[3][t][wave][lane]);
+        const float dsum = (red[0][t][4 + wave][lane] + red[1][t][4 + wave][lane]) + (red[2][t][4 + wave][lane] + red[3][t][4 + wave][lane]);
+        if (px < I && py + RT * t < I) {
+            const float D = dsum + (float)HW * 1e-9f;   // every object adds 1e-9 (models.py:527)
+            const float invD = r3_rcp(D);
+            const float pre = nsum * invD;
+            const float r = fminf(fmaxf(pre, 0.f), 1.f);
+            recon[pi[t]] = r;
+            // torch BCE: log clamped at -100; backward denominator max(r(1-r), 1e-12)
+            bce -= xv[t] * fmaxf(logf(r), -100.f) + (1.f - xv[t]) * fmaxf(logf(1.f - r), -100.f);
+            if (aux) {
+                const float gr = (pre >= 0.f && pre <= 1.f) ? (r - xv[t]) * r3_rcp(fmaxf(r * (1.f - r), 1e-12f)) : 0.f;
+                aux[pi[t]] = make_float2(gr * invD, pre);
+            }
         }
     }
     bce = block_reduce_sum_256(bce, red4);
-    if (tid == 0) bce_partial[blockIdx.x] = bce;
+    if (tid < NT) bce_partial[wg * NT + tid] = tid == 0 ? bce : 0.f;
 }
 
-int render_prep_bytes(int B, int HW) { return B * HW * (int)sizeof(RenderRec); }
+int render_prep_bytes(int B, int HW) { return B * HW * R3_REC_BYTES; }
 
 // SPAIR_ERR_UNSUPPORTED: the caller keeps k_render_fwd3 (which needs no records)
 int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac,
                 hipStream_t s) {
     if (ac || P != R3_P || HW > R3_MAXHW || I >= (int)R3_EMPTY || (reinterpret_cast<uintptr_t>(rec) & 15)) return SPAIR_ERR_UNSUPPORTED;
     const dim3 grid((B * HW + 255) / 256), block(256);
+    RenderObjRec* orec = reinterpret_cast<RenderObjRec*>(rec);
+    RenderCullRec* crec = reinterpret_cast<RenderCullRec*>(orec + (size_t)B * HW);
     if ((I & (I - 1)) == 0)
-        hipLaunchKernelGGL((k_render_prep<0, 1>), grid, block, 0, s, nbox, pres, depth, ld_pd, reinterpret_cast<RenderRec*>(rec), B, HW, I, P);
+        hipLaunchKernelGGL((k_render_prep<0, 1>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, B, HW, I, P);
     else
-        hipLaunchKernelGGL((k_render_prep<0, 0>), grid, block, 0, s, nbox, pres, depth, ld_pd, reinterpret_cast<RenderRec*>(rec), B, HW, I, P);
+        hipLaunchKernelGGL((k_render_prep<0, 0>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, B, HW, I, P);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
 
+#ifndef R3_NT
+#define R3_NT 4                     // 16-row tiles per workgroup region (one tile column, R3_NT tiles tall)
+#endif
 int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW,
                    int I, int P, int ac, hipStream_t s) {
     if (ac || P != R3_P || ld_s != R3_P * R3_P * 2 || HW > R3_MAXHW || I >= (int)R3_EMPTY) return SPAIR_ERR_UNSUPPORTED;
     if ((unsigned long long)B * HW * R3_SPRB >= 0xfffffff0ull - 64) return SPAIR_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(S16) & 15) || (reinterpret_cast<uintptr_t>(rec) & 15)) return SPAIR_ERR_UNSUPPORTED;
-    const int t = (I + RT - 1) / RT;
-    const dim3 grid(B * t * t), block(256);
+    const int t = (I + RT - 1) / RT, nx = (B & 7) == 0 ? 8 : 1;
+    // regions of R3_NT tiles when they tile the image's tile rows exactly (the bce_partial slots are the tiles'), single tiles otherwise
+    const int nt = (t % R3_NT) == 0 ? R3_NT : 1;
+    if (t * (t / nt) > 65535 || B / nx > 65535) return SPAIR_ERR_UNSUPPORTED;
+    const dim3 grid(nx, t * (t / nt), B / nx), block(256);
     const unsigned s_bytes = (unsigned)((size_t)B * HW * R3_SPRB);
-    if ((I & (I - 1)) == 0)
-        hipLaunchKernelGGL((k_render_fwd_mma<1>), grid, block, 0, s, S16, s_bytes, reinterpret_cast<const RenderRec*>(rec), x, recon,
-                           reinterpret_cast<float2*>(aux), bce_partial, B, HW, I);
-    else
-        hipLaunchKernelGGL((k_render_fwd_mma<0>), grid, block, 0, s, S16, s_bytes, reinterpret_cast<const RenderRec*>(rec), x, recon,
-                           reinterpret_cast<float2*>(aux), bce_partial, B, HW, I);
+    const RenderObjRec* orec = reinterpret_cast<const RenderObjRec*>(rec);
+    const RenderCullRec* crec = reinterpret_cast<const RenderCullRec*>(orec + (size_t)B * HW);
+    const bool ip2 = (I & (I - 1)) == 0;
+#define R3_LAUNCH(IP2_, NT_)                                                                                                           \
+    hipLaunchKernelGGL((k_render_fwd_mma<IP2_, NT_>), grid, block, 0, s, S16, s_bytes, orec, crec, x, recon, reinterpret_cast<float2*>(aux), \
+                       bce_partial, B, HW, I)
+    if (nt == 1) { if (ip2) R3_LAUNCH(1, 1); else R3_LAUNCH(0, 1); }
+    else { if (ip2) R3_LAUNCH(1, R3_NT); else R3_LAUNCH(0, R3_NT); }
+#undef R3_LAUNCH
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
