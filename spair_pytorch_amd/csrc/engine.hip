@@ -982,10 +982,17 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     prof_end(ps_bb, c.s);
     if (side && hipStreamWaitEvent(c.s, side->ev[4], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // tables, per-cell and decoder weights
     { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
-    // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer
+    // the KL terms and the renderer's per-object records only need the cell chain's outputs: they run on the helper stream beside the
+    // decoder (and the KL terms beside the renderer)
+    int rc_prep = SPAIR_ERR_UNSUPPORTED;
     {
         hipStream_t ks = side ? side->s : c.s;
         if (side) TRY(stream_link(c.s, ks, side->ev[0]));
+        if (d->dtype == SPAIR_BF16 && d->C == 1) {
+            rc_prep = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, ks);
+            if (rc_prep != SPAIR_OK && rc_prep != SPAIR_ERR_UNSUPPORTED) return rc_prep;
+            if (side && hipEventRecord(side->ev[2], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;      // (ev[2..4] were consumed before the cell chain)
+        }
         { ProfScope ps(PS_COUNT_KL, ks); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, ks)); }
         TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, ks));
         if (side && hipEventRecord(side->ev[1], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;
@@ -1031,11 +1038,10 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         ProfScope ps(PS_RENDER_FWD, c.s);
         // bf16 step: the sampling on the matrix cores from per-object records (render3.hip); every other case on the tap kernels
         int rc = SPAIR_ERR_UNSUPPORTED;
-        if (d->dtype == SPAIR_BF16 && d->C == 1) {
-            rc = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, c.s);
-            if (rc == SPAIR_OK)
-                rc = render_fwd_mma(c.w.S, c.w.ld_s, c.w.rrec, x, recon, st->train ? c.w.aux : nullptr, c.w.bce_partial, d->B, L.HW, d->I,
-                                    d->P, d->align_corners, c.s);
+        if (rc_prep == SPAIR_OK) {
+            if (side && hipStreamWaitEvent(c.s, side->ev[2], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
+            rc = render_fwd_mma(c.w.S, c.w.ld_s, c.w.rrec, x, recon, st->train ? c.w.aux : nullptr, c.w.bce_partial, d->B, L.HW, d->I,
+                                d->P, d->align_corners, c.s);
         }
         if (rc == SPAIR_ERR_UNSUPPORTED)
             rc = render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
