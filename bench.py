@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the bounded BASELINE configs[3] sub-record (256x256, 32x32 grid, batch 64) of the default single-GPU line")
     ap.add_argument("--config3-steps", type=int, default=20)
-    ap.add_argument("--repeat", type=int, default=3, help="repeat the K-step timed region this many times and report the fastest")
+    ap.add_argument("--repeat", type=int, default=3, help="repeat the K-step timed region this many times; the MEDIAN repeat is reported")
     ap.add_argument("--prof-every", type=int, default=4, help="record the per-kernel HIP event pairs on every n-th timed step")
     ap.add_argument("--prof-mask", type=lambda v: int(v, 0), default=-1, help="bit mask of the engine's event-pair slots to record (-1 = all)")
     args = ap.parse_args()
@@ -386,10 +386,12 @@ def main():
     cfg.set_grid(args.image, strides)
     torch.manual_seed(3)                                   # train.py:39
     model = SPAIR([1, args.image, args.image], None, dev, compute_dtype=args.dtype).to(dev)
-    # SPAIR_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of the three bucketed, overlapped ones
-    # (timing: the buckets' all-reduce issue -> complete times go into the N > 1 line's `ddp` record)
-    ddp.attach(model, world, overlap=os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0", timing=world > 1)
-    bwd_end = torch.cuda.Event(enable_timing=True) if world > 1 else None
+    # SPAIR_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of the three bucketed, overlapped ones.
+    # The timed region runs WITHOUT bucket instrumentation (no extra event records, no wait on the communication stream per bucket); the
+    # buckets' issue -> complete times of the N > 1 line's `ddp` record come from one extra step behind it (re-attached with timing=True)
+    ddp_overlap = os.environ.get("SPAIR_DDP_OVERLAP", "1") != "0"
+    ddp.attach(model, world, overlap=ddp_overlap, timing=False)
+    bwd_end = [None]
     if world > 1:
         ddp.broadcast_parameters(model.flat_parameters())
     opt = FusedAdam(model, lr=1e-4)
@@ -403,9 +405,11 @@ def main():
         opt.zero_grad()
         loss, recon, z_where, z_pres = model(x, gstep[0])
         last["z_pres"] = z_pres
+        last["z_where"] = z_where
         loss.backward()
         if world > 1:
-            bwd_end.record()
+            if bwd_end[0] is not None:
+                bwd_end[0].record()
             ddp.allreduce_gradients(model)       # three buckets behind the backward's readiness events, on a communication stream
         opt.step()
         gstep[0] += 1
@@ -418,9 +422,13 @@ def main():
     L.check(lib.spair_prof_enable(1), "prof_enable")
     lib.spair_prof_enable(0)
     # EXACTLY K steps bracketed by barrier + synchronize on both sides; the bracket is repeated `--repeat` times (default 3) and the
-    # fastest repeat is reported (`ms_per_step_repeats` lists all of them): one host-side hiccup (allocator, Python GC, a cold page) in a
-    # 0.1 s region otherwise decides the line.  Per-kernel event pairs are sampled in the FIRST repeat only.
+    # MEDIAN repeat is the line's ms_per_step / value (`ms_per_step_repeats` lists all of them, `ms_per_step_min` the fastest): one
+    # host-side hiccup (allocator, Python GC, a cold page) in a 0.1 s region does not decide the line, and neither does the luckiest
+    # repeat.  Per-kernel event pairs are sampled at the same cadence in EVERY repeat, so the reported repeat carries them too.
     rep_dt = []
+    nslots = len(SLOT_NAMES)
+    ms = (ctypes.c_float * nslots)()
+    cnt = (ctypes.c_int * nslots)()
     for rep in range(max(1, args.repeat)):
         if world > 1:
             dist.barrier()
@@ -428,31 +436,34 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             # the kernels' event pairs are sampled on every n-th step of the timed region (each pair costs ~3 us of queue time)
-            lib.spair_prof_enable(2 if (rep == 0 and i % args.prof_every == 0) else 0)
+            lib.spair_prof_enable(2 if i % args.prof_every == 0 else 0)
             loss = step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         rep_dt.append(time.perf_counter() - t0)
+        L.check(lib.spair_prof_read(ms, cnt, nslots), "prof_read")        # drains the event pool between repeats (outside the bracket)
+        lib.spair_prof_enable(0)
     if world > 1:
         tt = torch.tensor(rep_dt, device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # MAX over ranks, per repeat
         rep_dt = [float(v) for v in tt.tolist()]
-    dt = min(rep_dt)
-    nslots = len(SLOT_NAMES)
-    ms = (ctypes.c_float * nslots)()
-    cnt = (ctypes.c_int * nslots)()
-    L.check(lib.spair_prof_read(ms, cnt, nslots), "prof_read")
-    lib.spair_prof_enable(0)
+    srt = sorted(rep_dt)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])     # the median repeat
     terms = model.loss_terms().clone()
     ddp_rec = None
     if world > 1:
         terms = ddp.global_loss(terms)
-        # the LAST timed step's buckets (rank 0's view): does the window each bucket opens before the end of the backward hide its collective?
-        bt = ddp.bucket_timings(model, bwd_end)
+        # one extra, untimed step with the bucket instrumentation (rank 0's view): does the window each bucket opens before the end of
+        # the backward hide its collective?
+        ddp.attach(model, world, overlap=ddp_overlap, timing=True)
+        bwd_end[0] = torch.cuda.Event(enable_timing=True)
+        step()
+        torch.cuda.synchronize()
+        bt = ddp.bucket_timings(model, bwd_end[0])
         if bt is not None:
             ddp_rec = dict(backend=backend, overlap=True, buckets=bt,
-                           note="last timed step, rank 0: allreduce_ms = range final -> collective complete on the communication stream; "
+                           note="one instrumented step behind the timed region, rank 0: allreduce_ms = range final -> collective complete on the communication stream; "
                                 "done_after_backward_end_ms > 0 is the exposed part of that bucket")
         else:
             ddp_rec = dict(backend=backend, overlap=False, note="one all-reduce of the whole flat gradient behind the backward (SPAIR_DDP_OVERLAP=0)")
@@ -463,7 +474,7 @@ def main():
 
     K = args.steps
     d = model._last["engine"]["dims"]
-    kernels, per_step_ms = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, args.prof_every)))
+    kernels, per_step_ms = kernel_table(d, B, args.dtype, ms, cnt, len(range(0, K, args.prof_every)) * len(rep_dt))
     # K4 (the STN-forward gather is a stage of k_chain_fwd, not a launch): its share of the kernel from the in-kernel stage stamps of
     # one extra step outside the timed region
     # (rank 0 alone runs it, the other ranks have left: a forward pass only -- nothing collective)
@@ -488,28 +499,46 @@ def main():
                vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=workload, global_batch=world * B, image=args.image, grid=d.G, global_step=args.global_step,
                            parallelism="dp%d" % world),
-               repeat=len(rep_dt), ms_per_step_repeats=[v / K * 1e3 for v in rep_dt],
+               repeat=len(rep_dt), ms_per_step_repeats=[v / K * 1e3 for v in rep_dt], ms_per_step_min=min(rep_dt) / K * 1e3,
+               ms_per_step_note="ms_per_step / value = the MEDIAN of the repeats",
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
     if ddp_rec is not None:
         out["ddp"] = ddp_rec
     default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16"
     if world == 1 and not args.no_sweep and (args.sweep or default_workload):
-        # BASELINE configs[4] on one GPU: the count-prior schedule (config.py:65-69, models.py:186-188) changes z_pres and with it the
-        # renderer's active-cell density; same model state, only global_step differs between the points
+        # BASELINE configs[4] on one GPU: "z_pres discovery-prior curriculum sweep (max_objects 1 -> 11) ... sequential compositing kernel
+        # under varying active-cell density".  Three axes, every point from the same model and optimizer state:
+        #   schedule : global_step of the count-prior / training-wheel schedules (config.py:65-69, models.py:186-188), the bench batch;
+        #   objects  : scenes with at most k = 1, 3, 6, 11 digits (the dataset's max_objects);
+        #   density  : the state itself moved to where training takes it -- the presence logit's bias (obj_network.out.bias) bisected to
+        #              mean z_pres 0.05 / 0.3 / 0.7, the box-size means' bias (box_network.output_layers.0.bias[2:4]) set for mean object
+        #              sides of ~15 / 24 / 38 px: what the renderer's cost actually follows (active cells x footprint).
         from spair_pytorch_amd.models import step_scalars
-        sweep = []
+        sd = model.state_dict()
         snap = (model.flat_parameters().clone(), opt.state_dict())
         snap = (snap[0], {k: (v.clone() if torch.is_tensor(v) else v) for k, v in snap[1].items()})
-        for gs in (0, 2000, 4000, 6000, 7000, 8000, 10000):
+        x_main = x
+        nsl = len(SLOT_NAMES)
+        R_F, R_B = SLOT_NAMES.index("render_fwd"), SLOT_NAMES.index("render_bwd")
+
+        def restore():
             model.flat_parameters().copy_(snap[0])         # every point starts from the same model and optimizer state
             opt.load_state_dict(snap[1])
+
+        def time_point(gs, xin, label):
+            nonlocal x
+            x = xin
             gstep[0] = gs
             step()
             step()                                         # two warm steps behind the state restore
             torch.cuda.synchronize()
             # per-step device time from event pairs on the launch stream; the point's figure is the MEDIAN step (a host-side stall inside
-            # one step -- the restore's allocator traffic, a GC pause -- no longer moves it), the wall-clock mean is kept beside it
+            # one step -- the restore's allocator traffic, a GC pause -- does not move it), the wall-clock mean is kept beside it; the
+            # renderer's two kernels from the engine's own event slots over the same steps
+            pm, pc = (ctypes.c_float * nsl)(), (ctypes.c_int * nsl)()
+            lib.spair_prof_select(ctypes.c_ulonglong((1 << R_F) | (1 << R_B)))
+            lib.spair_prof_enable(1)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.sweep_steps)]
             t1 = time.perf_counter()
             for e0, e1 in evs:
@@ -518,13 +547,62 @@ def main():
                 e1.record()
             torch.cuda.synchronize()
             wall_ms = (time.perf_counter() - t1) / args.sweep_steps * 1e3
+            lib.spair_prof_read(pm, pc, nsl)
+            lib.spair_prof_enable(0)
             per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
             ms_s = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
             st_ = step_scalars(gs, B)
-            sweep.append(dict(global_step=gs, count_prior_prob=float(st_.count_prior_prob), wheel=float(st_.wheel), ms_per_step=ms_s,
-                              ms_per_step_wall_mean=wall_ms, ms_per_step_max=per[-1], images_per_sec=B / ms_s * 1e3, mean_z_pres=float(last["z_pres"].mean().item())))
+            zp, zw = last["z_pres"], last["z_where"]
+            side_px = float(zw[:, 2:4].mean().item()) * args.image       # z_where = (xt, yt, xs, ys) in image units (models.py:375-381)
+            # presence-weighted footprint: what the compositing kernels walk
+            rec = dict(axis=label, global_step=gs, count_prior_prob=float(st_.count_prior_prob), wheel=float(st_.wheel), ms_per_step=ms_s,
+                       ms_per_step_wall_mean=wall_ms, ms_per_step_max=per[-1], images_per_sec=B / ms_s * 1e3,
+                       mean_z_pres=float(zp.mean().item()), mean_box_side_px=side_px,
+                       render_fwd_ms=pm[R_F] / max(pc[R_F], 1), render_bwd_ms=pm[R_B] / max(pc[R_B], 1))
+            x = x_main
+            return rec
+
+        sweep = []
+        for gs in (0, 2000, 4000, 6000, 7000, 8000, 10000):
+            restore()
+            sweep.append(time_point(gs, x_main, "schedule"))
+        for k in (1, 3, 6, 11):
+            restore()
+            xk = torch.from_numpy(scattered_digits(4321, B, args.image, k)[0]).to(dev)
+            r = time_point(args.global_step, xk, "objects")
+            r["max_objects"] = k
+            sweep.append(r)
+        pres_b, box_b = sd["obj_network.out.bias"], sd["box_network.output_layers.0.bias"]
+
+        def mean_pres():
+            # a TRAINING-mode forward (relaxed-Bernoulli samples, as in the timed steps), no backward
+            return float(model(x_main, args.global_step)[3].mean().item())
+
+        for target_pres in (0.05, 0.3, 0.7):
+            for size_bias, size_name in ((-0.79, "~15 px"), (0.0, "~24 px"), (1.33, "~38 px")):
+                restore()
+                with torch.no_grad():
+                    box_b[2:4] += size_bias
+                    base = pres_b.clone()
+                    lo_, hi_ = -12.0, 12.0                  # the mean presence is monotone in the logit's bias
+                    for _ in range(14):
+                        mid = 0.5 * (lo_ + hi_)
+                        pres_b.copy_(base + mid)
+                        if mean_pres() < target_pres:
+                            lo_ = mid
+                        else:
+                            hi_ = mid
+                    pres_b.copy_(base + 0.5 * (lo_ + hi_))
+                r = time_point(args.global_step, x_main, "density")
+                r["target_mean_z_pres"] = target_pres
+                r["target_box_side"] = size_name
+                sweep.append(r)
+        restore()
+        lib.spair_prof_select(ctypes.c_ulonglong(args.prof_mask & 0xFFFFFFFFFFFFFFFF))
         out["sweep"] = sweep
-        out["sweep_note"] = "BASELINE configs[4] on ONE GPU (the 8-GPU form is the driver's): %d timed steps per point behind 2 warm steps; ms_per_step = median of the per-step event times" % args.sweep_steps
+        out["sweep_note"] = ("BASELINE configs[4] on ONE GPU (the 8-GPU form is the driver's): schedule / object-count / density axes, %d timed steps per "
+                             "point behind 2 warm steps, every point from the same model and optimizer state; ms_per_step = median of the per-step "
+                             "event times; render_*_ms = the renderer's two kernels over the same steps" % args.sweep_steps)
     if world == 1 and default_workload and not args.no_config3:
         # BASELINE configs[3] (256x256, 32x32 grid, batch 64) as a bounded sub-record of the default line: its own model, a few steps
         out["config3"] = config3_record(dev, args, strides)      # (the main model stays alive: two ~5 GB workspaces of 288 GB)

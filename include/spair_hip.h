@@ -104,9 +104,10 @@ int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long 
 int spair_chain_stamp_layout(int* fwd_per_wavefront, int* fwd_glimpse_interval, int* bwd_per_wavefront);
 /* wavefronts walked by the workgroup that stamps (sample 0; with the band split of grids wider than 16 cells, its top band) */
 int spair_chain_stamp_wavefronts(const SpairDims* d);
-/* band split of the fused per-cell kernels (grids wider than 16 cells: two workgroups per sample hand the boundary row's records /
- * context gradients to each other through `workspace`): writes 1 to *out (device int) if a bounded wait timed out in the latest
- * spair_forward / spair_backward on this workspace, 0 if not, -1 where the kernels run unsplit */
+/* band split of the fused per-cell kernels (grids wider than 16 cells: ceil(G / 8) workgroups per sample hand the boundary rows' records /
+ * context gradients to each other through `workspace`): writes 1 to *out (device int) if a bounded wait EVER timed out in a
+ * spair_forward / spair_backward on this workspace (sticky: only re-zeroing the workspace clears it; from that step on loss_out[0] and the
+ * gradient of virtual_edge_element are NaN, so a training loop sees it without calling this), 0 if not, -1 where the kernels run unsplit */
 int spair_chain_sync_status(const SpairDims* d, const void* workspace, int* out, void* stream);
 int spair_noise_fill(const SpairDims* d, uint64_t seed, float* eps_box, float* eps_attr, float* eps_depth, float* u_pres, void* stream);
 

@@ -21,7 +21,9 @@ struct ChainArgs {
     // ever READS from the band above it (a cell's context is (h-1, w-1), (h-1, w), (h-1, w+1), (h, w-1): models.py:297-304), so the bands of a
     // sample run as a pipeline -- the upper band publishes its last row's records, the lower one consumes them one wavefront later; the
     // backward kernel runs the same pipeline upwards with the context gradients.  `sync` (ints, zeroed before every launch): [0] start
-    // ticket, [2] time-out flag, [16 + b*nbands + band] wavefronts published; bnd_rec [B][nbands][G][REC], bnd_grad [B][nbands][G][3][REC].
+    // ticket, [2] time-out flag, [16 + b*nbands + band] wavefronts published; behind them ONE word that no launch clears
+    // (CHAIN_SYNC_STICKY: set with [2], zeroed only with the workspace) -- the loss and the edge gradient of a step turn NaN while it is set;
+    // bnd_rec [B][nbands][G][REC], bnd_grad [B][nbands][G][3][REC].
     int nbands;
     int* sync;
     float* bnd_rec;
@@ -29,6 +31,8 @@ struct ChainArgs {
 };
 #define CHAIN_MAX_BANDS 4
 #define CHAIN_SYNC_HDR 16
+#define CHAIN_SYNC_STICKY(B, nbands) (CHAIN_SYNC_HDR + 2 * (B) * (nbands))      // index of the sticky time-out word
+#define CHAIN_SYNC_WORDS(B, nbands) (CHAIN_SYNC_STICKY(B, nbands) + 4)
 int chain_bands(const SpairDims& d);          // 1 up to 16 x 16 cells; bands of 8 grid rows beyond (a wavefront then has <= 8 cells per band)
 
 // stage stamps (diagnostic, SpairStep.flags bit 1): stamps per wavefront; the forward kernel's intervals are

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tq + 1);
             if (!ok) __builtin_amdgcn_s_sleep(8);
         }
-        if (!ok) { sync_dead = 1; if (ln == 0) a.sync[2] = 1; }      // time-out: never wait again, flag the launch as failed
+        if (!ok) { sync_dead = 1; if (ln == 0) { a.sync[2] = 1; a.sync[CHAIN_SYNC_STICKY(L.B, NBn)] = 1; } }      // time-out: never wait again, flag the launch (and, sticky, the workspace) as failed
         if (ln < REC / 2) {
             const u64_t v = __hip_atomic_load(reinterpret_cast<const u64_t*>(a.bnd_rec + ((size_t)(b * NBn + band - 1) * G + w) * REC) + ln,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need);
             if (!ok) __builtin_amdgcn_s_sleep(8);
         }
-        if (!ok) { sync_dead = 1; if (ln == 0) a.sync[2] = 1; }
+        if (!ok) { sync_dead = 1; if (ln == 0) { a.sync[2] = 1; a.sync[CHAIN_SYNC_STICKY(L.B, NBn)] = 1; } }
         for (int i = ln; i < 3 * REC / 2; i += 64) {
             const u64_t v = __hip_atomic_load(reinterpret_cast<const u64_t*>(a.bnd_grad + ((size_t)(b * NBn + band + 1) * G + w) * 3 * REC) + i,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1501,7 +1501,8 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
 
 // gedge[j] += sum_b sum_s part[b][s][j]: 16 row groups of one workgroup sum contiguous chunks in row order (8 loads in flight each), then the
 // 16 group sums are added in group order -- the same association on every run
-__global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge) {
+__global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ part, int B, float* __restrict__ gedge,
+                                                      const int* __restrict__ failed) {
     __shared__ float grp[16][64];
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = 4 * B, per = (n + 15) / 16;
@@ -1524,11 +1525,15 @@ __global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ 
         float r = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) r += grp[e][j];
-        gedge[j] += r;
+        // a band-split hand-off of this workspace timed out (sticky word): the gradients of this step are not to be used -- NaN into a
+        // parameter gradient makes that visible in the next loss without a host-side check
+        gedge[j] += (failed && *failed) ? __builtin_nanf("") : r;
     }
 }
 
-int chain_bands(const SpairDims& d) { return d.G > 16 ? (d.G + 7) / 8 : 1; }      // G <= 32 (chain_fwd_supported): at most CHAIN_MAX_BANDS
+// G <= 32 (chain_fwd_supported): ceil(G / 8) bands of as-even-as-possible height, at most CHAIN_MAX_BANDS
+int chain_bands(const SpairDims& d) { return d.G > 16 ? (d.G + 7) / 8 : 1; }
+static_assert((32 + 7) / 8 <= CHAIN_MAX_BANDS, "chain_fwd_supported() admits G <= 32");
 
 static int chain_sync_reset(const ChainArgs& a, hipStream_t s) {
     if (a.nbands <= 1) return SPAIR_OK;
@@ -1545,7 +1550,8 @@ int chain_bwd(const ChainArgs& a, hipStream_t s) {
     return SPAIR_OK;
 }
 int chain_edge_reduce(const ChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(1024), 0, s, a.gedge_part, a.L.B * a.nbands, a.gedge);
+    hipLaunchKernelGGL(k_edge_reduce, dim3(1), dim3(1024), 0, s, a.gedge_part, a.L.B * a.nbands, a.gedge,
+                       a.nbands > 1 && a.sync ? a.sync + CHAIN_SYNC_STICKY(a.L.B, a.nbands) : nullptr);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

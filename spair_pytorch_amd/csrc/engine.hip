@@ -27,7 +27,7 @@ int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, c
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
-int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale, float beta, float* loss_out, hipStream_t s);
+int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale, float beta, float* loss_out, const int* failed, hipStream_t s);
 
 #define TRY(expr)                      \
     do {                               \
@@ -256,7 +256,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
     w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);
-    w.chain_sync = nbands > 1 ? c.take<int>((size_t)CHAIN_SYNC_HDR + 2 * (size_t)d.B * nbands) : nullptr;
+    w.chain_sync = nbands > 1 ? c.take<int>((size_t)CHAIN_SYNC_WORDS(d.B, nbands)) : nullptr;
     w.bnd_rec = nbands > 1 ? c.take<float>((size_t)d.B * nbands * d.G * L.REC) : nullptr;
     w.bnd_grad = nbands > 1 ? c.take<float>((size_t)d.B * nbands * d.G * 3 * L.REC) : nullptr;
     w.stamps = c.take<unsigned long long>(4096);
@@ -1051,7 +1051,8 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     if (side && hipStreamWaitEvent(c.s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
     ProfScope psl(PS_LOSS, c.s);
     TRY(loss_finalize(c.w.bce_partial, render_num_blocks(d->B, d->I), c.w.kl_partial, loss_gauss_kl_blocks(L), c.w.klp, d->B,
-                      st->kl_scale, d->vae_beta, loss_out, c.s));
+                      st->kl_scale, d->vae_beta, loss_out,
+                      c.use_chain && c.w.chain_sync ? c.w.chain_sync + CHAIN_SYNC_STICKY(d->B, chain_bands(*d)) : nullptr, c.s));
     return SPAIR_OK;
 }
 
@@ -1337,14 +1338,15 @@ extern "C" int spair_chain_stamps(const SpairDims* d, const void* workspace, uns
     return SPAIR_OK;
 }
 
-// band split of the fused chain kernels: 1 if a wait for the neighbouring band timed out in the latest launch on this workspace (results
-// are then wrong; never seen -- the test suite asserts 0), else 0; -1 where the chain runs unsplit.  Copies one int to `out` (device).
+// band split of the fused chain kernels: 1 if a wait for the neighbouring band ever timed out in a launch on this workspace (STICKY: no
+// launch clears it; the step's loss and edge-element gradient are NaN from then on -- never seen, the test suite asserts 0), else 0; -1 where
+// the chain runs unsplit.  Copies one int to `out` (device).
 extern "C" int spair_chain_sync_status(const SpairDims* d, const void* workspace, int* out, void* stream) {
     if (!d || !workspace || !out) return SPAIR_ERR_SHAPE;
     TRY(validate(*d));
     const Ws w = carve(*d, const_cast<void*>(workspace));
     if (!w.chain_sync) return hipMemsetAsync(out, 0xff, sizeof(int), (hipStream_t)stream) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
-    return hipMemcpyAsync(out, w.chain_sync + 2, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
+    return hipMemcpyAsync(out, w.chain_sync + CHAIN_SYNC_STICKY(d->B, chain_bands(*d)), sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
 }
 // number of wavefronts the stamping workgroup (sample 0, top band) walks: 3G-2 unsplit, its band's share otherwise
 extern "C" int spair_chain_stamp_wavefronts(const SpairDims* d) {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_gauss_kl(CellLayout L, CellBufs P, Cell
 // loss_out[0]=total, [1]=BCE, [2..7]=Gaussian KLs * kl_scale, [8]=presence KL * kl_scale
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ bce_partial, int n_bce, const float* __restrict__ kl_partial,
                                                        int n_kl, const float* __restrict__ klp, int B, float kl_scale, float beta,
-                                                       float* __restrict__ loss_out) {
+                                                       float* __restrict__ loss_out, const int* __restrict__ failed) {
     // all eight sums in one pass: every load of a thread is issued before the first add, one LDS reduction for the lot
     // (eight block reductions in sequence, each behind its own dependent loads, took 23 us between the renderer's two passes)
     __shared__ float red[4][8];
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
         float kl_total = 0.f;
         for (int k = 0; k < 7; ++k) { loss_out[2 + k] = kls[k]; kl_total += kls[k]; }
         loss_out[1] = bce;
-        loss_out[0] = bce + beta * kl_total;
+        // `failed`: the band-split chain's sticky time-out word (chain.h) -- a step whose hand-off timed out announces itself as a NaN loss
+        loss_out[0] = (failed && *failed) ? __builtin_nanf("") : bce + beta * kl_total;
     }
 }
 
@@ -168,8 +169,8 @@ int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, fl
     return SPAIR_OK;
 }
 int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale,
-                  float beta, float* loss_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, bce_partial, n_bce, kl_partial, n_kl, klp, B, kl_scale, beta, loss_out);
+                  float beta, float* loss_out, const int* failed, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, bce_partial, n_bce, kl_partial, n_kl, klp, B, kl_scale, beta, loss_out, failed);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

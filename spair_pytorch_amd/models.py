@@ -300,18 +300,24 @@ class SPAIR(nn.Module):
             if limit is None:
                 live = sum(int(v["workspace"].numel()) for v in self._engines.values())
                 limit = 2 if (live + nbytes) <= torch.cuda.get_device_properties(dev).total_memory // 4 else 1
+            block = None
             while len(self._engines) >= max(1, limit):      # evict BEFORE allocating: two multi-GB workspaces never coexist needlessly
                 old = self._engines.pop(next(iter(self._engines)))
                 # `_last` holds a strong reference to the engine of the latest forward: drop it too, or the evicted workspace stays alive
                 # until `_run_forward` reassigns `_last` -- i.e. across the allocation below (a pending backward through it raises, as for
-                # any evicted engine: the step function only holds a weak reference)
+                # any evicted engine: the step function only holds a weak reference; export_map and the logging helpers say so too)
                 if getattr(self, "_last", None) is not None and self._last.get("engine") is old:
                     self._last = None
+                # alternating batch sizes under limit 1 (the partial last batch of every epoch): the evicted block is re-used when the new
+                # workspace fits in it -- re-zeroed, no hipFree / hipMalloc / device synchronisation per alternation
+                if block is None and int(old["workspace"].numel()) >= nbytes:
+                    block = old["workspace"]
                 del old
-                if max(1, limit) == 1:
-                    torch.cuda.empty_cache()              # the limit-1 case exists because two workspaces do not fit comfortably: return the block
+            if block is None and max(1, limit) == 1:
+                torch.cuda.empty_cache()                  # the limit-1 case exists because two workspaces do not fit comfortably: return the block
+            ws = block.zero_() if block is not None else torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             e = _Engine(dims=d, generation=0,
-                     workspace=torch.zeros(nbytes, dtype=torch.uint8, device=dev),   # zero-initialised ONCE
+                     workspace=ws,                                                   # zero-initialised ONCE per engine
                      noise=dict(eps_box=torch.empty(batch, 4, G, G, device=dev), eps_attr=torch.empty(batch, A, G, G, device=dev),
                                 eps_depth=torch.empty(batch, 1, G, G, device=dev), u_pres=torch.empty(batch, 1, G, G, device=dev)))
         else:
@@ -402,9 +408,30 @@ class SPAIR(nn.Module):
         """Device tensor [9]: total, reconstruction BCE, KL cy,cx,height,width,attr,depth,pres (no sync)."""
         return self._loss_terms[:9]
 
+    def _last_engine(self):
+        last = getattr(self, "_last", None)
+        if last is None:
+            raise L.SpairHipError("no live forward pass: the model has not run yet, or the workspace of its latest forward was evicted by a "
+                                  "forward of another batch size (max_engines)")
+        return last['engine']
+
+    def chain_status(self):
+        """Band-split hand-off status of the latest forward's workspace (grids wider than 16 cells): -1 where the chain runs unsplit, 0 = every
+        hand-off arrived, 1 = a wait timed out (sticky; that step's loss and every later one is NaN).  SYNCHRONISES -- call it where the
+        host waits anyway (after ``loss.item()``, at the end of an epoch); ``check_chain_status()`` raises instead of returning 1."""
+        e = self._last_engine()
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        L.check(L.lib().spair_chain_sync_status(ctypes.byref(e['dims']), L.ptr(e['workspace']), L.ptr(out), L.stream()), "spair_chain_sync_status")
+        return int(out.item())
+
+    def check_chain_status(self):
+        if self.chain_status() == 1:
+            raise L.SpairHipError("a band-split hand-off of the per-cell chain timed out (preempted / oversubscribed GPU?): the results of this "
+                                  "workspace are not to be used -- restart the process, do not retry in place")
+
     def export_map(self, which):
         """Per-cell quantity of the last forward as an NCHW map (see spair_export_map)."""
-        e = self._last['engine']
+        e = self._last_engine()
         d = e['dims']
         ch = d.A if which in (0, 6, 12) else 1
         out = torch.empty(d.B, ch, d.G, d.G, device=self.device, dtype=torch.float32)

@@ -51,7 +51,7 @@ if __name__ == "__main__":
         import hashlib, os
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out["src_sha16"] = {}
-        for src in ("spair_pytorch_amd/csrc/chain.hip", "spair_pytorch_amd/csrc/render2.hip"):
+        for src in ("spair_pytorch_amd/csrc/chain.hip", "spair_pytorch_amd/csrc/render2.hip", "spair_pytorch_amd/csrc/render3.hip"):
             out["src_sha16"][src] = hashlib.sha256(open(os.path.join(root, src), "rb").read()).hexdigest()[:16]
         for key, kn in names.items():
             for tot, k, calls, rd, wr in rows:
