@@ -8,8 +8,8 @@
 #define KL_MAXBINS 1025   // HW+1 for G <= 32
 
 // (wave_lds_fence(), common.h: orders a wave's own LDS writes before its later reads of other lanes' values -- one wave per sample here)
-// One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane), so a step is
-// register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
+// One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane, held as PAIRS for
+// the packed fp32 pipe), so a step is register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
 // G = 32, where this kernel, not the decoder beside it, set the forward's length).
 template <int NBR>
 __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
@@ -39,25 +39,44 @@ __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, floa
     wave_lds_fence();
     float count = 0.f;
     float znext = zs[0];
+    // The loop is a chain of ~140 dependent single-wave instructions per cell.  The bins run as PAIRS on the packed fp32 pipe (v_pk_add /
+    // v_pk_mul / v_pk_fma_f32: two bins per instruction; the clamp is one v_med3_f32 per bin, the on/off select a wave-uniform fma):
+    // same operations per bin as the scalar form, the two partial sums associate pairwise (configs[3]: 0.56 -> 0.43 ms)
+    typedef float kl_f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = (NBR + 1) / 2;
+    kl_f2 c2[NP], e2[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        c2[k] = kl_f2{c[2 * k], 2 * k + 1 < NBR ? c[2 * k + 1] : 0.f};
+        e2[k] = kl_f2{ef[2 * k], 2 * k + 1 < NBR ? ef[2 * k + 1] : 0.f};
+    }
     for (int i = 0; i < HW; ++i) {
         const float z = znext;
         znext = zs[min(i + 1, HW - 1)];
         const float rem = (float)(HW - i), inv_rem = 1.f / rem;      // one IEEE division per step; x * (1/r) is within 1 ulp of x / r
         const bool on = rintf(z) != 0.f;   // torch.round: half to even
-        float pz = 0.f, np = 0.f;
+        const kl_f2 cnt2 = {count, count}, ir2 = {inv_rem, inv_rem};
+        // the factor of c: q where the cell is on, 1 - q where it is off = sa * q + sb with wave-uniform (sa, sb) -- exact either way
+        const float sa = on ? 1.f : -1.f, sb = on ? 0.f : 1.f;
+        kl_f2 pz2 = {0.f, 0.f}, np2 = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < NBR; ++k) {
-            const float q = fminf(fmaxf(ef[k] - count, 0.f), rem) * inv_rem;
-            pz += c[k] * q;
-            const float v = (on ? q : 1.f - q) * c[k];
-            c[k] = v;
-            np += v;
+        for (int k = 0; k < NP; ++k) {
+            kl_f2 d = e2[k] - cnt2;
+            d.x = __builtin_amdgcn_fmed3f(d.x, 0.f, rem);        // clamp(d, 0, rem) in one instruction
+            d.y = __builtin_amdgcn_fmed3f(d.y, 0.f, rem);
+            const kl_f2 q = d * ir2;
+            pz2 += c2[k] * q;
+            const kl_f2 sel = {__builtin_fmaf(sa, q.x, sb), __builtin_fmaf(sa, q.y, sb)};
+            const kl_f2 v = sel * c2[k];
+            c2[k] = v;
+            np2 += v;
         }
-        pz = wave_reduce_sum(pz);
-        np = fmaxf(wave_reduce_sum(np), 1e-6f);
+        const float pz = wave_reduce_sum(pz2.x + pz2.y);
+        const float np = fmaxf(wave_reduce_sum(np2.x + np2.y), 1e-6f);
         const float inv_np = 1.f / np;
+        const kl_f2 in2 = {inv_np, inv_np};
 #pragma unroll
-        for (int k = 0; k < NBR; ++k) c[k] = c[k] * inv_np;
+        for (int k = 0; k < NP; ++k) c2[k] = c2[k] * in2;
         if (lane == 0) pzs[i] = pz;
         count += on ? 1.f : 0.f;
     }
