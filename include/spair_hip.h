@@ -236,8 +236,8 @@ int spair_render_bwd16(const void* sprites_f16, int ld_s, const float* nbox, con
 /* The forward renderer of the bf16 step on the matrix cores (csrc/render3.hip; same reference lines: stn(inverse=True) modules.py:256-269 +
  * the composite models.py:511-540).  The inverse-STN sampling is separable, out_c = Wy . S_c . Wx^T with hat weights, and runs as three
  * v_mfma_f32_16x16x32_f16 per channel and (object, 16 x 16 tile) on the fp16 sprites as they lie in memory.
- * spair_render_prep writes 48 bytes of records per object (source-coordinate coefficients, presence, importance scale / floor, pixel footprint;
- * sample-major, 48 * B * HW bytes, 16-byte aligned, caller-owned) from the rows r = k * B + b of nbox [N][4] / pres [N] / depth [N];
+ * spair_render_prep writes 64 bytes of records per object (source-coordinate coefficients, presence, importance scale / floor, pixel footprint,
+ * raw inverse-affine parameters; sample-major, 64 * B * HW bytes, 16-byte aligned, caller-owned) from the rows r = k * B + b of nbox [N][4] / pres [N] / depth [N];
  * spair_render_fwd16m composites from the records: same outputs as spair_render_fwd16 (recon, aux, bce_partial), per pixel within 5e-4 of
  * it (fp16 hat weights on source coordinates rounded to 2^-11 texel, one fp16 rounding of the x-interpolated rows), unbiased.
  * SPAIR_ERR_UNSUPPORTED for P != 28, align_corners, HW > 1024: use spair_render_fwd16. */
@@ -245,6 +245,11 @@ int spair_render_prep(const float* nbox, const float* pres, const float* depth, 
                       int align_corners, void* stream);
 int spair_render_fwd16m(const void* sprites_f16, int ld_s, const void* records, const float* x, float* recon, float* aux,
                         float* bce_partial, int B, int HW, int C, int I, int P, int align_corners, void* stream);
+/* spair_render_bwd16 with the inverse-affine parameters and pixel footprints read from the records of spair_render_prep (the same nbox /
+ * pres / depth) instead of recomputed per object: what the training step runs; identical outputs */
+int spair_render_bwd16r(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth, const void* records,
+                        const float* aux, const float* grad_loss, void* dlogits_bf16, float* dnbox, float* dpres, float* ddepth,
+                        int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

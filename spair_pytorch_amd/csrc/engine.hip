@@ -23,7 +23,8 @@ int render_num_blocks(int B, int I);
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s);
 int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac, hipStream_t s);
 int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, hipStream_t s);
-int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s);
+int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, const void* rec, hipStream_t s);
+int render_prep_supported(int HW, int I, int P, int ac);
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
@@ -252,7 +253,7 @@ static Ws carve(const SpairDims& d, void* base) {
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
-    w.rrec = c.take_bytes((size_t)N * 48);                  // the renderer's per-object records (render3.hip)
+    w.rrec = c.take_bytes((size_t)N * 64);                  // the renderer's per-object records (render3.hip)
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
     w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);
@@ -982,20 +983,20 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     prof_end(ps_bb, c.s);
     if (side && hipStreamWaitEvent(c.s, side->ev[4], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;      // tables, per-cell and decoder weights
     { ProfScope ps(PS_CELLS_FWD, c.s); TRY(cells_fwd(c)); }
-    // the KL terms and the renderer's per-object records only need the cell chain's outputs: they run on the helper stream beside the
-    // decoder (and the KL terms beside the renderer)
+    // the KL terms only need the cell chain's outputs: they run on the helper stream beside the decoder and the renderer.  (The count-prior
+    // KL is one dependent chain per sample, ~0.17 ms beside the decoder at configs[1] and as long as decoder + renderer together: nothing
+    // may sit in front of it on the helper stream -- the renderer's record kernel, 6 us, runs on the caller's stream instead.)
     int rc_prep = SPAIR_ERR_UNSUPPORTED;
     {
         hipStream_t ks = side ? side->s : c.s;
         if (side) TRY(stream_link(c.s, ks, side->ev[0]));
-        if (d->dtype == SPAIR_BF16 && d->C == 1) {
-            rc_prep = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, ks);
-            if (rc_prep != SPAIR_OK && rc_prep != SPAIR_ERR_UNSUPPORTED) return rc_prep;
-            if (side && hipEventRecord(side->ev[2], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;      // (ev[2..4] were consumed before the cell chain)
-        }
         { ProfScope ps(PS_COUNT_KL, ks); TRY(loss_count_kl(L, P, st->count_prior_prob, c.w.klp, ks)); }
         TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, ks));
         if (side && hipEventRecord(side->ev[1], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    }
+    if (d->dtype == SPAIR_BF16 && d->C == 1) {
+        rc_prep = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, c.s);
+        if (rc_prep != SPAIR_OK && rc_prep != SPAIR_ERR_UNSUPPORTED) return rc_prep;
     }
     // decoder (models.py:474-492)
     const ParamLayout& PL = c.PL;
@@ -1039,7 +1040,6 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         // bf16 step: the sampling on the matrix cores from per-object records (render3.hip); every other case on the tap kernels
         int rc = SPAIR_ERR_UNSUPPORTED;
         if (rc_prep == SPAIR_OK) {
-            if (side && hipStreamWaitEvent(c.s, side->ev[2], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
             rc = render_fwd_mma(c.w.S, c.w.ld_s, c.w.rrec, x, recon, st->train ? c.w.aux : nullptr, c.w.bce_partial, d->B, L.HW, d->I,
                                 d->P, d->align_corners, c.s);
         }
@@ -1203,7 +1203,8 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         ProfScope ps(PS_RENDER_BWD, c.s);
         TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
-                       d->alpha_logit_scale, b16, b16, c.s));
+                       d->alpha_logit_scale, b16, b16,
+                       b16 && d->C == 1 && render_prep_supported(L.HW, d->I, d->P, d->align_corners) ? c.w.rrec : nullptr, c.s));
     }
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));

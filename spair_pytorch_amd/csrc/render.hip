@@ -435,7 +435,7 @@ int render_fwd2(const float* S, int ld_s, const float* nbox, const float* pres, 
                 float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, int s_bf16, hipStream_t s);
 int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                 const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
-                int ac, float obj_scale, float alpha_scale, hipStream_t s);
+                int ac, float obj_scale, float alpha_scale, const void* rec, hipStream_t s);
 int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac,
                 hipStream_t s);
 int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW,
@@ -461,12 +461,13 @@ int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, c
 
 int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I,
-               int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, hipStream_t s) {
+               int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, const void* rec, hipStream_t s) {
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if ((ld_s & 1) || (ld_g & 1)) return SPAIR_ERR_ALIGN;
     if (g_bf16 && s_bf16) {   // the bf16 step: one wave per object, sampling transposed on the matrix cores
+        // rec (optional): the per-object records the forward's k_render_prep left in the workspace
         const int rc = render_bwd2(S, ld_s, nbox, pres, depth, ld_pd, aux, gloss, dlogits, dnbox, dpres, ddepth, ld_g, B, HW, I, P, ac,
-                                   obj_scale, alpha_scale, s);
+                                   obj_scale, alpha_scale, rec, s);
         if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
     }
     if (I > RB_CAP || (long long)I * I > 0x7fffffffLL / 4 || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
@@ -495,7 +496,7 @@ extern "C" int spair_render_bwd(const float* sprites, int ld_s, const float* nbo
                                 float* ddepth, int B, int HW, int C, int I, int P, int align_corners, float obj_scale,
                                 float alpha_scale, void* stream) {
     return render_bwd(sprites, ld_s, nbox, pres, depth, 1, aux, grad_loss, dlogits, dnbox, dpres, ddepth, ld_s, B, HW, C, I, P,
-                      align_corners, obj_scale, alpha_scale, 0, 0, (hipStream_t)stream);
+                      align_corners, obj_scale, alpha_scale, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 // 16-bit sprite variants (what the bf16 training step runs): sprites are fp16 (grey, alpha) pairs [N][ld_s] (ld_s in elements), the
@@ -512,7 +513,7 @@ extern "C" int spair_render_bwd16(const void* sprites_f16, int ld_s, const float
                                   float alpha_scale, void* stream) {
     return render_bwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, aux, grad_loss,
                       reinterpret_cast<float*>(dlogits_bf16), dnbox, dpres, ddepth, ld_s, B, HW, C, I, P, align_corners, obj_scale,
-                      alpha_scale, 1, 1, (hipStream_t)stream);
+                      alpha_scale, 1, 1, nullptr, (hipStream_t)stream);
 }
 // The matrix-core forward renderer of the bf16 step (render3.hip): spair_render_prep writes the per-object records (32 bytes each,
 // B * HW of them, caller-owned), spair_render_fwd16m composites from them.  SPAIR_ERR_UNSUPPORTED (P != 28, align_corners, HW > 1024):
@@ -527,4 +528,14 @@ extern "C" int spair_render_fwd16m(const void* sprites_f16, int ld_s, const void
     if (C != 1) return SPAIR_ERR_UNSUPPORTED;
     if (B <= 0 || HW <= 0 || I <= 0) return SPAIR_ERR_SHAPE;
     return render_fwd_mma(sprites_f16, ld_s, records, x, recon, aux, bce_partial, B, HW, I, P, align_corners, (hipStream_t)stream);
+}
+// spair_render_bwd16 reading the inverse-affine parameters and footprints from the records spair_render_prep wrote for the same nbox /
+// pres / depth (what the training step does); same outputs.
+extern "C" int spair_render_bwd16r(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth,
+                                   const void* records, const float* aux, const float* grad_loss, void* dlogits_bf16, float* dnbox,
+                                   float* dpres, float* ddepth, int B, int HW, int C, int I, int P, int align_corners, float obj_scale,
+                                   float alpha_scale, void* stream) {
+    return render_bwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, aux, grad_loss,
+                      reinterpret_cast<float*>(dlogits_bf16), dnbox, dpres, ddepth, ld_s, B, HW, C, I, P, align_corners, obj_scale,
+                      alpha_scale, 1, 1, records, (hipStream_t)stream);
 }

@@ -19,6 +19,10 @@
 #include <stdlib.h>
 #include "render_common.h"
 
+int render_prep_supported(int HW, int I, int P, int ac);                        // render3.hip
+const void* render_rec_cull(const void* rec, int B, int HW);
+const void* render_rec_bwd(const void* rec, int B, int HW);
+
 #define RF_TC 32          // objects per tile pass (<= 64: the per-strip cull is one ballot)
 
 struct RfCand {
@@ -357,13 +361,16 @@ __device__ __forceinline__ Rb2Taps rb2_ld_taps(const char* tp, int rowb) {
     return t;
 }
 
-template <int PT, int AC, int IP2>
+// REC: the inverse-affine parameters and the pixel footprint come from the forward's per-object records (render3.hip: k_render_prep wrote
+// them with the very expressions below) instead of four IEEE divisions and two footprint searches per object
+template <int PT, int AC, int IP2, bool REC>
 __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const float* __restrict__ S, int ld_s, const float* __restrict__ nbox,
                                                     const float* __restrict__ pres, const float* __restrict__ depth, int ld_pd,
                                                     const float2* __restrict__ aux, const float* __restrict__ gloss,
                                                     __bf16* __restrict__ dlogits, float* __restrict__ dnbox, float* __restrict__ dpres,
                                                     float* __restrict__ ddepth, int ld_g, int B, int HW, int I, int Prt,
-                                                    float obj_scale, float alpha_scale) {
+                                                    float obj_scale, float alpha_scale, const uint4* __restrict__ crec,
+                                                    const float4* __restrict__ brec) {
     extern __shared__ __attribute__((aligned(16))) char smb[];
     const int P = PT ? PT : Prt;
     const int PS = P + 2;
@@ -387,17 +394,25 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
     const float pr = pres[(size_t)r * ld_pd], dp = depth[(size_t)r * ld_pd], pd = pr * dp;
     const float gl = *gloss;
     const float2* auxb = aux + (size_t)b * I * I;
-    const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
-    const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
-    const float ax = 1.f / nb.z, bx = -tx / nb.z, ay = 1.f / nb.w, by = -ty / nb.w;
-    const float mult = AC ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
-    float sx0, sxa, sy0, sya;
-    src_affine(ax, bx, I, P, AC, sx0, sxa);
-    src_affine(ay, by, I, P, AC, sy0, sya);
+    float ax, bx, ay, by;
     int PX0, PX1, PY0, PY1;
     const float inv_I = 1.f / (float)I;
-    rb2_range<AC, IP2>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, inv_I, P, PX0, PX1);
-    rb2_range<AC, IP2>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, inv_I, P, PY0, PY1);
+    const float mult = AC ? 0.5f * (float)(P - 1) : 0.5f * (float)P;
+    if constexpr (REC) {
+        const float4 pb = brec[(size_t)b * HW + k];
+        const uint4 pc = crec[(size_t)b * HW + k];
+        ax = pb.x; bx = pb.y; ay = pb.z; by = pb.w;
+        PX0 = pc.z & 0xffff; PX1 = pc.z >> 16; PY0 = pc.w & 0xffff; PY1 = pc.w >> 16;     // an empty footprint has first > last
+    } else {
+        const float4 nb = *reinterpret_cast<const float4*>(nbox + (size_t)r * 4);
+        const float tx = 2.f * nb.x - 1.f, ty = 2.f * nb.y - 1.f;
+        ax = 1.f / nb.z; bx = -tx / nb.z; ay = 1.f / nb.w; by = -ty / nb.w;
+        float sx0, sxa, sy0, sya;
+        src_affine(ax, bx, I, P, AC, sx0, sxa);
+        src_affine(ay, by, I, P, AC, sy0, sya);
+        rb2_range<AC, IP2>(ax, bx, sx0, __builtin_amdgcn_rcpf(sxa), I, inv_I, P, PX0, PX1);
+        rb2_range<AC, IP2>(ay, by, sy0, __builtin_amdgcn_rcpf(sya), I, inv_I, P, PY0, PY1);
+    }
     PX0 = __builtin_amdgcn_readfirstlane(PX0); PX1 = __builtin_amdgcn_readfirstlane(PX1);
     PY0 = __builtin_amdgcn_readfirstlane(PY0); PY1 = __builtin_amdgcn_readfirstlane(PY1);
     // ---- sprite -> LDS (zero border), adjoint tiles zeroed once (later chunks leave finite values under zero weights)
@@ -607,20 +622,23 @@ __global__ __launch_bounds__(64, RB2_WAVES_PER_SIMD) void k_render_bwd2(const fl
 // bf16 sprites in, bf16 d-logits out.  SPAIR_ERR_UNSUPPORTED: the caller falls back to the first-generation kernel.
 int render_bwd2(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
                 const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P,
-                int ac, float obj_scale, float alpha_scale, hipStream_t s) {
+                int ac, float obj_scale, float alpha_scale, const void* rec, hipStream_t s) {
     if ((P & 3) || P > 32 || P < 4 || (ld_s & 7) || (ld_g & 7) || HW > 65535) return SPAIR_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15)) return SPAIR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)rb2_lds_bytes(P);
     if (lds > 64 * 1024 || (size_t)P * P * 4 > RB2_ADJ_BYTES) return SPAIR_ERR_UNSUPPORTED;
     const dim3 grid(B, HW), block(64);
-#define RB2_LAUNCH(PT_, AC_, IP2_)                                                                                                        \
-    hipLaunchKernelGGL((k_render_bwd2<PT_, AC_, IP2_>), grid, block, lds, s, S, ld_s, nbox, pres, depth, ld_pd,                            \
+    const bool use_rec = rec && render_prep_supported(HW, I, P, ac);
+    const uint4* crec = use_rec ? reinterpret_cast<const uint4*>(render_rec_cull(rec, B, HW)) : nullptr;
+    const float4* brec = use_rec ? reinterpret_cast<const float4*>(render_rec_bwd(rec, B, HW)) : nullptr;
+#define RB2_LAUNCH(PT_, AC_, IP2_, REC_)                                                                                                  \
+    hipLaunchKernelGGL((k_render_bwd2<PT_, AC_, IP2_, REC_>), grid, block, lds, s, S, ld_s, nbox, pres, depth, ld_pd,                      \
                        reinterpret_cast<const float2*>(aux), gloss, reinterpret_cast<__bf16*>(dlogits), dnbox, dpres, ddepth, ld_g, B, HW, I, \
-                       P, obj_scale, alpha_scale)
+                       P, obj_scale, alpha_scale, crec, brec)
     const bool ip2 = (I & (I - 1)) == 0;
-    if (P == 28 && !ac && ip2) RB2_LAUNCH(28, 0, 1);
-    else if (ac) RB2_LAUNCH(0, 1, 0);
-    else RB2_LAUNCH(0, 0, 0);
+    if (P == 28 && !ac && ip2) { if (use_rec) RB2_LAUNCH(28, 0, 1, true); else RB2_LAUNCH(28, 0, 1, false); }
+    else if (ac) RB2_LAUNCH(0, 1, 0, false);
+    else { if (use_rec) RB2_LAUNCH(0, 0, 0, true); else RB2_LAUNCH(0, 0, 0, false); }
 #undef RB2_LAUNCH
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;

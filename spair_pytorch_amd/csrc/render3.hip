@@ -45,7 +45,7 @@ typedef unsigned short r3_u2 __attribute__((ext_vector_type(2)));
 #define R3_EMPTY 0x7fffu            // first index of an empty footprint
 #define R3_QMAGIC 6144.0f           // 1.5 * 2^12: (s + M) - M rounds s to a multiple of 2^-11 for |s| < 2^11
 
-// Per object, sample-major [b][k]: B * HW object records, then B * HW cull records.
+// Per object, sample-major [b][k]: B * HW object records, then B * HW cull records, then B * HW backward records.
 // Source coordinate of output index j on either axis: s = A * base(j) + Bc with A = a * P / 2, Bc = (b + 1) * P / 2 - 1 / 2 (the reference's
 // affine_grid + unnormalise sequence (g + 1) * P / 2 - 1 / 2, g = a * base + b, re-associated: <= 1e-5 texel from the sequence the backward
 // evaluates, far inside the 2^-12 texel of the rounding below).
@@ -59,12 +59,17 @@ struct __attribute__((aligned(16))) RenderCullRec {
     float Ay, By;                   // By = Bc (no rounding constant): the sprite-row window of a tile comes from floor(s)
     unsigned xr, yr;                // pixel footprint: first | last << 16 (first = R3_EMPTY: nothing to draw)
 };
-#define R3_REC_BYTES 48
+// the raw inverse-affine parameters (a_x, b_x, a_y, b_y), as the backward kernel forms them itself when it has no records
+struct __attribute__((aligned(16))) RenderBwdRec { float ax, bx, ay, by; };
+#define R3_REC_BYTES 64
+
+int render_prep_supported(int HW, int I, int P, int ac);
 
 template <int AC, int IP2>
 __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ nbox, const float* __restrict__ pres,
                                                      const float* __restrict__ depth, int ld_pd, RenderObjRec* __restrict__ orec,
-                                                     RenderCullRec* __restrict__ crec, int B, int HW, int I, int P) {
+                                                     RenderCullRec* __restrict__ crec, RenderBwdRec* __restrict__ brec, int B, int HW, int I,
+                                                     int P) {
     const int idx = blockIdx.x * 256 + threadIdx.x;          // = b * HW + k
     if (idx >= B * HW) return;
     const int b = idx / HW, k = idx - b * HW;
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ n
     c.yr = (unsigned)y0 | ((unsigned)y1 << 16);
     orec[idx] = o;
     crec[idx] = c;
+    brec[idx] = RenderBwdRec{ax, bx, ay, by};
 }
 
 // 8 hat weights max(0, 1 - |s - u_j|) of a coordinate that is a multiple of 2^-11, as an fp16 MFMA fragment.  c[jp] = -(u_2jp, u_2jp+1)
@@ -366,18 +372,25 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
 }
 
 int render_prep_bytes(int B, int HW) { return B * HW * R3_REC_BYTES; }
+// what the backward kernel reads of the records (render2.hip): footprints and raw parameters
+const void* render_rec_cull(const void* rec, int B, int HW) { return reinterpret_cast<const RenderObjRec*>(rec) + (size_t)B * HW; }
+const void* render_rec_bwd(const void* rec, int B, int HW) {
+    return reinterpret_cast<const RenderCullRec*>(render_rec_cull(rec, B, HW)) + (size_t)B * HW;
+}
+int render_prep_supported(int HW, int I, int P, int ac) { return !ac && P == R3_P && HW <= R3_MAXHW && I < (int)R3_EMPTY; }
 
 // SPAIR_ERR_UNSUPPORTED: the caller keeps k_render_fwd3 (which needs no records)
 int render_prep(const float* nbox, const float* pres, const float* depth, int ld_pd, void* rec, int B, int HW, int I, int P, int ac,
                 hipStream_t s) {
-    if (ac || P != R3_P || HW > R3_MAXHW || I >= (int)R3_EMPTY || (reinterpret_cast<uintptr_t>(rec) & 15)) return SPAIR_ERR_UNSUPPORTED;
+    if (!render_prep_supported(HW, I, P, ac) || (reinterpret_cast<uintptr_t>(rec) & 15)) return SPAIR_ERR_UNSUPPORTED;
     const dim3 grid((B * HW + 255) / 256), block(256);
     RenderObjRec* orec = reinterpret_cast<RenderObjRec*>(rec);
     RenderCullRec* crec = reinterpret_cast<RenderCullRec*>(orec + (size_t)B * HW);
+    RenderBwdRec* brec = reinterpret_cast<RenderBwdRec*>(crec + (size_t)B * HW);
     if ((I & (I - 1)) == 0)
-        hipLaunchKernelGGL((k_render_prep<0, 1>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, B, HW, I, P);
+        hipLaunchKernelGGL((k_render_prep<0, 1>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, brec, B, HW, I, P);
     else
-        hipLaunchKernelGGL((k_render_prep<0, 0>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, B, HW, I, P);
+        hipLaunchKernelGGL((k_render_prep<0, 0>), grid, block, 0, s, nbox, pres, depth, ld_pd, orec, crec, brec, B, HW, I, P);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

@@ -29,6 +29,14 @@ def test_default_bench_line_has_every_sub_record():
     assert roof["kernel"].startswith("chain") and 0 < roof["l2_stream"]["frac"] < 1
     assert {"chain_fwd", "chain_bwd", "render_fwd", "render_bwd", "conv1_fwd", "decoder_fwd", "stn_fwd"} <= set(rec["kernels"])
     assert rec["kernels"]["stn_fwd"]["stage_ms"] > 0
-    assert [p["global_step"] for p in rec["sweep"]] == [0, 2000, 4000, 6000, 7000, 8000, 10000]
+    sw = rec["sweep"]
+    assert [p["global_step"] for p in sw if p["axis"] == "schedule"] == [0, 2000, 4000, 6000, 7000, 8000, 10000]
+    assert [p["max_objects"] for p in sw if p["axis"] == "objects"] == [1, 3, 6, 11]
+    dens = [p for p in sw if p["axis"] == "density"]
+    assert len(dens) == 9 and all(p["render_fwd_ms"] > 0 and p["render_bwd_ms"] > 0 and p["mean_box_side_px"] > 0 for p in sw)
+    # the density axis moves what it is named for: presence and object size
+    assert max(p["mean_z_pres"] for p in dens) > 3 * min(p["mean_z_pres"] for p in dens)
+    assert max(p["mean_box_side_px"] for p in dens) > 1.5 * min(p["mean_box_side_px"] for p in dens)
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= max(rec["ms_per_step_repeats"])
     c3 = rec["config3"]
     assert "configs[3]" in c3["workload"] and c3["ms_per_step"] > 0 and "stn_fwd" in c3["kernels"]

@@ -196,7 +196,7 @@ def test_render16m_fwd_vs_oracle(B, G, I, smin, srange):
             L.check(L.lib().spair_render_fwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
                                                B, HW, 1, I, P, 0, L.stream()), "render fwd16")
         else:
-            recs = torch.zeros(N * 12, device="cuda", dtype=torch.int32)
+            recs = torch.zeros(N * 16, device="cuda", dtype=torch.int32)
             L.check(L.lib().spair_render_prep(L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(recs), B, HW, I, P, 0, L.stream()), "render prep")
             L.check(L.lib().spair_render_fwd16m(L.ptr(Sd), ld, L.ptr(recs), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part),
                                                 B, HW, 1, I, P, 0, L.stream()), "render fwd16m")
@@ -216,6 +216,49 @@ def test_render16m_fwd_vs_oracle(B, G, I, smin, srange):
     assert (aux_m[..., 1] - aux_t[..., 1]).abs().max() < 1.5e-3         # pre (unclamped)
     d0 = (aux_m[..., 0] - aux_t[..., 0]).abs()                         # dBCE/dpre / D
     assert (d0 <= 1e-2 * aux_t[..., 0].abs() + 1e-3 * aux_t[..., 0].abs().max()).all()
+
+
+@pytest.mark.parametrize("B,G,I,smin,srange", [(8, 4, 64, 0.08, 0.5), (4, 8, 128, 0.12, 0.12), (3, 5, 72, 0.05, 0.6)])
+def test_render16_bwd_from_records_equals_plain(B, G, I, smin, srange):
+    """spair_render_bwd16r (inverse-affine parameters and pixel footprints read from the records of spair_render_prep: what the training
+    step runs) against spair_render_bwd16 (recomputed per object): the records hold the same expressions' results, so every output is
+    bit-equal -- including objects that are off-screen or degenerate (empty footprint: all gradients zero)."""
+    L = _L()
+    P, HW = 28, G * G
+    N = B * HW
+    g = torch.Generator().manual_seed(B + G + I + 3)
+    Sd = torch.sigmoid(torch.randn(N, P * P * 2, generator=g)).half().contiguous().cuda()
+    nbox = torch.stack([torch.rand(N, generator=g) * 1.2 - 0.1, torch.rand(N, generator=g) * 1.2 - 0.1,
+                        torch.rand(N, generator=g) * srange + smin, torch.rand(N, generator=g) * srange + smin], 1)
+    nbox[0] = torch.tensor([5.0, 5.0, 0.2, 0.2]); nbox[1] = torch.tensor([-0.2, 0.98, 0.5, 0.5])
+    pres, depth = torch.rand(N, generator=g), torch.rand(N, generator=g) * 4
+    x = (torch.rand(B, 1, I, I, generator=g) > 0.7).float() * torch.rand(B, 1, I, I, generator=g)
+    nb, pr, dp, xd = nbox.cuda(), pres.cuda(), depth.cuda(), x.cuda()
+    ld = P * P * 2
+    recon = torch.zeros(B, 1, I, I, device="cuda")
+    aux = torch.zeros(B, I, I, 2, device="cuda")
+    part = torch.zeros(B * ((I + 15) // 16) ** 2, device="cuda")
+    recs = torch.zeros(N * 16, device="cuda", dtype=torch.int32)
+    L.check(L.lib().spair_render_prep(L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(recs), B, HW, I, P, 0, L.stream()), "render prep")
+    L.check(L.lib().spair_render_fwd16m(L.ptr(Sd), ld, L.ptr(recs), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part), B, HW, 1, I, P, 0,
+                                        L.stream()), "render fwd16m")
+    gl = torch.ones((), device="cuda")
+    out = []
+    for with_rec in (False, True):
+        dlog = torch.zeros(N, ld, device="cuda", dtype=torch.bfloat16)
+        dnb, dpr, ddp = torch.zeros(N, 4, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        if with_rec:
+            L.check(L.lib().spair_render_bwd16r(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(recs), L.ptr(aux), L.ptr(gl), L.ptr(dlog),
+                                                L.ptr(dnb), L.ptr(dpr), L.ptr(ddp), B, HW, 1, I, P, 0, ctypes_f(2.0), ctypes_f(0.1), L.stream()), "bwd16r")
+        else:
+            L.check(L.lib().spair_render_bwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(aux), L.ptr(gl), L.ptr(dlog),
+                                               L.ptr(dnb), L.ptr(dpr), L.ptr(ddp), B, HW, 1, I, P, 0, ctypes_f(2.0), ctypes_f(0.1), L.stream()), "bwd16")
+        torch.cuda.synchronize()
+        out.append((dlog.float().cpu(), dnb.cpu(), dpr.cpu(), ddp.cpu()))
+    for a, b in zip(out[0], out[1]):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
+    assert out[1][0].abs().max() > 0 and (out[1][1][0] == 0).all()     # the off-screen object: no gradient
 
 
 @pytest.mark.parametrize("B,I,pre,post", [(3, 128, 7, 7), (2, 48, 3, 5), (1, 32, 0, 2)])

@@ -26,7 +26,7 @@ for name in ("taps", "mma"):
     if name == "taps":
         L.check(L.lib().spair_render_fwd16(L.ptr(Sd), ld, L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part), B, HW, 1, I, P, 0, L.stream()), "t")
     else:
-        recs = torch.zeros(N * 12, device="cuda", dtype=torch.int32)
+        recs = torch.zeros(N * 16, device="cuda", dtype=torch.int32)
         L.check(L.lib().spair_render_prep(L.ptr(nb), L.ptr(pr), L.ptr(dp), L.ptr(recs), B, HW, I, P, 0, L.stream()), "p")
         L.check(L.lib().spair_render_fwd16m(L.ptr(Sd), ld, L.ptr(recs), L.ptr(xd), L.ptr(recon), L.ptr(aux), L.ptr(part), B, HW, 1, I, P, 0, L.stream()), "m")
         torch.cuda.synchronize()
