@@ -16,54 +16,22 @@
 //   * the accumulator of the first product IS the B operand of the second up to the fp16 conversion: lane (px, q) holds rows 4q..4q+3
 //     of both 16-row tiles, and K is only a summation index, so the second product simply enumerates the sprite rows in that order
 //     (the hat weights Wy are built in the same order);
-//   * the hat weights are exact in fp16: the source coordinate is rounded to a multiple of 2^-11 texel, so 1 - f and f have 11
-//     significant bits and the pair still sums to exactly 1;
+//   * the hat weights are formed in fp32 and rounded to fp16 once (render3.h): the small weight of a tap pair keeps 11 significant
+//     bits, the pair sums to 1 +- 2^-12;
 //   * per-object parameters come from two per-object records written once per step by k_render_prep (48 bytes together): the cull
 //     record (pixel footprint + the row coefficients: the tile cull is four integer compares) and the object record (source-coordinate
-//     coefficients with the rounding constant folded in, presence, importance scale and floor); a wave keeps the records of its
+//     coefficients, presence, importance scale and floor); a wave keeps the records of its
 //     objects one per lane and broadcasts a field with v_readlane;
 //   * importance max(alpha * pd, 0.01) = pd * max(alpha, 0.01 / pd): one v_pk_max_f16 per two texels, pd applied to the sampled tile
 //     in fp32 (pd <= 0.01: the importance is the constant 0.01 = 0.01 * max(alpha, 1)).
 // Work split: one workgroup (4 waves) per (sample, 16 x 16 tile); the tile's surviving objects are dealt round-robin to the waves, each
 // wave composites whole objects into its own (num, den) tile in registers, and the four partial tiles meet in LDS at the end.
 //
-// Numerics (fp16 sprites in both kernels, so this is about the sampling only): the coordinate rounding moves a sample by <= 2^-12 texel,
-// T is rounded to fp16 once (RNE, 2^-12 relative), the importance floor 0.01 / pd is an fp16 number; the products are exact and accumulate
+// Numerics (fp16 sprites in both kernels, so this is about the sampling only): hat weights and the x-interpolated rows T are rounded to
+// fp16 once each (nearest even, 2^-12 relative), the importance floor 0.01 / pd is an fp16 number; the products are exact and accumulate
 // in fp32.  Measured against the oracle on the same fp16 sprites: tests/test_kernels_gpu.py::test_render16m_fwd_vs_oracle.
 #include <stdlib.h>
-#include "render_common.h"
-
-typedef _Float16 r3_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 r3_h2 __attribute__((ext_vector_type(2)));
-typedef float r3_f2 __attribute__((ext_vector_type(2)));
-typedef unsigned short r3_u2 __attribute__((ext_vector_type(2)));
-
-#define R3_P 28                     // sprite side this kernel is built for (row = 112 B = 7 x 16 B)
-#define R3_ROWB (R3_P * 4)
-#define R3_SPRB (R3_P * R3_P * 4)
-#define R3_MAXHW 1024               // objects per sample (list capacity: HW / 4 entries per culling wave)
-#define R3_EMPTY 0x7fffu            // first index of an empty footprint
-#define R3_QMAGIC 6144.0f           // 1.5 * 2^12: (s + M) - M rounds s to a multiple of 2^-11 for |s| < 2^11
-
-// Per object, sample-major [b][k]: B * HW object records, then B * HW cull records, then B * HW backward records.
-// Source coordinate of output index j on either axis: s = A * base(j) + Bc with A = a * P / 2, Bc = (b + 1) * P / 2 - 1 / 2 (the reference's
-// affine_grid + unnormalise sequence (g + 1) * P / 2 - 1 / 2, g = a * base + b, re-associated: <= 1e-5 texel from the sequence the backward
-// evaluates, far inside the 2^-12 texel of the rounding below).
-struct __attribute__((aligned(16))) RenderObjRec {
-    float Ax, BxM, Ay, ByM;         // BxM = Bc + R3_QMAGIC: fma(A, base, BxM) - R3_QMAGIC is s rounded to a multiple of 2^-11
-    float pres, mscale;             // importance = mscale * max(alpha, mfloor)
-    unsigned mfloor;                // fp16 pair
-    unsigned pad;
-};
-struct __attribute__((aligned(16))) RenderCullRec {
-    float Ay, By;                   // By = Bc (no rounding constant): the sprite-row window of a tile comes from floor(s)
-    unsigned xr, yr;                // pixel footprint: first | last << 16 (first = R3_EMPTY: nothing to draw)
-};
-// the raw inverse-affine parameters (a_x, b_x, a_y, b_y), as the backward kernel forms them itself when it has no records
-struct __attribute__((aligned(16))) RenderBwdRec { float ax, bx, ay, by; };
-#define R3_REC_BYTES 64
-
-int render_prep_supported(int HW, int I, int P, int ac);
+#include "render3.h"
 
 template <int AC, int IP2>
 __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ nbox, const float* __restrict__ pres,
@@ -98,7 +66,7 @@ __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ n
     RenderObjRec o;
     o.Ax = ax * hp; o.Ay = ay * hp;
     const float bcx = fmaf(bx + 1.f, hp, -0.5f), bcy = fmaf(by + 1.f, hp, -0.5f);
-    o.BxM = bcx + R3_QMAGIC; o.ByM = bcy + R3_QMAGIC;
+    o.Bx = bcx; o.By = bcy;
     o.pres = pr;
     // max(alpha * pd, 0.01) = mscale * max(alpha, mfloor)
     const bool flat = !(pd > 0.01f);                          // alpha <= 1: the importance is 0.01 everywhere on the sprite
@@ -106,9 +74,9 @@ __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ n
     const _Float16 fl = flat ? (_Float16)1.f : (_Float16)fmaxf(0.01f / pd, 6.2e-5f);
     const r3_h2 fl2 = {fl, fl};
     o.mfloor = __builtin_bit_cast(unsigned, fl2);
-    o.pad = 0;
+    o.depth = depth[(size_t)r * ld_pd];
     RenderCullRec c;
-    c.Ay = o.Ay; c.By = bcy;
+    c.Ay = o.Ay; c.By = o.By;
     c.xr = (unsigned)x0 | ((unsigned)x1 << 16);
     c.yr = (unsigned)y0 | ((unsigned)y1 << 16);
     orec[idx] = o;
@@ -116,57 +84,9 @@ __global__ __launch_bounds__(256) void k_render_prep(const float* __restrict__ n
     brec[idx] = RenderBwdRec{ax, bx, ay, by};
 }
 
-// 8 hat weights max(0, 1 - |s - u_j|) of a coordinate that is a multiple of 2^-11, as an fp16 MFMA fragment.  c[jp] = -(u_2jp, u_2jp+1)
-// (a slot that must stay empty carries a large value).  d = s - u is exact in fp32 and, where |d| < 1, in fp16; 1 - |d| likewise.
-__device__ __forceinline__ r3_h8 r3_hat8(float s, const r3_f2 (&c)[4]) {
-    const r3_h2 one = {(_Float16)1.f, (_Float16)1.f}, zero = {(_Float16)0.f, (_Float16)0.f};
-    const r3_f2 s2 = {s, s};
-    r3_h2 w[4];
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-        const r3_f2 d = s2 + c[jp];
-        // three instructions per pair: v_pk_add_f32, v_cvt_pkrtz_f16_f32 |d|, v_pk_add_f16 ... clamp
-        const r3_h2 ad = __builtin_bit_cast(r3_h2, __builtin_amdgcn_cvt_pkrtz(__builtin_fabsf(d.x), __builtin_fabsf(d.y)));
-        w[jp] = __builtin_elementwise_min(__builtin_elementwise_max(one - ad, zero), one);
-    }
-    return r3_h8{w[0].x, w[0].y, w[1].x, w[1].y, w[2].x, w[2].y, w[3].x, w[3].y};
-}
-
-struct R3Frag { u32x4_t lo, hi; };      // 8 texels (grey, alpha) of one sprite row
-
-// fl: the importance floor as an fp16 pair -- 0 for a sprite row beyond the sprite, whose texels read as zeros: the PADDING's importance
-// is 0, not the floor (the reference clamps the importance sprite, then grid_sample pads it with zeros)
-__device__ __forceinline__ void r3_split(const R3Frag& f, unsigned fl, r3_h8& g, r3_h8& a, r3_h8& m) {
-    const unsigned d[8] = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
-    const r3_u2 floor2 = __builtin_bit_cast(r3_u2, fl);
-    unsigned gg[4], aa[4], mm[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        gg[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
-        aa[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
-        // importance / mscale, models.py:497-499: max(alpha, floor) on the BIT patterns (both >= 0: fp16 order = unsigned order; the
-        // float form costs a second v_pk_max_f16 per pair, the compiler's canonicalisation of a loaded value)
-        mm[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(r3_u2, aa[i]), floor2));
-    }
-    g = __builtin_bit_cast(r3_h8, u32x4_t{gg[0], gg[1], gg[2], gg[3]});
-    a = __builtin_bit_cast(r3_h8, u32x4_t{aa[0], aa[1], aa[2], aa[3]});
-    m = __builtin_bit_cast(r3_h8, u32x4_t{mm[0], mm[1], mm[2], mm[3]});
-}
-
-__device__ __forceinline__ unsigned r3_pk(float a, float b) {
-    const r3_h2 h = {(_Float16)a, (_Float16)b};            // v_cvt_pk_f16_f32: round to nearest even
-    return __builtin_bit_cast(unsigned, h);
-}
-
-// 1 / d: v_rcp_f32 + one Newton step (<= 1 ulp for normal d; the IEEE division sequence is ~10 instructions)
-__device__ __forceinline__ float r3_rcp(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, r, 1.f), r, r);
-}
-
 struct R3Obj {                      // everything of one (object, tile) pair that is in flight before its arithmetic
     R3Frag t0, t1;
-    float Ax, BxM, Ay, ByM, pres, mscale;       // the object record (wave-uniform)
+    float Ax, Bx, Ay, By, pres, mscale;         // the object record (wave-uniform)
     unsigned mfloor;
     unsigned e;                     // list entry: k | v0 << 16 | two << 24
 };
@@ -219,9 +139,9 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
             const int x0 = rc.z & 0xffff, x1 = rc.z >> 16, y0 = rc.w & 0xffff, y1 = rc.w >> 16;
             hit = x0 <= tx1 && x1 >= tx0 && y0 <= ty1 && y1 >= ty0;
             const float ay = __uint_as_float(rc.x), by = __uint_as_float(rc.y);
+            // the coordinates of the first / last pixel row that can draw: their taps are floor and floor + 1
             const float s0 = fmaf(ay, rf_base<0, IP2>(max(ty0, y0), I, inv_I), by);
             const float s1 = fmaf(ay, rf_base<0, IP2>(min(ty1, y1), I, inv_I), by);
-            // (the rounding to 2^-11 can only move a coordinate ONTO the next integer, never past it: the taps stay inside [floor, floor + 1])
             const int v0 = min(max((int)floorf(s0), 0), P - 16), v1 = max(min((int)floorf(s1) + 1, P - 1), v0);
             unsigned ym = 0;
 #pragma unroll
@@ -278,8 +198,8 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
             R3Obj o;
             const int jj = min(j, n - 1);
             o.e = rl(mine, jj);
-            o.Ax = __uint_as_float(rl(myra.x, jj)); o.BxM = __uint_as_float(rl(myra.y, jj));
-            o.Ay = __uint_as_float(rl(myra.z, jj)); o.ByM = __uint_as_float(rl(myra.w, jj));
+            o.Ax = __uint_as_float(rl(myra.x, jj)); o.Bx = __uint_as_float(rl(myra.y, jj));
+            o.Ay = __uint_as_float(rl(myra.z, jj)); o.By = __uint_as_float(rl(myra.w, jj));
             o.pres = __uint_as_float(rl(myrb.x, jj)); o.mscale = __uint_as_float(rl(myrb.y, jj));
             o.mfloor = rl(myrb.z, jj);
             const int k = o.e & 0xffff;
@@ -296,7 +216,7 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
         };
         auto composite = [&](const R3Obj& o) {
             const unsigned v0 = (o.e >> 16) & 0xff;
-            const float sx = fmaf(o.Ax, basex, o.BxM) - R3_QMAGIC;                       // multiples of 2^-11 texel
+            const float sx = fmaf(o.Ax, basex, o.Bx);
             const r3_h8 wx = r3_hat8(sx, cx);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             r3_h8 sg, sa, sm;
@@ -316,11 +236,11 @@ __global__ __launch_bounds__(256) void k_render_fwd_mma(const void* __restrict__
                 ha[2] = r3_pk(ta1[0], ta1[1]); ha[3] = r3_pk(ta1[2], ta1[3]);
                 hm[2] = r3_pk(tm1[0], tm1[1]); hm[3] = r3_pk(tm1[2], tm1[3]);
             }
-            const float yoff = R3_QMAGIC + (float)v0;
+            const float yoff = (float)v0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (NT == 1 || ((o.e >> (25 + t)) & 1u)) {
-                    const float sy = fmaf(o.Ay, basey[t], o.ByM) - yoff;                 // ... relative to the window's first row
+                    const float sy = fmaf(o.Ay, basey[t], o.By) - yoff;                 // ... relative to the window's first row
                     const r3_h8 wy = r3_hat8(sy, cy);
                     const f32x4 og = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, hg), z, 0, 0, 0);
                     const f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(wy, __builtin_bit_cast(r3_h8, ha), z, 0, 0, 0);
