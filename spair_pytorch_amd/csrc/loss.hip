@@ -18,9 +18,6 @@ __global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= L.B) return;
-#ifdef KL_PRIO
-    __builtin_amdgcn_s_setprio(KL_PRIO);
-#endif
     float* zs = z_sh[wave];
     float* pzs = pz_sh[wave];
     const int HW = L.HW, NB = HW + 1;
