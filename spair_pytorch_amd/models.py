@@ -117,7 +117,9 @@ class _StepFn(torch.autograd.Function):
         ctx.mark_non_differentiable(recon, z_where, z_pres)
         ctx.set_materialize_grads(False)     # otherwise autograd zero-fills a gradient for each non-differentiable output (17 MB per step)
         model._loss_terms = loss_terms
-        return loss_terms[0].clone(), recon, z_where, z_pres
+        # a view, not a copy: `loss_terms` is a fresh buffer of this forward (a device copy here is 6 us + a launch gap between the loss
+        # kernel and the backward's first kernel)
+        return loss_terms[0], recon, z_where, z_pres
 
     @staticmethod
     def backward(ctx, g_loss, g_recon, g_zw, g_zp):
