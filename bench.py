@@ -512,8 +512,10 @@ def main():
         #   schedule : global_step of the count-prior / training-wheel schedules (config.py:65-69, models.py:186-188), the bench batch;
         #   objects  : scenes with at most k = 1, 3, 6, 11 digits (the dataset's max_objects);
         #   density  : the state itself moved to where training takes it -- the presence logit's bias (obj_network.out.bias) bisected to
-        #              mean z_pres 0.05 / 0.3 / 0.7, the box-size means' bias (box_network.output_layers.0.bias[2:4]) set for mean object
-        #              sides of ~15 / 24 / 38 px: what the renderer's cost actually follows (active cells x footprint).
+        #              mean z_pres 0.05 / 0.3 / 0.7 (training-mode forwards), the box-size means' bias (box_network.output_layers.0.bias[2:4])
+        #              shifted by -0.79 / 0 / +1.33: what the renderer's cost actually follows (active cells x footprint).
+        # Every point runs whole steps with the learning rate at 0: 160 steps into training the state moves fast (12 steps change the
+        # mean presence by a third), and a point must measure the state it names.
         from spair_pytorch_amd.models import step_scalars
         sd = model.state_dict()
         snap = (model.flat_parameters().clone(), opt.state_dict())
@@ -523,8 +525,10 @@ def main():
         R_F, R_B = SLOT_NAMES.index("render_fwd"), SLOT_NAMES.index("render_bwd")
 
         def restore():
-            model.flat_parameters().copy_(snap[0])         # every point starts from the same model and optimizer state
+            model.flat_parameters().copy_(snap[0])         # every point starts from the same model and optimizer state ...
             opt.load_state_dict(snap[1])
+            opt.lr = 0.0                                   # ... and keeps it: the step runs whole (fwd + bwd + the Adam kernel), the
+                                                           # parameters do not move, so a point measures the state it names
 
         def time_point(gs, xin, label):
             nonlocal x
@@ -575,11 +579,11 @@ def main():
         pres_b, box_b = sd["obj_network.out.bias"], sd["box_network.output_layers.0.bias"]
 
         def mean_pres():
-            # a TRAINING-mode forward (relaxed-Bernoulli samples, as in the timed steps), no backward
-            return float(model(x_main, args.global_step)[3].mean().item())
+            with torch.enable_grad():                      # a TRAINING-mode forward (relaxed-Bernoulli samples, as in the timed steps), no backward
+                return float(model(x_main, args.global_step)[3].mean().item())
 
         for target_pres in (0.05, 0.3, 0.7):
-            for size_bias, size_name in ((-0.79, "~15 px"), (0.0, "~24 px"), (1.33, "~38 px")):
+            for size_bias in (-0.79, 0.0, 1.33):          # x 0.6 / x 1 / x 1.9 on the state's mean object side (15 / 24 / 38 px at initialisation)
                 restore()
                 with torch.no_grad():
                     box_b[2:4] += size_bias
@@ -595,13 +599,15 @@ def main():
                     pres_b.copy_(base + 0.5 * (lo_ + hi_))
                 r = time_point(args.global_step, x_main, "density")
                 r["target_mean_z_pres"] = target_pres
-                r["target_box_side"] = size_name
+                r["box_size_logit_bias"] = size_bias
                 sweep.append(r)
         restore()
+        opt.lr = float(snap[1]["lr"])
         lib.spair_prof_select(ctypes.c_ulonglong(args.prof_mask & 0xFFFFFFFFFFFFFFFF))
         out["sweep"] = sweep
         out["sweep_note"] = ("BASELINE configs[4] on ONE GPU (the 8-GPU form is the driver's): schedule / object-count / density axes, %d timed steps per "
-                             "point behind 2 warm steps, every point from the same model and optimizer state; ms_per_step = median of the per-step "
+                             "point behind 2 warm steps, every point from the same model and optimizer state with the learning rate at 0 (whole "
+                             "steps, frozen parameters: a point measures the state it names); ms_per_step = median of the per-step "
                              "event times; render_*_ms = the renderer's two kernels over the same steps" % args.sweep_steps)
     if world == 1 and default_workload and not args.no_config3:
         # BASELINE configs[3] (256x256, 32x32 grid, batch 64) as a bounded sub-record of the default line: its own model, a few steps
