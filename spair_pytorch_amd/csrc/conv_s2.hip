@@ -1,3 +1,4 @@
+#include <numeric>
 // Patch-resident forward of the backbone's strided convolutions in the bf16 step (reference: modules.py:59-64 -- Conv2d(128, 128, 4, stride 2)
 // + ReLU): conv_1 and conv_2 at 128 -> 128 channels, 4x4 kernel, stride 2, NHWC bf16 in / out.
 //
@@ -207,8 +208,14 @@ int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, voi
         return (int)((g1 + g1 / Hout + 1) * (Hout + 1) + (ml - g1 * Hout) + 1 - ((g0 + g0 / Hout) * (Hout + 1) + (m0 - g0 * Hout)) + 1);
     };
     int tiles = (int)((M + CP_BM - 1) / CP_BM), tpi = 0, worst = 0;
-    for (int t = 0; t < tiles && t < 4096; ++t) worst = std::max(worst, window((long long)t * CP_BM, std::min<long long>((long long)(t + 1) * CP_BM, M) - 1));
-    if (worst > CP_PPX) {
+    // the tile pattern repeats every Hout^2 / gcd(CP_BM, Hout^2) tiles: every distinct tile is checked (a period too long to walk -- an odd
+    // Hout: 16,129 tiles at 127 -- takes the per-image tiling, which is checked exactly below)
+    const long long period = (long long)Hout * Hout / std::gcd((long long)CP_BM, (long long)Hout * Hout);
+    const bool walk = std::min<long long>(tiles, period) <= 65536;
+    for (int t = 0; walk && t < tiles && t < period; ++t)
+        worst = std::max(worst, window((long long)t * CP_BM, std::min<long long>((long long)(t + 1) * CP_BM, M) - 1));
+    if (walk && tiles > period) worst = std::max(worst, window((long long)(tiles - 1) * CP_BM, M - 1));       // the batch's partial last tile
+    if (!walk || worst > CP_PPX) {
         const int HH = Hout * Hout;
         tpi = (HH + CP_BM - 1) / CP_BM;
         worst = 0;

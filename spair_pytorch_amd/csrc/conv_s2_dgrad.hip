@@ -1,3 +1,4 @@
+#include <numeric>
 // Patch-resident DATA GRADIENT of the backbone's strided convolutions in the bf16 step (the backward of modules.py:59-64's Conv2d(128, 128, 4,
 // stride 2) + the ReLU gate of the layer below), optionally with the stem's weight gradient taken from the gated tile (conv_1: d act0 is never
 // written to HBM, as in gemm16.hip's STEM path).
@@ -356,8 +357,13 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
         return (int)((g1 + g1 / Hc + 1) * (Ho + 2) + (ml - g1 * Hc) + 1 - ((g0 + g0 / Hc) * (Ho + 2) + (m0 - g0 * Hc)) + 1);
     };
     int tiles = (int)((M + DG_BM - 1) / DG_BM), tpi = 0, worst = 0;
-    for (int t = 0; t < tiles && t < 8192; ++t) worst = std::max(worst, window((long long)t * DG_BM, std::min<long long>((long long)(t + 1) * DG_BM, M) - 1));
-    if (worst > DG_PPX) {      // tiles that restart at every image (its last tile partial)
+    // the tile pattern repeats every HH / gcd(DG_BM, HH) tiles: every distinct tile is checked; a period too long to walk takes the per-image tiling
+    const long long HHc = (long long)Hc * Hc, period = HHc / std::gcd((long long)DG_BM, HHc);
+    const bool walk = std::min<long long>(tiles, period) <= 65536;
+    for (int t = 0; walk && t < tiles && t < period; ++t)
+        worst = std::max(worst, window((long long)t * DG_BM, std::min<long long>((long long)(t + 1) * DG_BM, M) - 1));
+    if (walk && tiles > period) worst = std::max(worst, window((long long)(tiles - 1) * DG_BM, M - 1));
+    if (!walk || worst > DG_PPX) {      // tiles that restart at every image (its last tile partial)
         const int HH = Hc * Hc;
         tpi = (HH + DG_BM - 1) / DG_BM;
         worst = 0;
