@@ -41,6 +41,15 @@ typedef struct SpairDims {
     float obj_logit_scale, alpha_logit_scale, alpha_logit_bias;
     float vae_beta;            /* VAE_BETA (config.py:55) */
     float prior_mean[6], prior_std[6];   /* cy, cx, height, width, attr, depth (config.py:45-52) */
+    /* Convolutional object encoder / decoder variant (CONV_OBJECT_ENCODER_TOPOLOGY, config.py:15-20; models.py:606-665 sketches the two
+     * classes but cannot run them: PARITY UNPINNED).  obj_conv = 1 replaces the MLP encoder by oc_n valid convolutions (filters oc_c,
+     * kernel oc_k, stride oc_s, ReLU after each) + Linear(flattened (C,H,W) -> 2A), and the MLP decoder by Linear(A -> flattened) + the
+     * mirrored ConvTranspose2d stack (output_padding retraces the encoder's sizes; ReLU between, none after the last; its C+1 output
+     * channels are the sprite's (colour.., alpha) logits).  fp32 step only (dtype SPAIR_DTYPE_F32), per-wavefront launches.  Parameter
+     * names: object_encoder.conv.conv_<i>.{weight,bias}, object_encoder.out.*, object_decoder.inp.*,
+     * object_decoder.conv.conv_transposed_<i>.* (ConvTranspose2d layout [in][out][k][k]). */
+    int obj_conv, oc_n;
+    int oc_k[4], oc_s[4], oc_c[4];
 } SpairDims;
 
 /* Per-step scalars (host side evaluates the two schedules, modules.py:191-213). */
@@ -132,6 +141,18 @@ int spair_gemm_nt_conv(const float* In, const int* conv13, const void* B, int ld
 int spair_gemm_tn_conv(const float* A, int lda, const float* In, const int* conv13, float* C, int ldc, int M,
                        int N, int R, int dtype, void* stream);
 int spair_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
+/* Direct fp32 convolutions of the convolutional object encoder / decoder variant (objconv.hip; SpairDims.obj_conv).  A tensor is
+ * described by t6 = {rs, ys, xs, cs, H, C}: element (r, y, x, c) at p[r*rs + y*ys + x*xs + c*cs], H x H pixels, C channels.  W is
+ * [X][Y][k][k] (nn.Conv2d: X = out, Y = in channels; nn.ConvTranspose2d: X = in, Y = out channels).
+ * spair_objconv_gather, transposed = 0: out(r,y,x,X) = bias + sum in(r, y*s+ky, x*s+kx, Y) * W  (Conv2d forward / ConvTranspose2d data
+ *   gradient); transposed = 1: out(r,y,x,Y) = bias + sum in(r, (y-ky)/s, (x-kx)/s, X) * W  (ConvTranspose2d forward / Conv2d data
+ *   gradient); then out = 0 where gate <= 0 (gate: same layout as out, or NULL), then ReLU if relu.
+ * spair_objconv_wgrad: G[cs][cb][ky][kx] += sum small(r,y,x,cs) * big(r, y*s+ky, x*s+kx, cb), bias_small[cs] += sum small (or NULL)
+ *   (Conv2d: small = d out, big = in; ConvTranspose2d: small = in, big = d out). */
+int spair_objconv_gather(int transposed, const float* in, const long long* in6, const float* W, const float* bias, float* out,
+                         const long long* out6, const float* gate, int k, int s, int relu, long long R, void* stream);
+int spair_objconv_wgrad(const float* small, const long long* small6, const float* big, const long long* big6, float* G,
+                        float* bias_small, int k, int s, long long R, void* stream);
 /* bf16-STORED operand GEMMs (the bf16 mode's activations and gradients live in HBM as bf16; same roles as above).
  * spair_gemm_nt16: C = epi(A * B^T), A bf16 [M][lda] or an NHWC conv gather (conv13), B bf16 [N][ldb], C bf16 (c_bf16)
  *   or fp32; relu_mask bf16 (mask_bf16) or fp32; cmap8 remaps output rows (stride-2 conv data gradient by parity class).

@@ -58,6 +58,12 @@ class OracleConfig:
     alpha_logit_bias: float = 5.0
     align_corners: bool = False                                # torch>=1.3 default
     inverse_mode: str = "lu"   # "lu": batched 3x3 inverse like modules.py:258-261; "closed": 1/xs form
+    # Convolutional object encoder / decoder variant: (filters, kernel, stride) per layer of CONV_OBJECT_ENCODER_TOPOLOGY
+    # (config.py:15-20), None = the live MLP pair.  PARITY UNPINNED: models.py:606-665 cannot run (Linear(123, ..), undefined
+    # self.linear, list.reverse() is None); this restates what the sketch says it means -- Conv2d + ReLU per layer, flatten in
+    # (C,H,W) order into `out`; decoder: `inp` Linear to the encoder's last map, the mirrored ConvTranspose2d stack with ReLU
+    # between layers, whose C+1 output channels are the per-pixel sprite logits (colour.., alpha).
+    object_conv: Optional[Sequence[Tuple[int, int, int]]] = None
 
 
 def exponential_decay(global_step, start, end, decay_rate, decay_step, staircase=False,
@@ -103,6 +109,37 @@ def _mlp(p, prefix, x, n_hidden=2, multi=False):
         return [F.linear(x, p[f"{prefix}.output_layers.{i}.weight"], p[f"{prefix}.output_layers.{i}.bias"])
                 for i in range(2)]
     return F.linear(x, p[f"{prefix}.out.weight"], p[f"{prefix}.out.bias"])
+
+
+def object_encoder(p, glimpse, cfg: "OracleConfig"):
+    """models.py:152 (MLP) / models.py:606-631 (conv sketch).  glimpse [B,C,P,P] -> [B,2A]."""
+    if cfg.object_conv is None:
+        return _mlp(p, "object_encoder", glimpse.flatten(1))
+    h = glimpse
+    for i, (_, k, s) in enumerate(cfg.object_conv):
+        h = F.relu(F.conv2d(h, p[f"object_encoder.conv.conv_{i}.weight"], p[f"object_encoder.conv.conv_{i}.bias"], stride=s))
+    return F.linear(h.flatten(1), p["object_encoder.out.weight"], p["object_encoder.out.bias"])
+
+
+def object_decoder(p, z, cfg: "OracleConfig"):
+    """models.py:165 (MLP) / models.py:633-665 (conv sketch).  z [N,A] -> logits [N,P,P,C+1]."""
+    px, C = cfg.object_shape[0], cfg.image_shape[0]
+    if cfg.object_conv is None:
+        return _mlp(p, "object_decoder", z).view(-1, px, px, C + 1)
+    sizes, chans = [px], [C]
+    for f, k, s in cfg.object_conv:
+        sizes.append((sizes[-1] - k) // s + 1)
+        chans.append(f)
+    n = len(cfg.object_conv)
+    h = F.linear(z, p["object_decoder.inp.weight"], p["object_decoder.inp.bias"]).view(-1, chans[-1], sizes[-1], sizes[-1])
+    for i in range(n):
+        _, k, s = cfg.object_conv[n - 1 - i]
+        op = sizes[n - 1 - i] - ((sizes[n - i] - 1) * s + k)
+        h = F.conv_transpose2d(h, p[f"object_decoder.conv.conv_transposed_{i}.weight"], p[f"object_decoder.conv.conv_transposed_{i}.bias"],
+                               stride=s, output_padding=op)
+        if i + 1 < n:
+            h = F.relu(h)
+    return h.permute(0, 2, 3, 1)
 
 
 def latent_to_mean_std(lat):
@@ -246,7 +283,7 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
             # --- z_what (models.py:82-85,383-391)
             glimpse = stn(x, nbox, tuple(cfg.object_shape), inverse=False,
                           align_corners=cfg.align_corners, fast=fast)
-            enc = _mlp(p, "object_encoder", glimpse.flatten(1))
+            enc = object_encoder(p, glimpse, cfg)
             a_mean, a_std = latent_to_mean_std(enc)
             attr = a_mean + a_std * noise["eps_attr"][:, :, h, w]
             means["attr"][ci], sigmas["attr"][ci] = a_mean, a_std
@@ -311,7 +348,7 @@ def decode_sprites(p, z_attr, z_depth, z_pres, cfg: OracleConfig):
     px = cfg.object_shape[0]
     C = cfg.image_shape[0]
     dec_in = z_attr.permute(0, 2, 3, 1).reshape(-1, A)
-    logits = _mlp(p, "object_decoder", dec_in).view(-1, px, px, C + 1)
+    logits = object_decoder(p, dec_in, cfg)
     colour = clamped_sigmoid(logits[..., :-1] * cfg.obj_logit_scale, analytical=True)
     alpha = clamped_sigmoid(logits[..., -1:] * cfg.alpha_logit_scale + cfg.alpha_logit_bias, analytical=True)
     alpha = alpha * z_pres.reshape(-1, 1, 1, 1)

@@ -19,8 +19,8 @@ DEFAULT_BACKBONE_TOPOLOGY = [
     dict(filters=128, kernel_size=1, stride=1),
     dict(filters=128, kernel_size=1, stride=1),
 ]
-# The reference's conv object encoder/decoder built from this is non-functional
-# (models.py:606-665); kept for name parity only.
+# The reference's conv object encoder/decoder built from this is non-functional (models.py:606-665,
+# SURVEY.md §0); here it is the OBJECT_ENCODER = 'conv' variant (bottom of this file).
 CONV_OBJECT_ENCODER_TOPOLOGY = [
     dict(filters=32, kernel_size=4, stride=2),
     dict(filters=32, kernel_size=3, stride=2),
@@ -71,6 +71,9 @@ IS_LOCAL = 'LOCAL' in os.environ
 COMPUTE_DTYPE = os.environ.get('SPAIR_DTYPE', 'bf16')
 # torch>=1.3 semantics (what the CPU oracle is pinned to); True reproduces the torch-1.0 era.
 ALIGN_CORNERS = False
+# 'mlp': the reference's live object encoder / decoder (models.py:152,165).  'conv': the pair built from CONV_OBJECT_ENCODER_TOPOLOGY
+# that models.py:606-665 sketches but cannot run -- trainable here on the fp32 step (COMPUTE_DTYPE 'f32'), parity unpinned.
+OBJECT_ENCODER = os.environ.get('SPAIR_OBJECT_ENCODER', 'mlp')
 
 
 def set_grid(image_side, strides):

@@ -14,6 +14,7 @@
 #include "misc.h"
 #include "chain.h"
 #include "dec_fused.h"
+#include "objconv.h"
 
 // kernels in other translation units
 int stn_glimpse_fwd(const float* x, const float* nbox, int B, float* out, int ld, int r0, int R, int C, int I, int P, int ac, int px16, hipStream_t s);
@@ -120,6 +121,19 @@ static int validate(const SpairDims& d) {
     }
     if (h != d.G) return SPAIR_ERR_SHAPE;
     if (d.G * d.G + 1 > 1025) return SPAIR_ERR_UNSUPPORTED;
+    if (d.obj_conv) {   // convolutional object encoder / decoder variant: fp32 step, per-wavefront launches (objconv.hip)
+        if (d.dtype != SPAIR_F32) return SPAIR_ERR_UNSUPPORTED;
+        if (d.oc_n < 1 || d.oc_n > 4) return SPAIR_ERR_SHAPE;
+        int hh = d.P, ci = d.C;
+        for (int i = 0; i < d.oc_n; ++i) {
+            if (d.oc_k[i] < 1 || d.oc_s[i] < 1 || d.oc_c[i] < 1 || d.oc_k[i] > hh) return SPAIR_ERR_SHAPE;
+            if ((long long)ci * d.oc_c[i] * d.oc_k[i] * d.oc_k[i] > 256 * 36 || d.oc_c[i] > 256) return SPAIR_ERR_UNSUPPORTED;
+            const int ho = (hh - d.oc_k[i]) / d.oc_s[i] + 1;
+            hh = ho; ci = d.oc_c[i];
+        }
+        if (((ci * hh * hh) & 7) || ((d.P * d.P * (d.C + 1)) & 7)) return SPAIR_ERR_ALIGN;       // rows handed to the GEMM / column-sum kernels
+        if ((long long)(d.C + 1) * d.oc_c[0] * d.oc_k[0] * d.oc_k[0] > 256 * 36) return SPAIR_ERR_UNSUPPORTED;
+    }
     return SPAIR_OK;
 }
 
@@ -146,6 +160,10 @@ struct Ws {
     float *tn_part, *tn_part2;                          // split-K partial tiles of the weight-gradient GEMMs (caller's / helper stream)
     float *aux, *bce_partial, *kl_partial, *klp, *gedge_part;
     void* rrec;
+    // convolutional object encoder / decoder variant (fp32): layer outputs and their gradients, N rows each
+    float *oc_ea[4], *oc_dea[4];      // encoder conv i (post-ReLU; the last one in (C,H,W) order = the Linear's input), d of the same
+    float *oc_dh, *oc_ddh;            // decoder Linear output (C,H,W) and its gradient
+    float *oc_da[4], *oc_dda[4];      // decoder transposed conv i < n-1 (post-ReLU, NHWC), d of the same (the last one writes the sprites)
     int* chain_sync;                  // band split of the fused chain (chain.h): start tickets, time-out word, per-(sample, band) counters
     float *bnd_rec, *bnd_grad;        // ... and the boundary rows handed from band to band
     unsigned long long* stamps;
@@ -254,6 +272,17 @@ static Ws carve(const SpairDims& d, void* base) {
     w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.rrec = c.take_bytes((size_t)N * 64);                  // the renderer's per-object records (render3.hip)
+    for (int i = 0; i < PL.oc_n; ++i) {
+        const ConvSpec& e = PL.oc_enc[i];
+        const size_t n = N * e.hout * e.hout * e.cout;
+        w.oc_ea[i] = c.take<float>(n); w.oc_dea[i] = c.take<float>(n);
+        if (i + 1 < PL.oc_n) {
+            const ConvSpec& t = PL.oc_dec[i];
+            const size_t m = N * t.hout * t.hout * t.cout;
+            w.oc_da[i] = c.take<float>(m); w.oc_dda[i] = c.take<float>(m);
+        }
+    }
+    if (PL.oc_n) { w.oc_dh = c.take<float>(N * PL.oc_flat); w.oc_ddh = c.take<float>(N * PL.oc_flat); }
     w.kl_partial = c.take<float>((size_t)loss_gauss_kl_blocks(L) * 6);
     w.klp = c.take<float>(d.B);
     w.gedge_part = c.take<float>((size_t)d.B * nbands * 4 * L.REC);
@@ -303,11 +332,29 @@ static std::vector<PInfo> param_infos(const SpairDims& d) {
     };
     lin("box_network.body.dense0", LIN_BOX0); lin("box_network.body.dense1", LIN_BOX1);
     lin("box_network.output_layers.0", LIN_BOXH0); lin("box_network.output_layers.1", LIN_BOXH1);
+    if (P.oc_n) {
+        for (int i = 0; i < P.oc_n; ++i) {
+            const ConvSpec& c = P.oc_enc[i];
+            snprintf(buf, sizeof(buf), "object_encoder.conv.conv_%d.weight", i); add(buf, c.w, 4, c.cout, c.cin, c.k, c.k);
+            snprintf(buf, sizeof(buf), "object_encoder.conv.conv_%d.bias", i); add(buf, c.b, 1, c.cout);
+        }
+        lin("object_encoder.out", LIN_ENC2);
+    } else {
     lin("object_encoder.dense0", LIN_ENC0); lin("object_encoder.dense1", LIN_ENC1); lin("object_encoder.out", LIN_ENC2);
+    }
     lin("z_network.body.dense0", LIN_Z0); lin("z_network.body.dense1", LIN_Z1);
     lin("z_network.output_layers.0", LIN_ZH0); lin("z_network.output_layers.1", LIN_ZH1);
     lin("obj_network.dense0", LIN_OBJ0); lin("obj_network.dense1", LIN_OBJ1); lin("obj_network.out", LIN_OBJ2);
+    if (P.oc_n) {
+        lin("object_decoder.inp", LIN_DEC0);
+        for (int i = 0; i < P.oc_n; ++i) {
+            const ConvSpec& c = P.oc_dec[i];
+            snprintf(buf, sizeof(buf), "object_decoder.conv.conv_transposed_%d.weight", i); add(buf, c.w, 4, c.cin, c.cout, c.k, c.k);
+            snprintf(buf, sizeof(buf), "object_decoder.conv.conv_transposed_%d.bias", i); add(buf, c.b, 1, c.cout);
+        }
+    } else {
     lin("object_decoder.dense0", LIN_DEC0); lin("object_decoder.dense1", LIN_DEC1); lin("object_decoder.out", LIN_DEC2);
+    }
     const int ad = 4 + d.A + 1;
     add("attn.gamma", P.attn_gamma, 1, 1);
     add("attn.query_conv.weight", P.attn_q_w, 4, ad / 8, ad, 1, 1); add("attn.query_conv.bias", P.attn_q_b, 1, ad / 8);
@@ -433,8 +480,8 @@ static int make_ctx(Ctx& c, const SpairDims* d, const SpairStep* st, const float
     c.w.cb.edge = params + c.PL.edge;
     c.w.cb.eps_box = eps_box; c.w.cb.eps_attr = eps_attr; c.w.cb.eps_depth = eps_depth; c.w.cb.u_pres = u_pres;
     fill_diag(c);
-    c.use_chain = chain_fwd_supported(*d) && !(st->flags & 1);
-    c.use_dec_fused = d->dtype == SPAIR_BF16 && !(st->flags & 16) && c.PL.lin[LIN_DEC0].out == SP_DEC_H1 && c.PL.lin[LIN_DEC1].out == SP_DEC_H2 &&
+    c.use_chain = chain_fwd_supported(*d) && !(st->flags & 1) && !d->obj_conv;
+    c.use_dec_fused = !d->obj_conv && d->dtype == SPAIR_BF16 && !(st->flags & 16) && c.PL.lin[LIN_DEC0].out == SP_DEC_H1 && c.PL.lin[LIN_DEC1].out == SP_DEC_H2 &&
                       dec_fused_supported(d->A, d->P * d->P * (d->C + 1), c.L.ld_rec, c.L.N, c.w.ld_s) && d->C == 1;
     return SPAIR_OK;
 }
@@ -531,6 +578,7 @@ static int prep_weights(Ctx& c, bool need_dgrad, int part) {
     for (int id = 0; part == 1 && id < LIN_COUNT; ++id) {
         if (id == LIN_BOXH0 || id == LIN_ZH0) continue;
         const LinSpec& l = c.PL.lin[id];
+        if (!l.in || !l.out) continue;        // (the convolutional variant has no dense0 / dense1 in its encoder, no dense1 / out in its decoder)
         const int ldf = round_up(l.in, 8);
         int head0 = -1;
         if (id == LIN_BOXH1) head0 = LIN_BOXH0;
@@ -888,6 +936,105 @@ static int fwd_lin_f32(Ctx& c, int id, const float* A, int lda, float* C, int ld
     return spair_gemm_nt_impl(g, false, SPAIR_F32, c.s);
 }
 
+// ---- convolutional object encoder / decoder variant (SpairDims.obj_conv; objconv.hip) --------------------------------------------------
+// Parity unpinned: the reference's ObjectConvEncoder / ObjectConvDecoder (models.py:606-665) cannot run; the layer sizes follow
+// CONV_OBJECT_ENCODER_TOPOLOGY's own comments (config.py:15-20).  Activations are per-object NHWC tensors, except the encoder's last
+// layer and the decoder's Linear output, which are stored in (C,H,W) order -- the order nn.Flatten / .view give the Linear layers.
+static OcTensor oc_enc_act(const Ctx& c, int i, bool grad) {
+    const ConvSpec& e = c.PL.oc_enc[i];
+    float* p = grad ? c.w.oc_dea[i] : c.w.oc_ea[i];
+    const long long rs = (long long)e.hout * e.hout * e.cout;
+    return i + 1 == c.PL.oc_n ? oc_chw(p, rs, e.hout, e.cout) : oc_hwc(p, rs, e.hout, e.cout);
+}
+static OcTensor oc_dec_act(const Ctx& c, int i, bool grad) {      // input of transposed conv i + 1 (i = -1: the Linear's output)
+    if (i < 0) return oc_chw(grad ? c.w.oc_ddh : c.w.oc_dh, c.PL.oc_flat, c.PL.oc_dec[0].hin, c.PL.oc_dec[0].cin);
+    const ConvSpec& t = c.PL.oc_dec[i];
+    return oc_hwc(grad ? c.w.oc_dda[i] : c.w.oc_da[i], (long long)t.hout * t.hout * t.cout, t.hout, t.cout);
+}
+static int bwd_lin(Ctx& c, int id, int out_total, const float* dOut, int ldo, float* dX, int ldx, int r0, int R, const float* mask, int ldmask);
+static int wgrad_lin(Ctx& c, int id, const float* dOut, int ldo, const float* In, int ldi, float* grads, int R);
+// Weight gradient of one layer: G[cs][cb][ky][kx] += sum small * big-through-the-taps.  When both operands are dense NHWC tensors it is the
+// split-K TN product of gemm.hip with the big tensor gathered as the implicit-GEMM operand (the kernel of the backbone's weight gradients:
+// conv0's 1.6 M positions took 1.1 ms as objconv's walk); the (C,H,W)-ordered layers at the 2 x 2 end keep the walk.
+static int oc_layer_wgrad(Ctx& c, const OcTensor& sm, const OcTensor& bg, float* G, float* bias_small, int k, int s, long long R) {
+    auto dense = [](const OcTensor& t) { return t.cs == 1 && t.xs == t.C && t.ys == t.H * t.C && t.rs == (long long)t.H * t.H * t.C; };
+    const long long rows = R * sm.H * sm.H;
+    if (dense(sm) && dense(bg) && (sm.C & 3) == 0 && rows < 0x7fffffffll && R * bg.H * bg.H * bg.C < 0x7fffffffll) {
+        GemmTN g;
+        memset(&g, 0, sizeof(g));
+        const int K = k * k * bg.C;
+        g.A = sm.p; g.lda = sm.C; g.B = bg.p; g.C = G; g.ldc = K; g.M = sm.C; g.N = round_up(K, 4); g.Mstore = sm.C; g.Nstore = K;
+        g.R = (int)rows; g.cw_cin = bg.C; g.cw_taps = k * k; g.colsum_out = bias_small;
+        g.conv.Hin = bg.H; g.conv.Win = bg.H; g.conv.Cin = bg.C; g.conv.Hout = sm.H; g.conv.Wout = sm.H; g.conv.kh = k; g.conv.kw = k;
+        g.conv.sy = s; g.conv.sx = s; g.conv.dky = 1; g.conv.dkx = 1; g.conv.oy = 0; g.conv.ox = 0;
+        return spair_gemm_tn_impl(g, true, SPAIR_F32, c.s);
+    }
+    return oc_wgrad(sm, bg, G, bias_small, k, s, R, c.s);
+}
+static int oc_encoder_fwd(Ctx& c, int r0, int R) {
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const int n = c.PL.oc_n;
+    OcTensor in = oc_hwc(P.glimpse, L.ld_gl, c.d.P, c.d.C);
+    for (int i = 0; i < n; ++i) {
+        const ConvSpec& e = c.PL.oc_enc[i];
+        const OcTensor out = oc_enc_act(c, i, false);
+        TRY(oc_gather(false, oc_rows(in, r0), c.params + e.w, c.params + e.b, oc_rows(out, r0), OcTensor{}, e.k, e.s, 1, R, c.s));
+        in = out;
+    }
+    return fwd_lin(c, LIN_ENC2, c.w.oc_ea[n - 1], c.PL.oc_flat, P.Oe, L.ld_oe, r0, R, c.params + c.PL.lin[LIN_ENC2].b, 2 * L.A, 0);
+}
+static int oc_encoder_bwd(Ctx& c, int r0, int R) {
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const int n = c.PL.oc_n, flat = c.PL.oc_flat;
+    TRY(bwd_lin(c, LIN_ENC2, 2 * L.A, P.dOe, L.ld_oe, c.w.oc_dea[n - 1], flat, r0, R, c.w.oc_ea[n - 1], flat));
+    for (int i = n - 1; i >= 0; --i) {
+        const ConvSpec& e = c.PL.oc_enc[i];
+        const OcTensor din = i ? oc_enc_act(c, i - 1, true) : oc_hwc(P.dGl, L.ld_gl, c.d.P, c.d.C);
+        const OcTensor gate = i ? oc_enc_act(c, i - 1, false) : OcTensor{};
+        TRY(oc_gather(true, oc_rows(oc_enc_act(c, i, true), r0), c.params + e.w, nullptr, oc_rows(din, r0), oc_rows(gate, r0), e.k, e.s, 0, R, c.s));
+    }
+    return SPAIR_OK;
+}
+static int oc_encoder_wgrad(Ctx& c, float* grads) {
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const int n = c.PL.oc_n;
+    for (int i = 0; i < n; ++i) {
+        const ConvSpec& e = c.PL.oc_enc[i];
+        const OcTensor big = i ? oc_enc_act(c, i - 1, false) : oc_hwc(P.glimpse, L.ld_gl, c.d.P, c.d.C);
+        TRY(oc_layer_wgrad(c, oc_enc_act(c, i, true), big, grads + e.w, grads + e.b, e.k, e.s, L.N));
+    }
+    return wgrad_lin(c, LIN_ENC2, P.dOe, L.ld_oe, c.w.oc_ea[n - 1], c.PL.oc_flat, grads, L.N);
+}
+static int oc_decoder_fwd(Ctx& c) {
+    const CellLayout& L = c.L;
+    const int n = c.PL.oc_n, flat = c.PL.oc_flat, per = c.d.P * c.d.P * (c.d.C + 1);
+    TRY(fwd_lin(c, LIN_DEC0, c.w.Za, L.ld_rec, c.w.oc_dh, flat, 0, L.N, c.params + c.PL.lin[LIN_DEC0].b, flat, 0));
+    for (int i = 0; i < n; ++i) {
+        const ConvSpec& t = c.PL.oc_dec[i];
+        const OcTensor out = i + 1 < n ? oc_dec_act(c, i, false) : oc_hwc(c.w.S, c.w.ld_s, t.hout, t.cout);
+        TRY(oc_gather(true, oc_dec_act(c, i - 1, false), c.params + t.w, c.params + t.b, out, OcTensor{}, t.k, t.s, i + 1 < n, L.N, c.s));
+    }
+    return render_sprite_act(c.w.S, c.w.ld_s, L.N, per, c.d.C + 1, c.d.obj_logit_scale, c.d.alpha_logit_scale, c.d.alpha_logit_bias, c.s);
+}
+static int oc_decoder_bwd(Ctx& c, float* grads) {
+    const CellLayout& L = c.L;
+    CellBufs& P = c.w.cb;
+    const int n = c.PL.oc_n, flat = c.PL.oc_flat;
+    for (int i = n - 1; i >= 0; --i) {
+        const ConvSpec& t = c.PL.oc_dec[i];
+        const OcTensor dout = i + 1 < n ? oc_dec_act(c, i, true) : oc_hwc(c.w.dLog, c.w.ld_s, t.hout, t.cout);
+        const OcTensor in = oc_dec_act(c, i - 1, false);
+        TRY(oc_layer_wgrad(c, in, dout, grads + t.w, nullptr, t.k, t.s, L.N));
+        TRY(spair_colsum_impl(dout.p, t.cout, L.N * t.hout * t.hout, t.cout, grads + t.b, c.s));
+        TRY(oc_gather(false, dout, c.params + t.w, nullptr, oc_dec_act(c, i - 1, true), i ? in : OcTensor{}, t.k, t.s, 0, L.N, c.s));
+    }
+    TRY(wgrad_lin(c, LIN_DEC0, c.w.oc_ddh, flat, c.w.Za, L.ld_rec, grads, L.N));
+    return bwd_lin(c, LIN_DEC0, flat, c.w.oc_ddh, flat, P.g_attr_r, L.ld_rec, 0, L.N, nullptr, 0);
+}
+
 static int cells_fwd(Ctx& c) {
     const CellLayout& L = c.L;
     CellBufs& P = c.w.cb;
@@ -925,9 +1072,12 @@ static int cells_fwd(Ctx& c) {
         TRY(cells_box_sample(L, P, c.H, r0, R, c.s));
         // z_what
         { ProfScope ps(PS_STN_FWD, c.s); TRY(stn_glimpse_fwd(c.x, P.nbox, L.B, P.glimpse, L.ld_gl, r0, R, c.d.C, c.d.I, c.d.P, c.d.align_corners, chain_image_fp16(c.d), c.s)); }
+        if (PL.oc_n) TRY(oc_encoder_fwd(c, r0, R));
+        else {
         TRY(fwd_lin(c, LIN_ENC0, P.glimpse, L.ld_gl, P.He1, SP_ENC_H1, r0, R, pr + PL.lin[LIN_ENC0].b, SP_ENC_H1, 1));
         TRY(fwd_lin(c, LIN_ENC1, P.He1, SP_ENC_H1, P.He2, SP_ENC_H2, r0, R, pr + PL.lin[LIN_ENC1].b, SP_ENC_H2, 1));
         TRY(fwd_lin(c, LIN_ENC2, P.He2, SP_ENC_H2, P.Oe, L.ld_oe, r0, R, pr + PL.lin[LIN_ENC2].b, 2 * L.A, 0));
+        }
         TRY(cells_attr_sample(L, P, r0, R, c.s));
         // z_depth
         TRY(fwd_lin(c, LIN_Z0, P.Xz, L.ld_x, P.Hz1, SP_LDH, r0, R, pr + PL.lin[LIN_Z0].b, SP_H, 1));
@@ -1007,7 +1157,9 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         const int b16 = d->dtype == SPAIR_BF16;
         const int K0 = round_up(PL.lin[LIN_DEC0].in, 8), K2 = round_up(PL.lin[LIN_DEC2].in, 8);
         if (b16 && !c.use_chain) TRY(spair_to_bf16(c.w.Za, L.ld_rec, c.w.Za16, L.ld_rec, N, L.ld_rec, c.s));     // the fused chain writes bf16 itself
-        if (c.use_dec_fused) {
+        if (PL.oc_n) {
+            TRY(oc_decoder_fwd(c));
+        } else if (c.use_dec_fused) {
             // all three layers + the sprite epilogue in one activation-stationary launch (dec_fused.hip)
             ProfScope p2(PS_DEC2_FWD, c.s);
             TRY(dec_fused_fwd(c.w.Za16, L.ld_rec, c.w.dec_stream, params + PL.lin[LIN_DEC0].b, params + PL.lin[LIN_DEC1].b, params + PL.lin[LIN_DEC2].b,
@@ -1243,6 +1395,10 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         }
         TRY(record_ready(ev_decoder, c.s));
         if (side) { c.s = main_s; c.tn_scratch = nullptr; }
+    } else if (PL.oc_n) {
+        ProfScope ps(PS_DECODER_BWD, c.s);
+        TRY(oc_decoder_bwd(c, grads));
+        TRY(record_ready(ev_decoder, c.s));
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }
@@ -1281,9 +1437,12 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         TRY(bwd_lin(c, LIN_Z1, SP_H, P.dHz2, SP_LDH, P.dHz1, SP_LDH, r0, R, P.Hz1, SP_LDH));
         TRY(bwd_lin(c, LIN_Z0, SP_H, P.dHz1, SP_LDH, P.dXz, L.ld_x, r0, R, nullptr, 0));
         TRY(cells_bwd_attr(L, P, c.H, r0, R, c.s));
+        if (PL.oc_n) TRY(oc_encoder_bwd(c, r0, R));
+        else {
         TRY(bwd_lin(c, LIN_ENC2, 2 * L.A, P.dOe, L.ld_oe, P.dHe2, SP_ENC_H2, r0, R, P.He2, SP_ENC_H2));
         TRY(bwd_lin(c, LIN_ENC1, SP_ENC_H2, P.dHe2, SP_ENC_H2, P.dHe1, SP_ENC_H1, r0, R, P.He1, SP_ENC_H1));
         TRY(bwd_lin(c, LIN_ENC0, SP_ENC_H1, P.dHe1, SP_ENC_H1, P.dGl, L.ld_gl, r0, R, nullptr, 0));
+        }
         TRY(stn_glimpse_bwd(x, P.nbox, L.B, P.dGl, L.ld_gl, P.g_nbox_stn, r0, R, d->C, d->I, d->P, d->align_corners, chain_image_fp16(*d), c.s));
         TRY(cells_bwd_box(L, P, c.H, r0, R, c.s));
         TRY(bwd_lin(c, LIN_BOXH1, L.NP + 8, P.dOb, L.ld_ob, P.dHb2, SP_LDH, r0, R, P.Hb2, SP_LDH));
@@ -1307,9 +1466,12 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     TRY(wgrad_lin(c, LIN_BOX1, P.dHb2, SP_LDH, P.Hb1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_BOXH1, P.dOb, L.ld_ob, P.Hb2, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_BOXH0, P.dOb + L.ob_lat, L.ld_ob, P.Hb2, SP_LDH, grads, N));
+    if (PL.oc_n) TRY(oc_encoder_wgrad(c, grads));
+    else {
     TRY(wgrad_lin(c, LIN_ENC0, P.dHe1, SP_ENC_H1, P.glimpse, L.ld_gl, grads, N));
     TRY(wgrad_lin(c, LIN_ENC1, P.dHe2, SP_ENC_H2, P.He1, SP_ENC_H1, grads, N));
     TRY(wgrad_lin(c, LIN_ENC2, P.dOe, L.ld_oe, P.He2, SP_ENC_H2, grads, N));
+    }
     TRY(wgrad_lin(c, LIN_Z0, P.dHz1, SP_LDH, P.Xz, L.ld_x, grads, N));
     TRY(wgrad_lin(c, LIN_Z1, P.dHz2, SP_LDH, P.Hz1, SP_LDH, grads, N));
     TRY(wgrad_lin(c, LIN_ZH1, P.dOz, L.ld_oz, P.Hz2, SP_LDH, grads, N));

@@ -68,6 +68,10 @@ struct ParamLayout {
     int n_conv;                       // including conv_out as the last entry
     ConvSpec conv[SP_MAX_CONV + 1];
     LinSpec lin[LIN_COUNT];
+    // convolutional object encoder / decoder variant (SpairDims.obj_conv): oc_n > 0 -- LIN_ENC0/1 and LIN_DEC1/2 are empty, LIN_ENC2 is
+    // Linear(oc_flat -> 2A), LIN_DEC0 is Linear(A -> oc_flat); oc_dec[i] mirrors oc_enc[oc_n-1-i] (weights [cin][cout][k][k])
+    int oc_n, oc_flat;
+    ConvSpec oc_enc[4], oc_dec[4];
     int64_t attn_gamma, attn_q_w, attn_q_b, attn_k_w, attn_k_b, attn_v_w, attn_v_b;
     int64_t total;
 };
@@ -105,12 +109,40 @@ static inline ParamLayout make_param_layout(const SpairDims& d) {
         P.lin[id].b = pl_take(cur, out);
     };
     lin(LIN_BOX0, L.F + L.CTX, SP_H); lin(LIN_BOX1, SP_H, SP_H); lin(LIN_BOXH0, SP_H, 8); lin(LIN_BOXH1, SP_H, L.NP);
+    P.oc_n = 0; P.oc_flat = 0;
+    if (d.obj_conv) {
+        P.oc_n = d.oc_n;
+        int ci = d.C, hh = d.P;
+        for (int i = 0; i < d.oc_n; ++i) {
+            ConvSpec& c = P.oc_enc[i];
+            c.cin = ci; c.cout = d.oc_c[i]; c.k = d.oc_k[i]; c.s = d.oc_s[i];
+            c.hin = hh; c.hout = (hh - c.k) / c.s + 1;
+            c.w = pl_take(cur, (int64_t)c.cout * ci * c.k * c.k);
+            c.b = pl_take(cur, c.cout);
+            ci = c.cout; hh = c.hout;
+        }
+        P.oc_flat = ci * hh * hh;
+        lin(LIN_ENC0, 0, 0); lin(LIN_ENC1, 0, 0); lin(LIN_ENC2, P.oc_flat, 2 * L.A);
+    } else {
     lin(LIN_ENC0, L.glimpse, SP_ENC_H1); lin(LIN_ENC1, SP_ENC_H1, SP_ENC_H2); lin(LIN_ENC2, SP_ENC_H2, 2 * L.A);
+    }
     const int zin = L.x_depth;  // F + CTX + NP + 4 + A
     lin(LIN_Z0, zin, SP_H); lin(LIN_Z1, SP_H, SP_H); lin(LIN_ZH0, SP_H, 2); lin(LIN_ZH1, SP_H, L.NP);
     lin(LIN_OBJ0, zin + 1, SP_H); lin(LIN_OBJ1, SP_H, SP_H); lin(LIN_OBJ2, SP_H, 1);
+    if (d.obj_conv) {
+        lin(LIN_DEC0, L.A, P.oc_flat); lin(LIN_DEC1, 0, 0); lin(LIN_DEC2, 0, 0);
+        for (int i = 0; i < d.oc_n; ++i) {
+            const ConvSpec& e = P.oc_enc[d.oc_n - 1 - i];
+            ConvSpec& c = P.oc_dec[i];
+            c.cin = e.cout; c.cout = (d.oc_n - 1 - i == 0) ? d.C + 1 : e.cin; c.k = e.k; c.s = e.s;
+            c.hin = e.hout; c.hout = e.hin;
+            c.w = pl_take(cur, (int64_t)c.cin * c.cout * c.k * c.k);
+            c.b = pl_take(cur, c.cout);
+        }
+    } else {
     lin(LIN_DEC0, L.A, SP_DEC_H1); lin(LIN_DEC1, SP_DEC_H1, SP_DEC_H2);
     lin(LIN_DEC2, SP_DEC_H2, d.P * d.P * (d.C + 1));
+    }
     const int ad = 4 + d.A + 1;  // Self_Attn(55) -- dead in the reference, kept for state_dict parity
     P.attn_gamma = pl_take(cur, 1);
     P.attn_q_w = pl_take(cur, (int64_t)(ad / 8) * ad); P.attn_q_b = pl_take(cur, ad / 8);

@@ -24,7 +24,7 @@ from torch import nn
 
 from . import _lib as L
 from . import config as cfg
-from .modules import Backbone, build_MLP, exponential_decay
+from .modules import Backbone, ObjectConvDecoder, ObjectConvEncoder, build_MLP, exponential_decay
 
 DIST_NAMES = ['cy_logit', 'cx_logit', 'height_logit', 'width_logit', 'attr', 'depth_logit']
 
@@ -39,7 +39,9 @@ class SpairDims(ctypes.Structure):
                 ("anchor", ctypes.c_float), ("max_yx", ctypes.c_float), ("min_yx", ctypes.c_float),
                 ("max_hw", ctypes.c_float), ("min_hw", ctypes.c_float), ("obj_logit_scale", ctypes.c_float),
                 ("alpha_logit_scale", ctypes.c_float), ("alpha_logit_bias", ctypes.c_float),
-                ("vae_beta", ctypes.c_float), ("prior_mean", ctypes.c_float * 6), ("prior_std", ctypes.c_float * 6)]
+                ("vae_beta", ctypes.c_float), ("prior_mean", ctypes.c_float * 6), ("prior_std", ctypes.c_float * 6),
+                ("obj_conv", ctypes.c_int), ("oc_n", ctypes.c_int), ("oc_k", ctypes.c_int * 4), ("oc_s", ctypes.c_int * 4),
+                ("oc_c", ctypes.c_int * 4)]
 
 
 class SpairStep(ctypes.Structure):
@@ -54,8 +56,9 @@ STEP_FLAGS = int(os.environ.get("SPAIR_STEP_FLAGS", "0"))
 _DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
 
-def make_dims(batch, image_shape, topology, dtype=None):
-    from .modules import backbone_geometry
+def make_dims(batch, image_shape, topology, dtype=None, object_conv_topology=None):
+    """``object_conv_topology``: the layer list of the convolutional object encoder / decoder variant (``None`` = the MLP pair)."""
+    from .modules import backbone_geometry, _topology_conv_args
     d = SpairDims()
     C, I, I2 = image_shape
     assert I == I2, "square images only"
@@ -75,6 +78,12 @@ def make_dims(batch, image_shape, topology, dtype=None):
     d.vae_beta = float(cfg.VAE_BETA)
     for i, n in enumerate(DIST_NAMES):
         d.prior_mean[i], d.prior_std[i] = float(cfg.PRIORS[n][0]), float(cfg.PRIORS[n][1])
+    if object_conv_topology is not None:
+        if len(object_conv_topology) > 4:
+            raise L.SpairHipError("the convolutional object encoder takes at most 4 layers")
+        d.obj_conv, d.oc_n = 1, len(object_conv_topology)
+        for i, layer in enumerate(object_conv_topology):
+            d.oc_c[i], d.oc_k[i], d.oc_s[i] = _topology_conv_args(layer)
     return d
 
 
@@ -136,13 +145,22 @@ class _StepFn(torch.autograd.Function):
 
 
 class SPAIR(nn.Module):
-    def __init__(self, image_shape, writer=None, device=None, compute_dtype=None):
+    def __init__(self, image_shape, writer=None, device=None, compute_dtype=None, object_encoder=None):
+        """``object_encoder``: 'mlp' (the reference's live configuration, models.py:152,165) or 'conv' -- the convolutional encoder /
+        decoder pair of ``cfg.CONV_OBJECT_ENCODER_TOPOLOGY`` (config.py:15-20) that models.py:606-665 sketches but cannot run
+        (parity unpinned); default ``cfg.OBJECT_ENCODER``.  The conv pair trains on the fp32 step (``compute_dtype='f32'``)."""
         super().__init__()
+        self.object_encoder_kind = (object_encoder or cfg.OBJECT_ENCODER).lower()
+        if self.object_encoder_kind not in ('mlp', 'conv'):
+            raise ValueError("object_encoder must be 'mlp' or 'conv'")
         self.image_shape = list(image_shape)
         self.writer = writer if writer is not None else _NullWriter()
         self.B = 1
         self.device = torch.device(device) if device is not None else torch.device('cuda')
         self.compute_dtype = (compute_dtype or cfg.COMPUTE_DTYPE).lower()
+        if self.object_encoder_kind == 'conv' and _DTYPES.get(self.compute_dtype) != 0:
+            raise L.SpairHipError("object_encoder='conv' runs on the fp32 step only: pass compute_dtype='f32' (the fused bf16 per-cell "
+                                  "kernels are built for the MLP encoder / decoder)")
         self.world_size = 1          # set by spair_pytorch_amd.ddp for the sharded loss (SURVEY §8(e))
         self.context_dim = (cfg.N_LOOKBACK * 2 + 1) ** 2 // 2 * (4 + cfg.N_ATTRIBUTES + 1 + 1)
         if cfg.N_LOOKBACK != 1:
@@ -173,11 +191,19 @@ class SPAIR(nn.Module):
         n_feat = self.feature_space_dim[0]
         self.box_network = build_MLP(n_feat + self.context_dim, multiple_output=(8, n_pass))
         obj_dim, chan = cfg.OBJECT_SHAPE[0], cfg.INPUT_IMAGE_SHAPE[0]
-        self.object_encoder = build_MLP(obj_dim * obj_dim * chan, 2 * cfg.N_ATTRIBUTES, hidden_layers=[256, 128])
+        if self.object_encoder_kind == 'conv':
+            self.object_conv_topology = [dict(t) for t in cfg.CONV_OBJECT_ENCODER_TOPOLOGY]
+            self.object_encoder = ObjectConvEncoder([chan, obj_dim, obj_dim], 2 * cfg.N_ATTRIBUTES, self.object_conv_topology)
+        else:
+            self.object_conv_topology = None
+            self.object_encoder = build_MLP(obj_dim * obj_dim * chan, 2 * cfg.N_ATTRIBUTES, hidden_layers=[256, 128])
         z_in = 4 + cfg.N_ATTRIBUTES + n_pass + self.context_dim + cfg.N_BACKBONE_FEATURES
         self.z_network = build_MLP(z_in, multiple_output=(2, n_pass))
         self.obj_network = build_MLP(z_in + 1, 1)
-        self.object_decoder = build_MLP(cfg.N_ATTRIBUTES, obj_dim * obj_dim * (chan + 1), hidden_layers=[128, 256])
+        if self.object_encoder_kind == 'conv':
+            self.object_decoder = ObjectConvDecoder(cfg.N_ATTRIBUTES, chan + 1, self.object_encoder.shapes, self.object_conv_topology)
+        else:
+            self.object_decoder = build_MLP(cfg.N_ATTRIBUTES, obj_dim * obj_dim * (chan + 1), hidden_layers=[128, 256])
         self.attn = _SelfAttnParams(55)   # dead in the reference (models.py:120,167); kept for state_dict parity
 
     def _build_edge_element(self):
@@ -193,7 +219,7 @@ class SPAIR(nn.Module):
 
     # ---- flat parameter / gradient buffers ---------------------------------------------------------
     def _dims(self, batch):
-        return make_dims(batch, self.image_shape, self.backbone.topology, self.compute_dtype)
+        return make_dims(batch, self.image_shape, self.backbone.topology, self.compute_dtype, self.object_conv_topology)
 
     def _flatten(self):
         """(Re)build the flat buffers on ``self.device`` and re-point every Parameter into them."""

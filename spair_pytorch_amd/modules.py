@@ -268,8 +268,9 @@ class ObjectConvEncoder(Module):
     """Convolutional glimpse encoder from ``cfg.CONV_OBJECT_ENCODER_TOPOLOGY`` (config.py:15-20), the variant the reference sketches in
     models.py:606-631 but never makes runnable (``Linear(123, ..)`` / ``self.linear`` undefined).  Opt-in and PARITY UNPINNED: the layer
     sizes follow the topology's own comments (28 -> 13 -> 6 -> 2 -> 2, 32 channels), flattened in (C, H, W) order into ``out``.
-    ``forward`` runs every convolution as the implicit GEMM of spair_gemm_nt_conv (exact fp32 MFMA mode) and the head through
-    spair_gemm_nt; inference helper (no autograd graph) -- the training step uses the MLP encoder inside the fused chain."""
+    ``SPAIR(..., object_encoder='conv')`` trains these parameters inside the HIP step (csrc/objconv.hip: direct fp32 convolutions per
+    dependency wavefront, hand-written data / weight gradients).  ``forward`` here is a stand-alone inference helper (no autograd graph):
+    every convolution as the implicit GEMM of spair_gemm_nt_conv (exact fp32 MFMA mode), the head through spair_gemm_nt."""
 
     def __init__(self, input_size, output_size, topology=None):
         super().__init__()
@@ -299,7 +300,8 @@ class ObjectConvDecoder(Module):
     """The mirrored decoder (models.py:633-665, equally non-functional there): ``Linear`` to the encoder's last feature map, then transposed
     convolutions of the reversed topology, ``output_padding`` chosen so that the encoder's sizes are retraced (2 -> 2 -> 6 -> 13 -> 28),
     no activation after the last one.  Each ConvTranspose2d runs on the HIP implicit-GEMM kernel as a stride-1 convolution of the
-    zero-upsampled, (k-1)-padded input with the flipped kernel.  Opt-in, parity unpinned, inference helper."""
+    zero-upsampled, (k-1)-padded input with the flipped kernel (stand-alone inference helper; inside the SPAIR step the layers run on
+    csrc/objconv.hip and are trained, the output channels being the sprite's (colour.., alpha) logits per pixel).  Opt-in, parity unpinned."""
 
     def __init__(self, input_size, output_channel, encoder_shapes=None, topology=None):
         super().__init__()
@@ -313,7 +315,7 @@ class ObjectConvDecoder(Module):
         for i, layer in enumerate(reversed(topo)):
             _, k, st = _topology_conv_args(layer)
             target = encoder_shapes[len(topo) - 1 - i]
-            f = target[0]
+            f = output_channel if i == len(topo) - 1 else target[0]     # (the encoder's own input has `chan` channels, the sprite chan + 1)
             op = target[1] - ((h - 1) * st + k)
             assert 0 <= op < max(st, 1) or (st == 1 and op == 0), "topology cannot be mirrored"
             net['conv_transposed_%d' % i] = nn.ConvTranspose2d(n_prev, f, kernel_size=k, stride=st, output_padding=op)

@@ -91,6 +91,48 @@ def test_flat_layout_matches_module():
     assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
 
 
+def test_flat_layout_of_the_conv_object_variant():
+    """SpairDims.obj_conv: object_encoder / object_decoder are the convolutional pair of CONV_OBJECT_ENCODER_TOPOLOGY (config.py:15-20;
+    parity unpinned, models.py:606-665 cannot run) -- same naming contract (every module parameter has a slot of its shape), the decoder
+    parameters in the first gradient bucket, the encoder's in the second; the bf16 step refuses the variant."""
+    _fresh_cfg()
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd.models import SPAIR, make_dims
+    m = SPAIR([1, 128, 128], None, torch.device("cpu"), compute_dtype="f32", object_encoder="conv")
+    d = m._dims(4)
+    assert d.obj_conv == 1 and d.oc_n == 4 and list(d.oc_k) == [4, 3, 3, 1] and list(d.oc_s) == [2, 2, 2, 1]
+    lib = L.lib()
+    named = dict(m.named_parameters())
+    n = lib.spair_param_count(ctypes.byref(d))
+    assert n == len(named)
+    name = ctypes.create_string_buffer(128)
+    off, ndim, shape = ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+    offs, end = {}, 0
+    for i in range(n):
+        assert lib.spair_param_info(ctypes.byref(d), i, name, 128, ctypes.byref(off), shape, ctypes.byref(ndim)) == 0
+        key = name.value.decode()
+        shp = tuple(shape[k] for k in range(ndim.value))
+        assert tuple(named[key].shape) == shp, key
+        assert off.value % 4 == 0 and off.value >= end
+        end = off.value + int(np.prod(shp))
+        offs[key] = off.value
+    assert tuple(named["object_encoder.out.weight"].shape) == (100, 128)
+    assert tuple(named["object_decoder.conv.conv_transposed_3.weight"].shape) == (32, 2, 4, 4)
+    lo, hi = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
+    assert lib.spair_grad_buckets(ctypes.byref(d), lo, hi) == 0
+    for key, o in offs.items():
+        if key.startswith("object_decoder."):
+            assert lo[0] <= o < hi[0], key
+        if key.startswith("object_encoder."):
+            assert lo[1] <= o < hi[1], key
+    lib.spair_workspace_bytes.restype = ctypes.c_int64
+    assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
+    d.dtype = 1
+    assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
+    with pytest.raises(L.SpairHipError):
+        SPAIR([1, 128, 128], None, torch.device("cpu"), compute_dtype="bf16", object_encoder="conv")
+
+
 def test_no_cpu_fallback():
     _fresh_cfg()
     from spair_pytorch_amd import _lib as L

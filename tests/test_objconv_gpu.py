@@ -1,0 +1,171 @@
+"""The convolutional object encoder / decoder variant (SpairDims.obj_conv, csrc/objconv.hip).
+
+PARITY UNPINNED against the reference: its ObjectConvEncoder / ObjectConvDecoder (models.py:606-665) cannot run.  What is checked:
+the direct convolution kernels against torch's conv2d / conv_transpose2d and their autograd gradients, the whole fp32 step with the
+variant on against the CPU oracle's restatement of the same topology (forward terms and every gradient tensor, by autograd), and that
+training with it lowers the loss."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+from oracle import spair_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOPO = [(32, 4, 2), (32, 3, 2), (32, 3, 2), (32, 1, 1)]
+
+
+def t6(rs, ys, xs, cs, H, C):
+    return (ctypes.c_longlong * 6)(rs, ys, xs, cs, H, C)
+
+
+def hwc(H, C):
+    return t6(H * H * C, H * C, C, 1, H, C)
+
+
+def chw(H, C):
+    return t6(H * H * C, H, 1, H * H, H, C)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,hin", [(1, 32, 4, 2, 28), (32, 32, 3, 2, 13), (32, 32, 3, 2, 6), (32, 32, 1, 1, 2), (3, 24, 5, 3, 17)])
+def test_conv2d_forward_and_gradients(cin, cout, k, s, hin):
+    from spair_pytorch_amd import _lib as L
+    lib = L.lib()
+    R = 37
+    g = torch.Generator().manual_seed(cin * 100 + k)
+    x = torch.randn(R, cin, hin, hin, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.2).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_()
+    y = F.relu(F.conv2d(x, w, b, stride=s))
+    hout = y.shape[-1]
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty(R, hout, hout, cout, device="cuda")
+    wd, bd = w.detach().cuda(), b.detach().cuda()
+    L.check(lib.spair_objconv_gather(0, L.ptr(xd), hwc(hin, cin), L.ptr(wd), L.ptr(bd), L.ptr(out), hwc(hout, cout),
+                                     None, k, s, 1, ctypes.c_longlong(R), L.stream()), "gather")
+    assert (out.cpu().permute(0, 3, 1, 2) - y.detach()).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    # gradient of the pre-activation (what the step stores), then data and weight gradients
+    dpre = (dy * (y.detach() > 0)).permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.full((R, hin, hin, cin), 7.0, device="cuda")
+    L.check(lib.spair_objconv_gather(1, L.ptr(dpre), hwc(hout, cout), L.ptr(wd), None, L.ptr(dx), hwc(hin, cin), None, k, s, 0, ctypes.c_longlong(R), L.stream()), "dgrad")
+    assert (dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max().item() <= 2e-5 * x.grad.abs().max().item()
+    gw = torch.zeros_like(wd)
+    gb = torch.zeros(cout, device="cuda")
+    L.check(lib.spair_objconv_wgrad(L.ptr(dpre), hwc(hout, cout), L.ptr(xd), hwc(hin, cin), L.ptr(gw), L.ptr(gb), k, s, ctypes.c_longlong(R), L.stream()), "wgrad")
+    assert (gw.cpu() - w.grad).abs().max().item() <= 3e-5 * w.grad.abs().max().item()
+    assert (gb.cpu() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("cin,cout,k,s,hin,op", [(32, 32, 1, 1, 2, 0), (32, 32, 3, 2, 2, 1), (32, 32, 3, 2, 6, 0), (32, 2, 4, 2, 13, 0)])
+def test_conv_transpose2d_forward_and_gradients(cin, cout, k, s, hin, op):
+    from spair_pytorch_amd import _lib as L
+    lib = L.lib()
+    R = 29
+    g = torch.Generator().manual_seed(cin + 7 * k + hin)
+    x = torch.randn(R, cin, hin, hin, generator=g).relu().requires_grad_()     # a post-ReLU activation: its zeros gate the data gradient
+    w = (torch.randn(cin, cout, k, k, generator=g) * 0.2).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_()
+    y = F.conv_transpose2d(x, w, b, stride=s, output_padding=op)
+    hout = y.shape[-1]
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # input in (C,H,W) order (the decoder's Linear output), output NHWC
+    xd = x.detach().contiguous().cuda()
+    out = torch.empty(R, hout, hout, cout, device="cuda")
+    wd, bd = w.detach().cuda(), b.detach().cuda()
+    L.check(lib.spair_objconv_gather(1, L.ptr(xd), chw(hin, cin), L.ptr(wd), L.ptr(bd), L.ptr(out), hwc(hout, cout), None, k, s, 0, ctypes.c_longlong(R), L.stream()), "convT")
+    assert (out.cpu().permute(0, 3, 1, 2) - y.detach()).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.empty(R, cin, hin, hin, device="cuda")
+    L.check(lib.spair_objconv_gather(0, L.ptr(dyd), hwc(hout, cout), L.ptr(wd), None, L.ptr(dx), chw(hin, cin), L.ptr(xd), k, s, 0, ctypes.c_longlong(R), L.stream()), "convT dgrad")
+    want = x.grad * (x.detach() > 0)
+    assert (dx.cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    gw = torch.zeros_like(wd)
+    L.check(lib.spair_objconv_wgrad(L.ptr(xd), chw(hin, cin), L.ptr(dyd), hwc(hout, cout), L.ptr(gw), None, k, s, ctypes.c_longlong(R), L.stream()), "convT wgrad")
+    assert (gw.cpu() - w.grad).abs().max().item() <= 3e-5 * w.grad.abs().max().item()
+
+
+def _conv_model(I, strides, seed):
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd.models import SPAIR
+    cfg.set_grid(I, strides)
+    torch.manual_seed(seed)
+    return SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype="f32", object_encoder="conv").to("cuda")
+
+
+def test_variant_refuses_the_bf16_step():
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd.models import SPAIR
+    with pytest.raises(L.SpairHipError):
+        SPAIR([1, 48, 48], None, torch.device("cuda"), compute_dtype="bf16", object_encoder="conv")
+
+
+@pytest.mark.parametrize("I,B,step", [(48, 4, 1), (48, 3, 1500)])
+def test_step_with_conv_object_networks_matches_autograd(I, B, step):
+    from spair_pytorch_amd.data import scattered_digits
+    strides = (2, 2, 2, 1, 1, 1)
+    m = _conv_model(I, strides, seed=5)
+    G = gi.grid_side(I, strides)
+    names = [k for k, _ in m.named_parameters()]
+    assert "object_encoder.conv.conv_0.weight" in names and "object_decoder.conv.conv_transposed_3.weight" in names
+    assert "object_encoder.dense0.weight" not in names
+    x_np = scattered_digits(21, B, I, 4)[0]
+    noise_np = gi.make_noise(9, B, G)
+    x = torch.from_numpy(x_np).cuda()
+    noise = {k: torch.from_numpy(v).cuda() for k, v in noise_np.items()}
+    m.zero_grad()
+    loss, recon, z_where, z_pres = m(x, step, noise=noise)
+    terms = m.loss_terms().cpu().numpy()
+    loss.backward()
+    # the oracle's restatement of the same topology, gradients by autograd
+    p = {k: v.detach().cpu().clone().requires_grad_(not k.startswith("attn.")) for k, v in m.state_dict().items()}
+    cfg_o = orc.OracleConfig(image_shape=(1, I, I), conv_strides=strides, object_conv=TOPO)
+    out = orc.forward(p, torch.from_numpy(x_np), step, {k: torch.from_numpy(v) for k, v in noise_np.items()}, cfg_o)
+    out["loss"].backward()
+    assert abs(terms[0] - out["loss"].item()) <= 2e-5 * abs(out["loss"].item())
+    assert abs(terms[1] - out["terms"]["recon"].item()) <= 2e-5 * out["terms"]["recon"].item()
+    assert (recon.cpu() - out["recon_x"].detach()).abs().max().item() <= 2e-4
+    assert (z_where.cpu() - out["z_where"].detach()).abs().max().item() <= 1e-4
+    assert (z_pres.cpu() - out["z_pres"].detach()).abs().max().item() <= 1e-4
+    assert (m.export_map(0).cpu() - out["z_attr"].detach()).abs().max().item() <= 1e-4 * max(1.0, out["z_attr"].abs().max().item())
+    bad = []
+    for k, q in m.named_parameters():
+        if k.startswith("attn."):
+            continue
+        g, ref = q.grad.cpu().double(), p[k].grad.double()
+        err = (g - ref).abs().max().item()
+        if err > 2e-3 * ref.abs().max().item() + 1e-6:
+            bad.append((k, err, ref.abs().max().item()))
+    assert not bad, bad
+    for k in ("object_encoder.conv.conv_0.weight", "object_decoder.conv.conv_transposed_3.weight", "object_decoder.inp.bias"):
+        assert p[k].grad.abs().max().item() > 0, k          # (the comparison above is not of zeros)
+
+
+def test_training_with_conv_object_networks_lowers_the_loss():
+    from spair_pytorch_amd.data import scattered_digits
+    from spair_pytorch_amd.optim import FusedAdam
+    I, B, strides = 48, 16, (2, 2, 2, 1, 1, 1)
+    m = _conv_model(I, strides, seed=3)
+    opt = FusedAdam(m, lr=1e-3)
+    x = torch.from_numpy(scattered_digits(4, B, I, 4)[0]).cuda()
+    G = gi.grid_side(I, strides)
+    noise = {k: torch.from_numpy(v).cuda() for k, v in gi.make_noise(2, B, G).items()}      # fixed draws: the loss is a function of the parameters
+    losses = []
+    for it in range(30):
+        m.zero_grad()
+        loss = m(x, 1, noise=noise)[0]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all()
+    assert losses[1] < losses[0], losses             # one optimizer step already lowers it
+    assert losses[-1] < 0.9 * losses[0], losses
+    before = m.state_dict()["object_encoder.conv.conv_1.weight"].clone()
+    m.zero_grad(); m(x, 1, noise=noise)[0].backward(); opt.step()
+    assert (m.state_dict()["object_encoder.conv.conv_1.weight"] - before).abs().max().item() > 0      # the conv parameters are trained

@@ -47,3 +47,9 @@ for key in ("mix", "mma"):
         d = (a[:, c] - b[:, c]).abs(); i = int(d.argmax())
         print("%s: max|taps| %.4g  max err %.4g (rel %.3g) at object %d | rms rel %.3g" % (
             nm, b[:, c].abs().max(), d.max(), d.max() / b[:, c].abs().max(), i, (d.pow(2).mean().sqrt() / b[:, c].pow(2).mean().sqrt())))
+a, b = res["mma"], res["taps"]
+for c, nm in enumerate(("tx", "ty", "xs", "ys")):
+    sel = b[:, c].abs() > 0.02 * b[:, c].abs().max()
+    ratio = a[sel, c] / b[sel, c]
+    print(nm, "ratio mma/taps over %d objects: quantiles 5/25/50/75/95 %%:" % int(sel.sum()), [round(float(v), 4) for v in torch.quantile(ratio, torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95]))],
+          " sum ratio %.5f" % (a[:, c].sum() / b[:, c].sum()), " norm ratio %.5f" % (a[:, c].norm() / b[:, c].norm()))
