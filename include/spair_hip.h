@@ -50,6 +50,11 @@ typedef struct SpairDims {
      * object_decoder.conv.conv_transposed_<i>.* (ConvTranspose2d layout [in][out][k][k]). */
     int obj_conv, oc_n;
     int oc_k[4], oc_s[4], oc_c[4];
+    /* N_LOOKBACK (config.py:31, models.py:292-320): a cell's lateral context is the 2L(L+1) already-visited cells of rows h-L..h,
+     * columns w-L..w+L, in the reference's order (row-major, the current cell and those to its right dropped); out-of-grid slots read
+     * the learned edge element.  0 is read as 1 (the reference's configuration: UL, U, UR, L).  L != 1 runs on the per-wavefront
+     * launches (dependency wavefronts t = (L+1) h + w); the fused per-cell kernels are built for L = 1.  1 <= L <= 3. */
+    int lookback;
 } SpairDims;
 
 /* Per-step scalars (host side evaluates the two schedules, modules.py:191-213). */

@@ -259,9 +259,10 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
             ci = h * G + w
             cell_feat = feat[:, :, h, w]
             # context: UL, U, UR, L (models.py:292-320)
-            ctx = torch.cat([rec.get((h - 1, w - 1), edge), rec.get((h - 1, w), edge),
-                             rec.get((h - 1, w + 1), edge) if w + 1 < G else edge,
-                             rec.get((h, w - 1), edge)], dim=-1)
+            # rows h-L..h, columns w-L..w+L in row-major order, without the current cell and its right-hand side (L = 1: UL, U, UR, L)
+            Lb = cfg.n_lookback
+            ctx = torch.cat([rec.get((h + dh, w + dw), edge) if 0 <= w + dw < G else edge
+                             for dh in range(-Lb, 1) for dw in range(-Lb, (Lb if dh else -1) + 1)], dim=-1)
             # --- z_where (models.py:76-79,322-381)
             lat, passthru = _mlp(p, "box_network", torch.cat([cell_feat, ctx], -1), multi=True)
             mean, std = latent_to_mean_std(lat)

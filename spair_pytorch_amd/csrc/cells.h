@@ -51,7 +51,7 @@ struct CellBufs {
     float* dfeat;
 };
 
-int cells_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start, hipStream_t s);
+int cells_init_tables(int G, int LB, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start, hipStream_t s);
 int cells_ctx_gather(const CellLayout& L, const CellBufs& P, int r0, int R, hipStream_t s);
 int cells_box_sample(const CellLayout& L, const CellBufs& P, const CellHyper& H, int r0, int R, hipStream_t s);
 int cells_attr_sample(const CellLayout& L, const CellBufs& P, int r0, int R, hipStream_t s);

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(128) void k_ctx_gather(CellLayout L, CellBufs P, in
             v = frow[col];
         } else {
             const int s = (col - L.F) / L.REC, j = (col - L.F) - s * L.REC;
-            const int nb = P.nbr[cp * 4 + s];
+            const int nb = P.nbr[cp * L.NB + s];
             v = nb >= 0 ? P.rec[((size_t)nb * L.B + b) * L.ld_rec + j] : P.edge[j];
         }
         P.Xb[(size_t)r * L.ld_xb + col] = v;
@@ -127,9 +127,8 @@ __global__ __launch_bounds__(256) void k_bwd_pres(CellLayout L, CellBufs P, Cell
     float gsum_pres = 0.f;
     for (int j = lane; j < L.REC; j += 64) {
         float g = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int q = P.cons[cp * 4 + s];
+        for (int s = 0; s < L.NB; ++s) {
+            const int q = P.cons[cp * L.NB + s];
             if (q < 0) continue;
             const size_t qr = (size_t)q * L.B + b;
             const int col = L.x_ctx + s * L.REC + j;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void k_dfeat_edge(CellLayout L, CellBufs P, in
             if (s < 0) {
                 const int h = P.cell_h[cp], w = P.cell_w[cp];
                 P.dfeat[((size_t)(b * L.G + h) * L.G + w) * P.ld_feat + c] = v;
-            } else if (P.nbr[cp * 4 + s] < 0) {
+            } else if (P.nbr[cp * L.NB + s] < 0) {
                 acc += v;
             }
         }
@@ -234,43 +233,49 @@ __global__ __launch_bounds__(256) void k_dfeat_edge(CellLayout L, CellBufs P, in
 }
 
 // ---- tables: wavefront order, neighbours, consumers -----------------------------------------
-__global__ __launch_bounds__(1024) void k_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start) {
-    __shared__ int dstart[3 * 32 + 2];
-    const int T = 3 * G - 2, HW = G * G;
+// LB = N_LOOKBACK: cell (h, w) reads rows h-LB..h, columns w-LB..w+LB of the cells before it, so t = (LB+1) h + w is a dependency order
+// (its latest input, (h-1, w+LB), has t - 1); LB = 1 gives the 3G-2 anti-diagonals of UL, U, UR, L.
+__global__ __launch_bounds__(1024) void k_init_tables(int G, int LB, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start) {
+    __shared__ int dstart[5 * 32 + 2];
+    const int S = LB + 1, T = S * (G - 1) + G, HW = G * G, NB = 2 * LB * S;
     if (threadIdx.x == 0) {
         int c = 0;
         for (int t = 0; t < T; ++t) {
             dstart[t] = c;
-            const int hlo = max(0, (t - (G - 1) + 1) / 2), hhi = min(G - 1, t / 2);   // 0 <= t-2h < G
+            const int hlo = max(0, (t - (G - 1) + S - 1) / S), hhi = min(G - 1, t / S);   // 0 <= t - S h < G
             c += max(0, hhi - hlo + 1);
         }
         dstart[T] = c;
     }
     __syncthreads();
     for (int t = threadIdx.x; t <= T; t += blockDim.x) diag_start[t] = dstart[t];
-    // wavefront index of cell (h,w): cells of diagonal t = 2h+w are ordered by ascending h
+    // wavefront index of cell (h,w): cells of wavefront t = S h + w are ordered by ascending h
     auto cp_of = [&](int h, int w) {
-        const int t = 2 * h + w;
-        const int hlo = max(0, (t - (G - 1) + 1) / 2);
+        const int t = S * h + w;
+        const int hlo = max(0, (t - (G - 1) + S - 1) / S);
         return dstart[t] + (h - hlo);
     };
-    const int dh[4] = {-1, -1, -1, 0}, dw[4] = {-1, 0, 1, -1};   // UL, U, UR, L (models.py:297-304)
     for (int k = threadIdx.x; k < HW; k += blockDim.x) {
         const int h = k / G, w = k - h * G;
         const int c = cp_of(h, w);
         cell_h[c] = h; cell_w[c] = w; cidx[k] = c;
-        for (int s = 0; s < 4; ++s) {
-            const int nh = h + dh[s], nw = w + dw[s];
-            nbr[c * 4 + s] = (nh >= 0 && nh < G && nw >= 0 && nw < G) ? cp_of(nh, nw) : -1;
-            const int qh = h - dh[s], qw = w - dw[s];   // the cell that sees (h,w) in slot s
-            cons[c * 4 + s] = (qh >= 0 && qh < G && qw >= 0 && qw < G) ? cp_of(qh, qw) : -1;
-        }
+        // slots in the reference's order (models.py:297-304): rows -LB..0, columns -LB..LB, without the current cell and its right side
+        // (LB = 1: UL, U, UR, L)
+        int s = 0;
+        for (int dh = -LB; dh <= 0; ++dh)
+            for (int dw = -LB; dw <= (dh ? LB : -1); ++dw, ++s) {
+                const int nh = h + dh, nw = w + dw;
+                nbr[c * NB + s] = (nh >= 0 && nh < G && nw >= 0 && nw < G) ? cp_of(nh, nw) : -1;
+                const int qh = h - dh, qw = w - dw;   // the cell that sees (h,w) in slot s
+                cons[c * NB + s] = (qh >= 0 && qh < G && qw >= 0 && qw < G) ? cp_of(qh, qw) : -1;
+            }
     }
 }
 
 // ---- host launchers -------------------------------------------------------------------------
-int cells_init_tables(int G, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_tables, dim3(1), dim3(1024), 0, s, G, cell_h, cell_w, cidx, nbr, cons, diag_start);
+int cells_init_tables(int G, int LB, int* cell_h, int* cell_w, int* cidx, int* nbr, int* cons, int* diag_start, hipStream_t s) {
+    if (G > 32 || LB < 1 || LB > 3) return SPAIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_init_tables, dim3(1), dim3(1024), 0, s, G, LB, cell_h, cell_w, cidx, nbr, cons, diag_start);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

@@ -1557,7 +1557,7 @@ int chain_edge_reduce(const ChainArgs& a, hipStream_t s) {
 }
 
 int chain_fwd_supported(const SpairDims& d) {
-    return d.dtype == SPAIR_BF16 && d.F == F && d.A == A_ && d.NP == NP && d.P == 28 && d.C == 1 && d.G <= 32 &&
+    return d.dtype == SPAIR_BF16 && d.lookback <= 1 && !d.obj_conv && d.F == F && d.A == A_ && d.NP == NP && d.P == 28 && d.C == 1 && d.G <= 32 &&
            (d.G + 1) / 2 <= MT && d.G >= 2;
 }
 

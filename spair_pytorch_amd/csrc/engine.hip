@@ -121,6 +121,8 @@ static int validate(const SpairDims& d) {
     }
     if (h != d.G) return SPAIR_ERR_SHAPE;
     if (d.G * d.G + 1 > 1025) return SPAIR_ERR_UNSUPPORTED;
+    if (d.lookback < 0 || d.lookback > 3) return SPAIR_ERR_UNSUPPORTED;
+    if (d.lookback > 1 && d.G > 32) return SPAIR_ERR_UNSUPPORTED;
     if (d.obj_conv) {   // convolutional object encoder / decoder variant: fp32 step, per-wavefront launches (objconv.hip)
         if (d.dtype != SPAIR_F32) return SPAIR_ERR_UNSUPPORTED;
         if (d.oc_n < 1 || d.oc_n > 4) return SPAIR_ERR_SHAPE;
@@ -192,7 +194,7 @@ static Ws carve(const SpairDims& d, void* base) {
     const size_t es = d.dtype == SPAIR_BF16 ? 2 : 4;
     const size_t N = (size_t)L.N;
     w.cell_h = c.take<int>(L.HW); w.cell_w = c.take<int>(L.HW); w.cidx = c.take<int>(L.HW);
-    w.nbr = c.take<int>(4 * L.HW); w.cons = c.take<int>(4 * L.HW); w.diag_start = c.take<int>(3 * L.G + 2);
+    w.nbr = c.take<int>(L.NB * L.HW); w.cons = c.take<int>(L.NB * L.HW); w.diag_start = c.take<int>((L.LB + 2) * L.G + 2);
     // prepared weights
     for (int i = 1; i < PL.n_conv; ++i) {
         const ConvSpec& cs = PL.conv[i];
@@ -449,13 +451,14 @@ static int stream_link(hipStream_t from, hipStream_t to, hipEvent_t e) {
 
 static void fill_diag(Ctx& c) {
     const int G = c.d.G;
-    c.T = 3 * G - 2;
+    const int S = c.L.LB + 1;             // dependency wavefronts t = (N_LOOKBACK + 1) h + w (cells.hip, k_init_tables)
+    c.T = S * (G - 1) + G;
     c.dstart.assign(c.T + 1, 0);
     int n = 0;
     for (int t = 0; t < c.T; ++t) {
         c.dstart[t] = n;
         for (int h = 0; h < G; ++h) {
-            const int w = t - 2 * h;
+            const int w = t - S * h;
             if (w >= 0 && w < G) ++n;
         }
     }
@@ -1113,7 +1116,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             ProfScope ps(PS_PREP, c.s);
             TRY(prep_weights(c, st->train != 0, 0));       // conv weights first: conv_1 waits for these only
             if (side && hipEventRecord(side->ev[3], side->s) != hipSuccess) return SPAIR_ERR_LAUNCH;
-            TRY(cells_init_tables(d->G, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
+            TRY(cells_init_tables(d->G, c.L.LB, c.w.cell_h, c.w.cell_w, c.w.cidx, c.w.nbr, c.w.cons, c.w.diag_start, c.s));
             if (st->draw_noise)
                 TRY(spair_noise_fill(d, st->noise_seed, const_cast<float*>(eps_box), const_cast<float*>(eps_attr), const_cast<float*>(eps_depth),
                                      const_cast<float*>(u_pres), c.s));

@@ -19,7 +19,8 @@
 struct CellLayout {
     int B, G, HW, N;            // N = B*HW
     int F, A, NP, REC;          // backbone features, attrs, passthrough, record width (4+A+2)
-    int CTX;                    // 4*REC
+    int LB, NB;                 // N_LOOKBACK and its 2*LB*(LB+1) context neighbours
+    int CTX;                    // NB*REC
     // column offsets inside the X buffers (reference concat order, models.py:76,88,100)
     int x_ctx, x_pass, x_box, x_attr, x_depth;
     int ld_xb, ld_x;            // leading dims of Xb (F+CTX padded) and Xz/Xo
@@ -35,7 +36,8 @@ struct CellLayout {
 static inline CellLayout make_cell_layout(const SpairDims& d) {
     CellLayout L;
     L.B = d.B; L.G = d.G; L.HW = d.G * d.G; L.N = d.B * L.HW;
-    L.F = d.F; L.A = d.A; L.NP = d.NP; L.REC = 4 + d.A + 2; L.CTX = 4 * L.REC;
+    L.F = d.F; L.A = d.A; L.NP = d.NP; L.REC = 4 + d.A + 2;
+    L.LB = d.lookback > 0 ? d.lookback : 1; L.NB = 2 * L.LB * (L.LB + 1); L.CTX = L.NB * L.REC;
     L.x_ctx = L.F; L.x_pass = L.F + L.CTX; L.x_box = L.x_pass + L.NP; L.x_attr = L.x_box + 4;
     L.x_depth = L.x_attr + L.A;
     L.ld_xb = round_up(L.F + L.CTX, 8);

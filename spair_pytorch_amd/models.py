@@ -41,7 +41,7 @@ class SpairDims(ctypes.Structure):
                 ("alpha_logit_scale", ctypes.c_float), ("alpha_logit_bias", ctypes.c_float),
                 ("vae_beta", ctypes.c_float), ("prior_mean", ctypes.c_float * 6), ("prior_std", ctypes.c_float * 6),
                 ("obj_conv", ctypes.c_int), ("oc_n", ctypes.c_int), ("oc_k", ctypes.c_int * 4), ("oc_s", ctypes.c_int * 4),
-                ("oc_c", ctypes.c_int * 4)]
+                ("oc_c", ctypes.c_int * 4), ("lookback", ctypes.c_int)]
 
 
 class SpairStep(ctypes.Structure):
@@ -56,7 +56,7 @@ STEP_FLAGS = int(os.environ.get("SPAIR_STEP_FLAGS", "0"))
 _DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
 
-def make_dims(batch, image_shape, topology, dtype=None, object_conv_topology=None):
+def make_dims(batch, image_shape, topology, dtype=None, object_conv_topology=None, lookback=1):
     """``object_conv_topology``: the layer list of the convolutional object encoder / decoder variant (``None`` = the MLP pair)."""
     from .modules import backbone_geometry, _topology_conv_args
     d = SpairDims()
@@ -78,6 +78,7 @@ def make_dims(batch, image_shape, topology, dtype=None, object_conv_topology=Non
     d.vae_beta = float(cfg.VAE_BETA)
     for i, n in enumerate(DIST_NAMES):
         d.prior_mean[i], d.prior_std[i] = float(cfg.PRIORS[n][0]), float(cfg.PRIORS[n][1])
+    d.lookback = int(lookback)
     if object_conv_topology is not None:
         if len(object_conv_topology) > 4:
             raise L.SpairHipError("the convolutional object encoder takes at most 4 layers")
@@ -163,8 +164,9 @@ class SPAIR(nn.Module):
                                   "kernels are built for the MLP encoder / decoder)")
         self.world_size = 1          # set by spair_pytorch_amd.ddp for the sharded loss
         self.context_dim = (cfg.N_LOOKBACK * 2 + 1) ** 2 // 2 * (4 + cfg.N_ATTRIBUTES + 1 + 1)
-        if cfg.N_LOOKBACK != 1:
-            raise L.SpairHipError("only N_LOOKBACK=1 (4 neighbours, the reference configuration) is implemented")
+        self.lookback = int(cfg.N_LOOKBACK)
+        if not 1 <= self.lookback <= 3:
+            raise L.SpairHipError("N_LOOKBACK must be 1, 2 or 3 (4, 12 or 24 context neighbours)")
         self._build_networks()
         self._build_edge_element()
         self._build_indep_prior()
@@ -219,7 +221,7 @@ class SPAIR(nn.Module):
 
     # ---- flat parameter / gradient buffers ---------------------------------------------------------
     def _dims(self, batch):
-        return make_dims(batch, self.image_shape, self.backbone.topology, self.compute_dtype, self.object_conv_topology)
+        return make_dims(batch, self.image_shape, self.backbone.topology, self.compute_dtype, self.object_conv_topology, self.lookback)
 
     def _flatten(self):
         """(Re)build the flat buffers on ``self.device`` and re-point every Parameter into them."""

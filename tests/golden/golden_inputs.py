@@ -15,10 +15,15 @@ N_BACKBONE_FEATURES = 100
 N_PASSTHROUGH = 100
 N_ATTR = 50
 OBJ_PX = 28
-CONTEXT_DIM = 4 * (4 + N_ATTR + 1 + 1)  # 224
+CONTEXT_DIM = 4 * (4 + N_ATTR + 1 + 1)  # 224 (N_LOOKBACK = 1)
 
 
-def param_shapes(in_chan=1, conv_kernels=(4, 4, 4, 1, 1, 1), filters=128):
+def context_dim(lookback=1):
+    """models.py:26: ((2L+1)^2 // 2) records of 4 + A + 2."""
+    return (2 * lookback + 1) ** 2 // 2 * (4 + N_ATTR + 1 + 1)
+
+
+def param_shapes(in_chan=1, conv_kernels=(4, 4, 4, 1, 1, 1), filters=128, lookback=1):
     """Ordered {key: shape} for every tensor of the reference state_dict."""
     s = {}
     s["virtual_edge_element"] = (4 + N_ATTR + 2,)
@@ -45,6 +50,7 @@ def param_shapes(in_chan=1, conv_kernels=(4, 4, 4, 1, 1, 1), filters=128):
             s[f"{prefix}.out.weight"] = (outs, p)
             s[f"{prefix}.out.bias"] = (outs,)
 
+    CONTEXT_DIM = context_dim(lookback)
     box_in = N_BACKBONE_FEATURES + CONTEXT_DIM
     mlp("box_network", box_in, (100, 100), (8, N_PASSTHROUGH), True)
     mlp("object_encoder", OBJ_PX * OBJ_PX * in_chan, (256, 128), 2 * N_ATTR, False)
@@ -59,12 +65,12 @@ def param_shapes(in_chan=1, conv_kernels=(4, 4, 4, 1, 1, 1), filters=128):
     return s
 
 
-def make_weights(seed, scale=1.0, in_chan=1):
+def make_weights(seed, scale=1.0, in_chan=1, lookback=1):
     """U(-1/sqrt(fan_in), 1/sqrt(fan_in)) * scale per tensor (PyTorch-default-like
     magnitude), float32.  Returns {key: np.ndarray}."""
     rng = np.random.default_rng(seed)
     out = {}
-    shapes = param_shapes(in_chan)
+    shapes = param_shapes(in_chan, lookback=lookback)
     for key, shp in shapes.items():
         if key == "virtual_edge_element":
             t = rng.standard_normal(shp).astype(np.float32)
@@ -134,6 +140,12 @@ CASES = {
     "ref_default_b2_step1001": dict(I=128, strides=(3, 2, 2, 1, 1, 1), B=2, step=1001, wseed=14, wscale=1.5, max_objects=11),
     # configs[3] geometry (256x256, 32x32 grid) as a B=1 slice
     "c4_b1_step1001": dict(I=256, strides=(2, 2, 2, 1, 1, 1), B=1, step=1001, wseed=15, wscale=1.0, max_objects=11),
+}
+# N_LOOKBACK = 2 (config.py:31; 12 context neighbours, models.py:292-320): kept apart from CASES -- the fused bf16 kernels are built for
+# N_LOOKBACK = 1, these run on the per-wavefront launches (tests/test_lookback_gpu.py)
+LOOKBACK_CASES = {
+    "lb2_c1_b4_step1001": dict(I=48, strides=(2, 2, 2, 1, 1, 1), B=4, step=1001, wseed=16, wscale=1.0, max_objects=3, lookback=2),
+    "lb2_i80_b2_step1": dict(I=80, strides=(2, 2, 2, 1, 1, 1), B=2, step=1, wseed=17, wscale=1.5, max_objects=5, lookback=2),
 }
 
 

@@ -133,6 +133,34 @@ def test_flat_layout_of_the_conv_object_variant():
         SPAIR([1, 128, 128], None, torch.device("cpu"), compute_dtype="bf16", object_encoder="conv")
 
 
+def test_flat_layout_with_lookback_2():
+    """N_LOOKBACK = 2 (config.py:31): 12 context records -> box network input 100 + 672, z / obj inputs wider by the same 448."""
+    _fresh_cfg()
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd import _lib as L
+    from spair_pytorch_amd.models import SPAIR
+    cfg.N_LOOKBACK = 2
+    try:
+        m = SPAIR([1, 128, 128], None, torch.device("cpu"))
+        d = m._dims(4)
+        assert d.lookback == 2
+        lib = L.lib()
+        named = dict(m.named_parameters())
+        name = ctypes.create_string_buffer(128)
+        off, ndim, shape = ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i in range(lib.spair_param_count(ctypes.byref(d))):
+            assert lib.spair_param_info(ctypes.byref(d), i, name, 128, ctypes.byref(off), shape, ctypes.byref(ndim)) == 0
+            assert tuple(named[name.value.decode()].shape) == tuple(shape[k] for k in range(ndim.value)), name.value
+        assert tuple(named["box_network.body.dense0.weight"].shape) == (100, 772)
+        assert tuple(named["obj_network.dense0.weight"].shape) == (100, 4 + 50 + 100 + 672 + 100 + 1)
+        lib.spair_workspace_bytes.restype = ctypes.c_int64
+        assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
+        d.lookback = 4
+        assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
+    finally:
+        cfg.N_LOOKBACK = 1
+
+
 def test_no_cpu_fallback():
     _fresh_cfg()
     from spair_pytorch_amd import _lib as L

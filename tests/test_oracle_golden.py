@@ -9,7 +9,7 @@ from helpers import KL_NAMES, case_noise, case_weights, load_case, oracle_cfg
 from oracle import spair_oracle as orc
 
 # c4 (32x32 grid, 1024 sequential cells) is the slow one: ~1 min
-CASES = list(gi.CASES)
+CASES = list(gi.CASES) + list(gi.LOOKBACK_CASES)      # (the N_LOOKBACK = 2 fixtures pin the generalised context gather)
 
 
 def rel(a, b):
