@@ -11,6 +11,7 @@
 // Everything the backward pass and the weight-gradient GEMMs need is written to the same HBM row
 // buffers the per-wavefront path produces, so the two paths are interchangeable (and are compared
 // against each other in tests/test_chain_gpu.py).
+#include <type_traits>
 #include "cell_math.h"
 #include "chain.h"
 #include "stn_math.h"
@@ -179,6 +180,55 @@ __device__ __forceinline__ void wg_gemm_t(const __bf16* inA, int ldA, const __bf
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[f % RD]), x[f], acc, 0, 0, 0);
         if (f + RD < KT) p.q[f % RD] = base[(size_t)(f + RD) * 64];
     }
+}
+
+// EARLY PRODUCTS (round 5).  Z0 and OBJ0 multiply [feat | ctx | pass | box | attr (| depth)]: the first KC = 352 columns (11 of their 16
+// k-steps) have been in LDS since the wavefront's S0 stage, and every GEMM stage takes its pack bytes at ~105 GB/s of L1 fill (the two
+// stages: 112 KiB = 1.05 us each).  Those 11 k-steps of BOTH layers (they share the activation fragments) are multiplied inside the glimpse
+// sampling stage instead, which streams no packs: timing-only removal of them priced the move at 1.65 us of a 15.8-us wavefront.  The
+// partial sums travel in two accumulators; the Z0 / OBJ0 stages start from them and run their last KTOT - KSKIP k-steps (wg_gemm_tk).
+// Same products in the same order as the undivided stage: results are bit-identical.
+template <int KTOT, int KSKIP, int NT>
+__device__ __forceinline__ void pipe_fill_k(const uint4* __restrict__ Wp, WPipe& p, int wave, int lane) {
+    const uint4* base = tile_base<KTOT, NT, 0>(Wp, wave, lane) + (size_t)KSKIP * 64;
+#pragma unroll
+    for (int f = 0; f < KTOT - KSKIP; ++f) p.q[f] = base[f * 64];
+}
+template <int KTOT, int KSKIP>
+__device__ __forceinline__ void wg_gemm_tk(const __bf16* inB, int ldB, WPipe& p, f32x4& acc, int lane) {
+    constexpr int KT = KTOT - KSKIP;
+    static_assert(KT <= RD, "the remaining fragments sit in the ring");
+    const __bf16* pb = inB + (lane & 15) * ldB + (lane >> 4) * 8;
+    bf16x8 x[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) x[kt] = *reinterpret_cast<const bf16x8*>(pb + kt * 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < KT; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[f]), x[f], acc, 0, 0, 0);
+}
+// ring <- k-steps [K0, K0 + N) of the two layers' tiles, slot 2 j = layer A, 2 j + 1 = layer B (N <= RD / 2)
+template <int KTOT, int NT, int K0, int N>
+__device__ __forceinline__ void early_fill(const uint4* __restrict__ Wa, const uint4* __restrict__ Wb, WPipe& p, int wave, int lane) {
+    static_assert(2 * N <= RD, "two fragments per k-step");
+    const uint4* ba = tile_base<KTOT, NT, 0>(Wa, wave, lane) + (size_t)K0 * 64;
+    const uint4* bb = tile_base<KTOT, NT, 0>(Wb, wave, lane) + (size_t)K0 * 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { p.q[2 * j] = ba[j * 64]; p.q[2 * j + 1] = bb[j * 64]; }
+}
+template <int N>
+__device__ __forceinline__ void early_mfma(const bf16x8 (&x)[N], const WPipe& p, f32x4& accA, f32x4& accB) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[2 * j]), x[j], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(p.q[2 * j + 1]), x[j], accB, 0, 0, 0);
+    }
+}
+// stores through a buffer descriptor, non-temporal (see CH_GSTORE); a masked lane passes BUF_OOB
+__device__ __forceinline__ void buf_store8_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned lo, unsigned hi) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{lo, hi}, r, (int)byte_off, 0, 2);
+}
+__device__ __forceinline__ void buf_store16_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 2);
 }
 
 // Two column tiles per wave (tiles `wave` and `wave + 8`: the encoder's 256-wide first layer) sharing every activation fragment; the K loop
@@ -630,7 +680,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             copy_rows_w<25, 8>(Hb, LD_H * 2, P.Hb2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
             copy_rows_w<(F + CTX + 4) / 8, 16>(Xc, LD_XC * 2, P.Xb, (size_t)L.ld_xb * 2, rr_cur, nc, lane);      // (beside wave 6's latent pass)
         }
-        pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
+        if constexpr (IMG) early_fill<16, 7, 0, 6>(a.w[CW_Z0], a.w[CW_OBJ0], pipe, wave, lane);      // early products, first six k-steps
+        else pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
         // ---- box latents (models.py:322-381): one latent per lane of wave 6; lane k of a row owns z_k -> (cell_y, cell_x, height, width)[k]
         // -> box / nbox element k ^ 1.  LDS only: records, stats and the box reach HBM through the store wave.
         if (wave == 6) {
@@ -679,7 +730,10 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         const float gmult = a.ac ? 0.5f * (float)(a.I - 1) : 0.5f * (float)a.I;      // d(source pixel coordinate) / d(normalised coordinate) where not clipped
-        for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) {
+        // four glimpse elements (one row i, columns j0..j0+3 of one cell): bilinear taps, value + the two coordinate derivatives.
+        // `buffered`: the HBM stores go through buffer descriptors with `live` as the lane mask (see the early products below)
+        const __amdgpu_buffer_rsrc_t rs_gl = buf_rsrc(P.glimpse), rs_gxy = buf_rsrc(P.gxy);
+        auto sample4 = [&](int idx, bool live, auto buffered) {
             const int row = idx / (GLN / 4), e = (idx - row * (GLN / 4)) * 4;
             const int i = e / PG, j0 = e - i * PG;              // P % 4 == 0: the 4 elements share the row i
             const uint2 ye = gtab[row][1][i];
@@ -716,9 +770,60 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             }
             bf16x4 o;
             o[0] = (__bf16)out[0]; o[1] = (__bf16)out[1]; o[2] = (__bf16)out[2]; o[3] = (__bf16)out[3];
-            *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;
-            CH_GSTORE(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)rr_cur[row] * L.ld_gl + e), o);
-            CH_GSTORE(reinterpret_cast<u32x4_t*>(P.gxy + (size_t)rr_cur[row] * L.ld_gl + e), ((u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]}));
+            *reinterpret_cast<bf16x4*>(&Gl[row * LD_GL + e]) = o;      // (a masked lane re-computes the stage's last element: same value, same address)
+            if constexpr (decltype(buffered)::value) {
+                const unsigned eo = (unsigned)rr_cur[row] * (unsigned)L.ld_gl + (unsigned)e;      // every row buffer is < 4 GB
+                const u32x2_t ob = __builtin_bit_cast(u32x2_t, o);
+                buf_store8_nt(rs_gl, live ? eo * 2u : BUF_OOB, ob.x, ob.y);
+                buf_store16_nt(rs_gxy, live ? eo * 4u : BUF_OOB, (u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]});
+            } else {
+                CH_GSTORE(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.glimpse) + (size_t)rr_cur[row] * L.ld_gl + e), o);
+                CH_GSTORE(reinterpret_cast<u32x4_t*>(P.gxy + (size_t)rr_cur[row] * L.ld_gl + e), ((u32x4_t){gxy[0], gxy[1], gxy[2], gxy[3]}));
+            }
+        };
+        f32x4 accZ = {0.f, 0.f, 0.f, 0.f}, accO = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (IMG) {
+            // The sampling rounds with the early products of Z0 / OBJ0 between them (see wg_gemm_tk).  A round is wave-uniform code without
+            // lane predication: lanes past the stage's last element re-compute it and mask their HBM stores through the descriptor, a round
+            // past the end issues the two stores fully masked -- every path carries the same number of memory operations, so the waits
+            // for the weight fragments stay counted (vmcnt(n)) instead of collapsing to vmcnt(0) at each join, which would also wait for
+            // the acknowledgement of the round's own stores.
+            const int lim = __builtin_amdgcn_readfirstlane(nc) * (GLN / 4);
+            auto round = [&](int it) {
+                if (it * NTH + wave * 64 < lim) sample4(min(tid + it * NTH, lim - 1), tid + it * NTH < lim, std::true_type{});      // (per wave)
+                else {      // (masked: the data operand is whatever is live)
+                    const u32x4_t junk = __builtin_bit_cast(u32x4_t, accZ);
+                    buf_store8_nt(rs_gl, BUF_OOB, junk.x, junk.y);
+                    buf_store16_nt(rs_gxy, BUF_OOB, junk);
+                }
+            };
+            const int ntz = min(wave, 6);
+            const __bf16* pxc = Xc + (lane & 15) * LD_XC + (lane >> 4) * 8;
+            accZ = *reinterpret_cast<const f32x4*>(bias_sh + BIAS_OFF[CW_Z0] + ntz * 16 + (lane >> 4) * 4);
+            accO = *reinterpret_cast<const f32x4*>(bias_sh + BIAS_OFF[CW_OBJ0] + ntz * 16 + (lane >> 4) * 4);
+            // (the activation fragments are read behind each round, not ahead of it: 24 registers live across a sampling round spilled, and
+            //  a spill reload inside the round waits -- in-order vmcnt -- for every weight fragment issued before it)
+            round(0);
+            {
+                bf16x8 xe[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) xe[j] = *reinterpret_cast<const bf16x8*>(pxc + j * 32);
+                early_mfma<6>(xe, pipe, accZ, accO);
+            }
+            early_fill<16, 7, 6, 5>(a.w[CW_Z0], a.w[CW_OBJ0], pipe, wave, lane);
+            round(1);
+            round(2);
+            {
+                bf16x8 xe[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) xe[j] = *reinterpret_cast<const bf16x8*>(pxc + (6 + j) * 32);
+                early_mfma<5>(xe, pipe, accZ, accO);
+            }
+            pipe_fill2<25>(a.w[CW_ENC0], pipe, wave, lane);
+            round(3);
+            for (int idx = tid + 4 * NTH; idx < lim; idx += NTH) sample4(idx, true, std::false_type{});      // (more than 10 cells per wavefront: not with G <= 16)
+        } else {
+            for (int idx = tid; idx < nc * (GLN / 4); idx += NTH) sample4(idx, true, std::false_type{});
         }
         lds_barrier();
         CH_STAMP();
@@ -742,7 +847,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ENC2], pipe, bias_sh + BIAS_OFF[CW_ENC2], acc, wave, lane);
-            pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
+            if constexpr (IMG) pipe_fill_k<16, 11, 7>(a.w[CW_Z0], pipe, wave, lane);
+            else pipe_fill<16, 7>(a.w[CW_Z0], pipe, wave, lane);
             wg_store_t<7, false>(acc, 2 * A_, nullptr, 0, 0, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         }
         lds_barrier();
@@ -766,7 +872,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // rows -- the attr columns of the same tile, their two pad columns being the tile's zero depth / pad slots -- and sd_attr)
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, bias_sh + BIAS_OFF[CW_Z0], acc, wave, lane);
+            if constexpr (IMG) { acc = accZ; wg_gemm_tk<16, 11>(XtZ, LD_XT, pipe, acc, lane); }
+            else wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtZ, LD_XT, a.w[CW_Z0], pipe, bias_sh + BIAS_OFF[CW_Z0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_Z1], pipe, wave, lane);
             wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HZ1 * 4);
         } else {
@@ -790,7 +897,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         if (wave < 7) {
             f32x4 acc;
             wg_gemm_t<4, 0, 7>(Hb, LD_H, nullptr, 0, a.w[CW_ZH], pipe, bias_sh + BIAS_OFF[CW_ZH], acc, wave, lane);
-            pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
+            if constexpr (IMG) pipe_fill_k<16, 11, 7>(a.w[CW_OBJ0], pipe, wave, lane);
+            else pipe_fill<16, 7>(a.w[CW_OBJ0], pipe, wave, lane);
             wg_store_t<7, false>(acc, NP + 4, XtO, LD_XT, NP, Ost, LD_O, nullptr, 0, rr_cur, nc, wave, lane);
         } else {
             copy_rows_w<25, 8>(Hb, LD_H * 2, P.Hz2, (size_t)SP_LDH * 2, rr_cur, nc, lane);
@@ -814,7 +922,8 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         // ---- z_pres (models.py:100-102,393-411); the store wave: z head rows, the obj-net's input tail [pass | box | attr | depth]
         if (wave < 7) {
             f32x4 acc;
-            wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, bias_sh + BIAS_OFF[CW_OBJ0], acc, wave, lane);
+            if constexpr (IMG) { acc = accO; wg_gemm_tk<16, 11>(XtO, LD_XT, pipe, acc, lane); }
+            else wg_gemm_t<11, 5, 7>(Xc, LD_XC, XtO, LD_XT, a.w[CW_OBJ0], pipe, bias_sh + BIAS_OFF[CW_OBJ0], acc, wave, lane);
             pipe_fill<4, 7>(a.w[CW_OBJ1], pipe, wave, lane);
             wg_store_t<7, true>(acc, 100, Ha, LD_H, 100, nullptr, 0, nullptr, 0, rr_cur, nc, wave, lane, mbt + MB_HO1 * 4);
         } else {
