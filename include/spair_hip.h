@@ -109,7 +109,10 @@ int spair_backward_ev(const SpairDims* d, const SpairStep* st, const float* para
 int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                float beta1, float beta2, float eps, int step, void* stream);
 /* Copy a per-row quantity of the last forward into an NCHW map [B,ch,G,G].
- * which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 their sigma, 14 count-prior p_z */
+ * which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 their sigma, 14 count-prior p_z;
+ * after a backward, its per-cell latent gradients: 100 d box head latents [8] (mean 4 | log-std 4), 101 d encoder output [2A], 102 d depth
+ * latents [2], 103 d presence logit [1] as the per-wavefront launches store them (fp32 rows); 200..203 the same as the fused chain stores
+ * them (bf16 rows) */
 int spair_export_map(const SpairDims* d, const void* workspace, int which, float* out, void* stream);
 /* diagnostic: stage time stamps of the fused forward chain kernel (SpairStep.flags bit 1), n <= 4096 uint64 */
 int spair_chain_stamps(const SpairDims* d, const void* workspace, unsigned long long* out, int n, void* stream);

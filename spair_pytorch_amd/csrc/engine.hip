@@ -1548,6 +1548,15 @@ extern "C" int spair_export_map(const SpairDims* d, const void* workspace, int w
     else if (which == 12) { src = P.sd_attr; ld = L.ld_rec; col0 = 0; ch = L.A; }
     else if (which == 13) { src = P.stat; ld = SP_LDSTAT; col0 = ST_SD_DEPTH; ch = 1; }
     else if (which == 14) { src = P.stat; ld = SP_LDSTAT; col0 = ST_PZ; ch = 1; }
+    else if (which >= 100 && which < 104 || which >= 200 && which < 204) {
+        // the last BACKWARD's per-cell latent gradients (tests: the fused chain against the per-wavefront launches, cell by cell)
+        const int k = which % 100;
+        if (k == 0) { src = P.dOb; ld = L.ld_ob; col0 = L.ob_lat; ch = 8; }
+        else if (k == 1) { src = P.dOe; ld = L.ld_oe; col0 = 0; ch = 2 * L.A; }
+        else if (k == 2) { src = P.dOz; ld = L.ld_oz; col0 = L.oz_lat; ch = 2; }
+        else { src = P.dOo; ld = L.ld_oo; col0 = 0; ch = 1; }
+        if (which >= 200) return misc_export16(src, ld, col0, ch, w.cell_h, w.cell_w, d->B, d->G, out, s);
+    }
     else return SPAIR_ERR_SHAPE;
     return misc_export(src, ld, col0, ch, w.cell_h, w.cell_w, d->B, d->G, out, s);
 }

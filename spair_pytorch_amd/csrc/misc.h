@@ -18,6 +18,7 @@ struct PrepTable {
 int misc_pad_input(const float* x, float* xp, int B, int C, int I, int pre, int Ip, hipStream_t s);
 int misc_prep(const PrepTable& T, hipStream_t s);
 int misc_export(const float* src, int ld, int col0, int ch, const int* cell_h, const int* cell_w, int B, int G, float* out, hipStream_t s);
+int misc_export16(const void* src, int ld, int col0, int ch, const int* cell_h, const int* cell_w, int B, int G, float* out, hipStream_t s);
 // x: the unpadded image [B,1,I,I] (read directly when misc_conv0_reads_unpadded), xp: its zero-padded copy [B,Hin,Hin,C] (the general path)
 bool misc_conv0_reads_unpadded(int B, int Hin, int C, int k, int Cout);
 int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float* bias, float* out, int B, int I, int pre, int Hin, int C, int k, int s,

@@ -167,6 +167,24 @@ __global__ __launch_bounds__(256) void k_export(const float* __restrict__ src, i
     const int cp = (int)(r / B), b = (int)(r - (long long)cp * B);
     out[(((size_t)b * ch + c) * G + cell_h[cp]) * G + cell_w[cp]] = src[r * ld + col0 + c];
 }
+// the same from a row buffer stored as bf16 (the fused chain's gradient rows: same leading dimension in ELEMENTS)
+__global__ __launch_bounds__(256) void k_export16(const __bf16* __restrict__ src, int ld, int col0, int ch, const int* __restrict__ cell_h,
+                                                  const int* __restrict__ cell_w, int B, int G, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * G * G * ch;
+    if (idx >= total) return;
+    const int c = (int)(idx % ch);
+    const long long r = idx / ch;
+    const int cp = (int)(r / B), b = (int)(r - (long long)cp * B);
+    out[(((size_t)b * ch + c) * G + cell_h[cp]) * G + cell_w[cp]] = (float)src[r * ld + col0 + c];
+}
+int misc_export16(const void* src, int ld, int col0, int ch, const int* cell_h, const int* cell_w, int B, int G, float* out, hipStream_t s) {
+    const long long total = (long long)B * G * G * ch;
+    hipLaunchKernelGGL(k_export16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(src), ld, col0, ch,
+                       cell_h, cell_w, B, G, out);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
 int misc_export(const float* src, int ld, int col0, int ch, const int* cell_h, const int* cell_w, int B, int G, float* out,
                 hipStream_t s) {
     const long long total = (long long)B * G * G * ch;

@@ -463,7 +463,7 @@ class SPAIR(nn.Module):
         """Per-cell quantity of the last forward as an NCHW map (see spair_export_map)."""
         e = self._last_engine()
         d = e['dims']
-        ch = d.A if which in (0, 6, 12) else 1
+        ch = d.A if which in (0, 6, 12) else {0: 8, 1: 2 * d.A, 2: 2, 3: 1}[which % 100] if which >= 100 else 1
         out = torch.empty(d.B, ch, d.G, d.G, device=self.device, dtype=torch.float32)
         L.check(L.lib().spair_export_map(ctypes.byref(d), L.ptr(e['workspace']), int(which), L.ptr(out), L.stream()), "spair_export_map")
         return out
