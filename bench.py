@@ -231,7 +231,9 @@ def stn_fwd_from_stamps(model, step_fn, d, B, dtype, chain_fwd_ms):
     return dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, avg_ms=None, stage_ms=ms_, traffic=None,
                 share_of_chain_fwd=share,
                 note="fused stage of k_chain_fwd (no launch of its own): stage share from in-kernel s_memtime stamps of sample 0 x the kernel's "
-                     "event time; the stamping workgroup runs this stage %d times" % T)
+                     "event time; the stamping workgroup runs this stage %d times.  Since round 5 the stage also hosts the early products of "
+                     "Z0 / OBJ0 on images up to 128 px (22 MFMAs per wave, ~0.8 of its 3.6 us by sub-stamps, DESIGN 4.1): stage_ms is an upper "
+                     "bound on the sampling's own time" % T)
 
 
 def _sha16(path):
