@@ -146,6 +146,7 @@ CASES = {
 LOOKBACK_CASES = {
     "lb2_c1_b4_step1001": dict(I=48, strides=(2, 2, 2, 1, 1, 1), B=4, step=1001, wseed=16, wscale=1.0, max_objects=3, lookback=2),
     "lb2_i80_b2_step1": dict(I=80, strides=(2, 2, 2, 1, 1, 1), B=2, step=1, wseed=17, wscale=1.5, max_objects=5, lookback=2),
+    "lb3_c1_b3_step7001": dict(I=48, strides=(2, 2, 2, 1, 1, 1), B=3, step=7001, wseed=18, wscale=1.0, max_objects=3, lookback=3),
 }
 
 

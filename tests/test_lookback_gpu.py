@@ -1,5 +1,5 @@
-"""N_LOOKBACK = 2 (config.py:31; models.py:292-320: 12 context neighbours instead of 4) against fixtures produced by the reference itself
-(tests/golden/lb2_*.npz, make_golden.py).  The fused per-cell kernels are built for N_LOOKBACK = 1; other values run on the per-wavefront
+"""N_LOOKBACK = 2 and 3 (config.py:31; models.py:292-320: 12 / 24 context neighbours instead of 4) against fixtures produced by the reference itself
+(tests/golden/lb2_*.npz, lb3_*.npz, make_golden.py).  The fused per-cell kernels are built for N_LOOKBACK = 1; other values run on the per-wavefront
 launches with dependency wavefronts t = (L+1) h + w."""
 import numpy as np
 import pytest
@@ -38,7 +38,8 @@ def rel(a, b):
 def test_fp32_step_with_lookback_2_matches_reference(name, lookback_cfg):
     z, case = load_case(name)
     m = build(case, "f32", lookback_cfg)
-    assert m.context_dim == 12 * 56 and tuple(m.state_dict()["box_network.body.dense0.weight"].shape) == (100, 100 + 672)
+    nb = 2 * case["lookback"] * (case["lookback"] + 1)
+    assert m.context_dim == nb * 56 and tuple(m.state_dict()["box_network.body.dense0.weight"].shape) == (100, 100 + nb * 56)
     x = torch.from_numpy(z["x"]).cuda()
     noise = {k: torch.from_numpy(z[k]).cuda() for k in ("eps_box", "eps_attr", "eps_depth", "u_pres")}
     m.zero_grad()
