@@ -45,7 +45,8 @@ typedef struct SpairDims {
      * classes but cannot run them: PARITY UNPINNED).  obj_conv = 1 replaces the MLP encoder by oc_n valid convolutions (filters oc_c,
      * kernel oc_k, stride oc_s, ReLU after each) + Linear(flattened (C,H,W) -> 2A), and the MLP decoder by Linear(A -> flattened) + the
      * mirrored ConvTranspose2d stack (output_padding retraces the encoder's sizes; ReLU between, none after the last; its C+1 output
-     * channels are the sprite's (colour.., alpha) logits).  fp32 step only (dtype SPAIR_DTYPE_F32), per-wavefront launches.  Parameter
+     * channels are the sprite's (colour.., alpha) logits).  Per-wavefront launches in either dtype; the convolutions themselves and the
+     * sprites they produce are fp32 (the bf16 step keeps bf16 GEMM operands for the backbone, the other per-cell nets and the two Linears).  Parameter
      * names: object_encoder.conv.conv_<i>.{weight,bias}, object_encoder.out.*, object_decoder.inp.*,
      * object_decoder.conv.conv_transposed_<i>.* (ConvTranspose2d layout [in][out][k][k]). */
     int obj_conv, oc_n;

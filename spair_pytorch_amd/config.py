@@ -72,7 +72,7 @@ COMPUTE_DTYPE = os.environ.get('SPAIR_DTYPE', 'bf16')
 # torch>=1.3 semantics (what the CPU oracle is pinned to); True reproduces the torch-1.0 era.
 ALIGN_CORNERS = False
 # 'mlp': the reference's live object encoder / decoder (models.py:152,165).  'conv': the pair built from CONV_OBJECT_ENCODER_TOPOLOGY
-# that models.py:606-665 sketches but cannot run -- trainable here on the fp32 step (COMPUTE_DTYPE 'f32'), parity unpinned.
+# that models.py:606-665 sketches but cannot run -- trainable here (per-wavefront launches, either COMPUTE_DTYPE), parity unpinned.
 OBJECT_ENCODER = os.environ.get('SPAIR_OBJECT_ENCODER', 'mlp')
 
 

@@ -123,8 +123,7 @@ static int validate(const SpairDims& d) {
     if (d.G * d.G + 1 > 1025) return SPAIR_ERR_UNSUPPORTED;
     if (d.lookback < 0 || d.lookback > 3) return SPAIR_ERR_UNSUPPORTED;
     if (d.lookback > 1 && d.G > 32) return SPAIR_ERR_UNSUPPORTED;
-    if (d.obj_conv) {   // convolutional object encoder / decoder variant: fp32 step, per-wavefront launches (objconv.hip)
-        if (d.dtype != SPAIR_F32) return SPAIR_ERR_UNSUPPORTED;
+    if (d.obj_conv) {   // convolutional object encoder / decoder variant: per-wavefront launches, the convolutions themselves in fp32 (objconv.hip)
         if (d.oc_n < 1 || d.oc_n > 4) return SPAIR_ERR_SHAPE;
         int hh = d.P, ci = d.C;
         for (int i = 0; i < d.oc_n; ++i) {
@@ -265,7 +264,7 @@ static Ws carve(const SpairDims& d, void* base) {
     b.mbits = chain_fwd_supported(d) ? c.take<unsigned long long>((size_t)d.B * nbands * (3 * d.G - 2) * 66 * 4) : nullptr;
     w.Hd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es)); w.Hd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es));
     w.S = c.take<float>(N * w.ld_s);
-    w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * es));
+    w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * (d.obj_conv ? 4 : es)));      // (the conv decoder takes fp32 sprite gradients in both modes)
     w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
     w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
     b.Za16 = w.Za16; b.dfeat16 = w.dfeat16;
@@ -1147,7 +1146,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         TRY(loss_gauss_kl(L, P, c.H, c.w.kl_partial, ks));
         if (side && hipEventRecord(side->ev[1], ks) != hipSuccess) return SPAIR_ERR_LAUNCH;
     }
-    if (d->dtype == SPAIR_BF16 && d->C == 1) {
+    if (d->dtype == SPAIR_BF16 && d->C == 1 && !d->obj_conv) {      // (the conv decoder's sprites are fp32: tap renderer)
         rc_prep = render_prep(P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.rrec, d->B, L.HW, d->I, d->P, d->align_corners, c.s);
         if (rc_prep != SPAIR_OK && rc_prep != SPAIR_ERR_UNSUPPORTED) return rc_prep;
     }
@@ -1200,7 +1199,7 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
         }
         if (rc == SPAIR_ERR_UNSUPPORTED)
             rc = render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
-                            c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16, c.s);
+                            c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16 && !d->obj_conv, c.s);
         TRY(rc);
     }
     if (side && hipStreamWaitEvent(c.s, side->ev[1], 0) != hipSuccess) return SPAIR_ERR_LAUNCH;
@@ -1358,15 +1357,19 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         ProfScope ps(PS_RENDER_BWD, c.s);
         TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
-                       d->alpha_logit_scale, b16, b16,
-                       b16 && d->C == 1 && render_prep_supported(L.HW, d->I, d->P, d->align_corners) ? c.w.rrec : nullptr, c.s));
+                       d->alpha_logit_scale, b16 && !d->obj_conv, b16 && !d->obj_conv,
+                       b16 && !d->obj_conv && d->C == 1 && render_prep_supported(L.HW, d->I, d->P, d->align_corners) ? c.w.rrec : nullptr, c.s));
     }
     SideStream* side = nullptr;
     if (!(st->flags & 4)) TRY(side_stream(side));
     std::unique_lock<std::mutex> enq_lock;
     if (side) enq_lock = std::unique_lock<std::mutex>(side->enq_mu);
     hipStream_t const main_s = c.s;
-    if (b16) {   // decoder, bf16-stored activations and gradients: the data-gradient chain stays on the caller's stream, the three
+    if (PL.oc_n) {
+        ProfScope ps(PS_DECODER_BWD, c.s);
+        TRY(oc_decoder_bwd(c, grads));
+        TRY(record_ready(ev_decoder, c.s));
+    } else if (b16) {   // decoder, bf16-stored activations and gradients: the data-gradient chain stays on the caller's stream, the three
                  // weight gradients go to the helper stream and overlap with the (latency-bound) per-cell backward chain
         const LinSpec &l2 = PL.lin[LIN_DEC2], &l1 = PL.lin[LIN_DEC1], &l0 = PL.lin[LIN_DEC0];
         {
@@ -1398,10 +1401,6 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         }
         TRY(record_ready(ev_decoder, c.s));
         if (side) { c.s = main_s; c.tn_scratch = nullptr; }
-    } else if (PL.oc_n) {
-        ProfScope ps(PS_DECODER_BWD, c.s);
-        TRY(oc_decoder_bwd(c, grads));
-        TRY(record_ready(ev_decoder, c.s));
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }

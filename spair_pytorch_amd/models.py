@@ -149,7 +149,8 @@ class SPAIR(nn.Module):
     def __init__(self, image_shape, writer=None, device=None, compute_dtype=None, object_encoder=None):
         """``object_encoder``: 'mlp' (the reference's live configuration, models.py:152,165) or 'conv' -- the convolutional encoder /
         decoder pair of ``cfg.CONV_OBJECT_ENCODER_TOPOLOGY`` (config.py:15-20) that models.py:606-665 sketches but cannot run
-        (parity unpinned); default ``cfg.OBJECT_ENCODER``.  The conv pair trains on the fp32 step (``compute_dtype='f32'``)."""
+        (parity unpinned); default ``cfg.OBJECT_ENCODER``.  The conv pair runs on the per-wavefront launches in either compute dtype (its
+        own convolutions in fp32; the fused bf16 per-cell kernels are built for the MLP pair)."""
         super().__init__()
         self.object_encoder_kind = (object_encoder or cfg.OBJECT_ENCODER).lower()
         if self.object_encoder_kind not in ('mlp', 'conv'):
@@ -159,9 +160,6 @@ class SPAIR(nn.Module):
         self.B = 1
         self.device = torch.device(device) if device is not None else torch.device('cuda')
         self.compute_dtype = (compute_dtype or cfg.COMPUTE_DTYPE).lower()
-        if self.object_encoder_kind == 'conv' and _DTYPES.get(self.compute_dtype) != 0:
-            raise L.SpairHipError("object_encoder='conv' runs on the fp32 step only: pass compute_dtype='f32' (the fused bf16 per-cell "
-                                  "kernels are built for the MLP encoder / decoder)")
         self.world_size = 1          # set by spair_pytorch_amd.ddp for the sharded loss
         self.context_dim = (cfg.N_LOOKBACK * 2 + 1) ** 2 // 2 * (4 + cfg.N_ATTRIBUTES + 1 + 1)
         self.lookback = int(cfg.N_LOOKBACK)

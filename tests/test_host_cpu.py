@@ -94,7 +94,7 @@ def test_flat_layout_matches_module():
 def test_flat_layout_of_the_conv_object_variant():
     """SpairDims.obj_conv: object_encoder / object_decoder are the convolutional pair of CONV_OBJECT_ENCODER_TOPOLOGY (config.py:15-20;
     parity unpinned, models.py:606-665 cannot run) -- same naming contract (every module parameter has a slot of its shape), the decoder
-    parameters in the first gradient bucket, the encoder's in the second; the bf16 step refuses the variant."""
+    parameters in the first gradient bucket, the encoder's in the second."""
     _fresh_cfg()
     from spair_pytorch_amd import _lib as L
     from spair_pytorch_amd.models import SPAIR, make_dims
@@ -127,10 +127,10 @@ def test_flat_layout_of_the_conv_object_variant():
             assert lo[1] <= o < hi[1], key
     lib.spair_workspace_bytes.restype = ctypes.c_int64
     assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
-    d.dtype = 1
+    d.dtype = 1                     # the bf16 step takes the variant too (per-wavefront launches)
+    assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
+    d.oc_n = 5
     assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
-    with pytest.raises(L.SpairHipError):
-        SPAIR([1, 128, 128], None, torch.device("cpu"), compute_dtype="bf16", object_encoder="conv")
 
 
 def test_flat_layout_with_lookback_2():
