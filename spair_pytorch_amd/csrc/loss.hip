@@ -11,16 +11,19 @@
 // One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane, held as PAIRS for
 // the packed fp32 pipe), so a step is register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
 // G = 32, where this kernel, not the decoder beside it, set the forward's length).
-template <int NBR>
-__global__ __launch_bounds__(256) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
-    __shared__ float z_sh[4][KL_MAXBINS - 1];
-    __shared__ float pz_sh[4][KL_MAXBINS - 1];
+// WPB waves (= samples) per workgroup.  The kernel runs on the helper stream beside the decoder and the forward renderer; its waves are single
+// dependent chains that take issue slots from whatever shares their SIMD.  Four per workgroup (one per SIMD of a quarter of the CUs) is the
+// measured optimum at 16 x 16 cells, B = 256: 16 / 8 / 4 / 2 / 1 waves per workgroup = step 3.289 / 3.246 / 3.221 / 3.274 / 3.336 ms -- packed, the
+// kernel itself becomes the longest thing beside the decoder (0.24 ms); spread, every CU's renderer waves share a SIMD with it.
+template <int NBR, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
+    extern __shared__ float kl_sh[];          // [WPB][2][HW]: z_pres in cell order, p_z
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wave;
+    const int b = blockIdx.x * WPB + wave;
     if (b >= L.B) return;
-    float* zs = z_sh[wave];
-    float* pzs = pz_sh[wave];
     const int HW = L.HW, NB = HW + 1;
+    float* zs = kl_sh + (size_t)wave * 2 * HW;
+    float* pzs = zs + HW;
     // all of this sample's z_pres in row-major cell order: no global access inside the sequential loop
     for (int i = lane; i < HW; i += 64) zs[i] = P.rec[((size_t)P.cidx[i] * L.B + b) * L.ld_rec + L.REC - 1];
     // geometric count distribution (1-p) p^k, normalised (models.py:190-193)
@@ -180,10 +183,17 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
 
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s) {
     if (L.HW + 1 > KL_MAXBINS) return SPAIR_ERR_UNSUPPORTED;
-    const dim3 grid(ceil_div(L.B, 4));
-    if (L.HW + 1 <= 5 * 64) hipLaunchKernelGGL(k_count_kl<5>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
-    else if (L.HW + 1 <= 9 * 64) hipLaunchKernelGGL(k_count_kl<9>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
-    else hipLaunchKernelGGL(k_count_kl<17>, grid, dim3(256), 0, s, L, P, prior_prob, klp);
+#ifndef KL_WPB_SMALL
+#define KL_WPB_SMALL 4
+#endif
+    if (L.HW + 1 <= 5 * 64) {
+        constexpr int W = KL_WPB_SMALL;
+        hipLaunchKernelGGL((k_count_kl<5, W>), dim3(ceil_div(L.B, W)), dim3(W * 64), (size_t)W * 2 * L.HW * sizeof(float), s, L, P, prior_prob, klp);
+    } else if (L.HW + 1 <= 9 * 64) {
+        hipLaunchKernelGGL((k_count_kl<9, 4>), dim3(ceil_div(L.B, 4)), dim3(256), (size_t)4 * 2 * L.HW * sizeof(float), s, L, P, prior_prob, klp);
+    } else {
+        hipLaunchKernelGGL((k_count_kl<17, 4>), dim3(ceil_div(L.B, 4)), dim3(256), (size_t)4 * 2 * L.HW * sizeof(float), s, L, P, prior_prob, klp);
+    }
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }
