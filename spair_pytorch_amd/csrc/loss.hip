@@ -11,6 +11,23 @@
 // One wave per sample; the (HW+1)-bin count distribution lives in REGISTERS (bin e = k*64 + lane, NBR bins per lane, held as PAIRS for
 // the packed fp32 pipe), so a step is register math + two DPP wave reductions (with the bins in LDS each step paid two LDS round trips per bin: 2.2 us per step at
 // G = 32, where this kernel, not the decoder beside it, set the forward's length).
+// 1 / x: v_rcp_f32 + one Newton step (<= 1 ulp for normal x; the IEEE division sequence is ~12 instructions of the ~130 a cell costs)
+__device__ __forceinline__ float kl_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);
+}
+// Wave sum through the gfx9 row-broadcast DPP forms: four adds give every lane its 16-lane row's sum, row_bcast:15 / row_bcast:31 carry the
+// sums up the rows, lane 63 holds the total -- 6 DPP adds + 1 v_readlane instead of 4 + 4 readlanes + 3 adds (wave_reduce_sum, common.h)
+__device__ __forceinline__ float kl_wave_sum(float v) {
+    v = dpp_add_<0xB1>(v);
+    v = dpp_add_<0x4E>(v);
+    v = dpp_add_<0x141>(v);
+    v = dpp_add_<0x140>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));      // row_bcast:15 -> rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));      // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // WPB waves (= samples) per workgroup.  The kernel runs on the helper stream beside the decoder and the forward renderer; its waves are single
 // dependent chains that take issue slots from whatever shares their SIMD.  Four per workgroup (one per SIMD of a quarter of the CUs) is the
 // measured optimum at 16 x 16 cells, B = 256: 16 / 8 / 4 / 2 / 1 waves per workgroup = step 3.289 / 3.246 / 3.221 / 3.274 / 3.336 ms -- packed, the
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P,
     for (int i = 0; i < HW; ++i) {
         const float z = znext;
         znext = zs[min(i + 1, HW - 1)];
-        const float rem = (float)(HW - i), inv_rem = 1.f / rem;      // one IEEE division per step; x * (1/r) is within 1 ulp of x / r
+        const float rem = (float)(HW - i), inv_rem = kl_rcp(rem);    // x * (1/r) is within 1-2 ulp of x / r
         const bool on = rintf(z) != 0.f;   // torch.round: half to even
         const kl_f2 cnt2 = {count, count}, ir2 = {inv_rem, inv_rem};
         // the factor of c: q where the cell is on, 1 - q where it is off = sa * q + sb with wave-uniform (sa, sb) -- exact either way
@@ -74,9 +91,9 @@ __global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P,
             c2[k] = v;
             np2 += v;
         }
-        const float pz = wave_reduce_sum(pz2.x + pz2.y);
-        const float np = fmaxf(wave_reduce_sum(np2.x + np2.y), 1e-6f);
-        const float inv_np = 1.f / np;
+        const float pz = kl_wave_sum(pz2.x + pz2.y);
+        const float np = fmaxf(kl_wave_sum(np2.x + np2.y), 1e-6f);
+        const float inv_np = kl_rcp(np);
         const kl_f2 in2 = {inv_np, inv_np};
 #pragma unroll
         for (int k = 0; k < NP; ++k) c2[k] = c2[k] * in2;
