@@ -28,10 +28,73 @@ __device__ __forceinline__ float kl_wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- K8: the sequential count-prior KL (models.py:186-257) ----------------------------------------------------------------------------------
+// One wave per sample walks the HW cells in row-major order.  The count distribution lives in REGISTERS in RELATIVE form: bin j = (total
+// object count) - (objects seen so far), j = k * 64 + lane in register k.  In that form
+//   * the factor of a bin is q_j = j / rem (rem = cells left), no subtraction of the running count and no clamp: the bins outside [0, rem]
+//     are exactly the ones that hold no mass (a cell that is ON multiplies bin 0 by q_0 = 0 and then every bin moves down by one -- one
+//     wavefront-shift DPP move per register, on the few steps where a cell is on; a cell that is OFF multiplies bin `rem` by 1 - 1 = 0);
+//   * the number of registers that can hold mass, floor(rem / 64) + 1, depends on the step only, not on the data: the loop is a sequence of
+//     phases with NA = NBR, NBR - 1, ..., 1 active registers, each compiled for its own NA -- half the bin work on average, no branches.
+// (Absolute bins with clamps cost 9 instructions per pair of bins on all NBR registers of every step: 0.46 ms at 32 x 32 cells, where this
+//  kernel is exposed behind the chain)  The bins run as PAIRS on the packed fp32 pipe; only the last active register can hold
+// bins past `rem` (residues of 1 - rem * (1 / rem) ~ 1e-7): its factor is clamped to 1 so that they cannot grow.
 // WPB waves (= samples) per workgroup.  The kernel runs on the helper stream beside the decoder and the forward renderer; its waves are single
 // dependent chains that take issue slots from whatever shares their SIMD.  Four per workgroup (one per SIMD of a quarter of the CUs) is the
 // measured optimum at 16 x 16 cells, B = 256: 16 / 8 / 4 / 2 / 1 waves per workgroup = step 3.289 / 3.246 / 3.221 / 3.274 / 3.336 ms -- packed, the
 // kernel itself becomes the longest thing beside the decoder (0.24 ms); spread, every CU's renderer waves share a SIMD with it.
+typedef float kl_f2 __attribute__((ext_vector_type(2)));
+struct KlState { float znext, count_on; };
+
+template <int NA, int NP>
+__device__ __forceinline__ void kl_step(kl_f2 (&c2)[NP], const kl_f2 (&e2)[NP], const float* zs, float* pzs, int i, int HW, int lane, float& znext) {
+    constexpr int PA = (NA + 1) / 2;                 // active pairs
+    const float z = znext;
+    znext = zs[min(i + 1, HW - 1)];
+    const float rem = (float)(HW - i), inv_rem = kl_rcp(rem);      // x * (1/r) is within 1-2 ulp of x / r
+    const bool on = rintf(z) != 0.f;                 // torch.round: half to even
+    // the factor of c: q where the cell is on, 1 - q where it is off = sa * q + sb with wave-uniform (sa, sb) -- exact either way
+    const float sa = on ? 1.f : -1.f, sb = on ? 0.f : 1.f;
+    const kl_f2 ir2 = {inv_rem, inv_rem}, sa2 = {sa, sa}, sb2 = {sb, sb};
+    kl_f2 pz2 = {0.f, 0.f}, np2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PA; ++k) {
+        kl_f2 q = e2[k] * ir2;
+        if (k == (NA - 1) / 2) {                      // the last active register: bins past `rem`
+            if ((NA - 1) & 1) q.y = fminf(q.y, 1.f); else q.x = fminf(q.x, 1.f);
+        }
+        pz2 += c2[k] * q;
+        const kl_f2 v = (sa2 * q + sb2) * c2[k];
+        c2[k] = v;
+        np2 += v;
+    }
+    const float pz = kl_wave_sum(pz2.x + pz2.y);
+    const float np = fmaxf(kl_wave_sum(np2.x + np2.y), 1e-6f);
+    const float inv_np = kl_rcp(np);
+    const kl_f2 in2 = {inv_np, inv_np};
+#pragma unroll
+    for (int k = 0; k < PA; ++k) c2[k] = c2[k] * in2;
+    if (lane == 0) pzs[i] = pz;
+    if (on) {                                         // wave-uniform: every bin moves down by one (bin 0, now empty, drops out)
+        auto shl1 = [](float cur, float from_next) {      // lane l <- lane l + 1; lane 63 <- lane 0 of the next register
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, from_next), __builtin_bit_cast(int, cur), 0x130, 0xf, 0xf, false));
+        };
+        auto lane0 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)); };
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const float nxt = r + 1 < NA ? lane0((r + 1) & 1 ? c2[(r + 1) / 2].y : c2[(r + 1) / 2].x) : 0.f;
+            if (r & 1) c2[r / 2].y = shl1(c2[r / 2].y, nxt); else c2[r / 2].x = shl1(c2[r / 2].x, nxt);
+        }
+    }
+}
+template <int NA, int NP>
+__device__ __forceinline__ void kl_phase(kl_f2 (&c2)[NP], const kl_f2 (&e2)[NP], const float* zs, float* pzs, int HW, int lane, float& znext) {
+    // steps with floor((HW - i) / 64) + 1 == NA
+    const int lo = max(0, HW - 64 * NA + 1), hi = min(HW - 1, HW - 64 * (NA - 1));
+    for (int i = lo; i <= hi; ++i) kl_step<NA, NP>(c2, e2, zs, pzs, i, HW, lane, znext);
+    if constexpr (NA > 1) kl_phase<NA - 1, NP>(c2, e2, zs, pzs, HW, lane, znext);
+}
+
 template <int NBR, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P, float prior_prob, float* __restrict__ klp) {
     extern __shared__ float kl_sh[];          // [WPB][2][HW]: z_pres in cell order, p_z
@@ -57,12 +120,6 @@ __global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P,
 #pragma unroll
     for (int k = 0; k < NBR; ++k) c[k] = c[k] / norm0;
     wave_lds_fence();
-    float count = 0.f;
-    float znext = zs[0];
-    // The loop is a chain of ~140 dependent single-wave instructions per cell.  The bins run as PAIRS on the packed fp32 pipe (v_pk_add /
-    // v_pk_mul / v_pk_fma_f32: two bins per instruction; the clamp is one v_med3_f32 per bin, the on/off select a wave-uniform fma):
-    // same operations per bin as the scalar form, the two partial sums associate pairwise (configs[3]: 0.56 -> 0.43 ms)
-    typedef float kl_f2 __attribute__((ext_vector_type(2)));
     constexpr int NP = (NBR + 1) / 2;
     kl_f2 c2[NP], e2[NP];
 #pragma unroll
@@ -70,36 +127,8 @@ __global__ __launch_bounds__(WPB * 64) void k_count_kl(CellLayout L, CellBufs P,
         c2[k] = kl_f2{c[2 * k], 2 * k + 1 < NBR ? c[2 * k + 1] : 0.f};
         e2[k] = kl_f2{ef[2 * k], 2 * k + 1 < NBR ? ef[2 * k + 1] : 0.f};
     }
-    for (int i = 0; i < HW; ++i) {
-        const float z = znext;
-        znext = zs[min(i + 1, HW - 1)];
-        const float rem = (float)(HW - i), inv_rem = kl_rcp(rem);    // x * (1/r) is within 1-2 ulp of x / r
-        const bool on = rintf(z) != 0.f;   // torch.round: half to even
-        const kl_f2 cnt2 = {count, count}, ir2 = {inv_rem, inv_rem};
-        // the factor of c: q where the cell is on, 1 - q where it is off = sa * q + sb with wave-uniform (sa, sb) -- exact either way
-        const float sa = on ? 1.f : -1.f, sb = on ? 0.f : 1.f;
-        kl_f2 pz2 = {0.f, 0.f}, np2 = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            kl_f2 d = e2[k] - cnt2;
-            d.x = __builtin_amdgcn_fmed3f(d.x, 0.f, rem);        // clamp(d, 0, rem) in one instruction
-            d.y = __builtin_amdgcn_fmed3f(d.y, 0.f, rem);
-            const kl_f2 q = d * ir2;
-            pz2 += c2[k] * q;
-            const kl_f2 sel = {__builtin_fmaf(sa, q.x, sb), __builtin_fmaf(sa, q.y, sb)};
-            const kl_f2 v = sel * c2[k];
-            c2[k] = v;
-            np2 += v;
-        }
-        const float pz = kl_wave_sum(pz2.x + pz2.y);
-        const float np = fmaxf(kl_wave_sum(np2.x + np2.y), 1e-6f);
-        const float inv_np = kl_rcp(np);
-        const kl_f2 in2 = {inv_np, inv_np};
-#pragma unroll
-        for (int k = 0; k < NP; ++k) c2[k] = c2[k] * in2;
-        if (lane == 0) pzs[i] = pz;
-        count += on ? 1.f : 0.f;
-    }
+    float znext = zs[0];
+    kl_phase<NBR, NP>(c2, e2, zs, pzs, HW, lane, znext);
     wave_lds_fence();
     // Bernoulli KL per cell (models.py:223-226) and the p_z map the backward pass needs
     float klsum = 0.f;
