@@ -759,7 +759,20 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const float wx1 = __uint_as_float(xf[q]), wx0 = 1.f - wx1;
                 const int x1 = xin ? x0 + 1 : x0;
                 const float m1 = xin ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
-                const float v00 = px(r0o + x0), v01 = m1 * px(r0o + x1), v10 = n1 * px(r1o + x0), v11 = m1 * n1 * px(r1o + x1);
+                float v00, v01, v10, v11;
+                if constexpr (IMG) {
+                    v00 = px(r0o + x0); v01 = m1 * px(r0o + x1); v10 = n1 * px(r1o + x0); v11 = m1 * n1 * px(r1o + x1);
+                } else {
+                    // the two taps of a row as ONE 8-byte load (4-byte aligned: global memory takes it): half the loads of the stage that the
+                    // vector-memory front end bounds on images too wide for the LDS copy.  At the right border (x0 = I - 1, second tap masked)
+                    // the pair starts one pixel to the left.
+                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    const int xl = min(x0, a.I - 2);
+                    const f2u p0 = *reinterpret_cast<const f2u*>(img + r0o + xl), p1 = *reinterpret_cast<const f2u*>(img + r1o + xl);
+                    const bool sh = x0 != xl;
+                    v00 = sh ? p0.y : p0.x; v01 = m1 * p0.y;
+                    v10 = n1 * (sh ? p1.y : p1.x); v11 = m1 * n1 * p1.y;
+                }
                 out[q] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
                 // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
                 const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
