@@ -5,10 +5,12 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spair_pytorch_amd import _lib as L, config as cfg, models
 from spair_pytorch_amd.data import scattered_digits
-cfg.set_grid(128, (2, 2, 2, 1, 1, 1))
+IMG_SIDE = int(os.environ.get("STAMP_IMAGE", "128"))           # STAMP_IMAGE=256 STAMP_BATCH=64: configs[3] (the stamping workgroup is sample 0's top band)
+BATCH = int(os.environ.get("STAMP_BATCH", "256"))
+cfg.set_grid(IMG_SIDE, (2, 2, 2, 1, 1, 1))
 torch.manual_seed(3)
-m = models.SPAIR([1, 128, 128], None, torch.device("cuda"), compute_dtype="bf16").to("cuda")
-x = torch.from_numpy(scattered_digits(1, 256, 128, 11)[0]).cuda()
+m = models.SPAIR([1, IMG_SIDE, IMG_SIDE], None, torch.device("cuda"), compute_dtype="bf16").to("cuda")
+x = torch.from_numpy(scattered_digits(1, BATCH, IMG_SIDE, 11)[0]).cuda()
 models.STEP_FLAGS = 2
 for _ in range(2):
     m.zero_grad()
@@ -16,7 +18,8 @@ for _ in range(2):
     loss.backward()
 torch.cuda.synchronize()
 e = m._last["engine"]
-T = 3 * 16 - 2
+_tw = ctypes.c_int(0)
+T = L.lib().spair_chain_stamp_wavefronts(ctypes.byref(e["dims"]))
 _ns, _gl, _nb = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
 L.check(L.lib().spair_chain_stamp_layout(ctypes.byref(_ns), ctypes.byref(_gl), ctypes.byref(_nb)), "stamp_layout")
 NS = _ns.value
