@@ -241,6 +241,14 @@ int spair_conv_s2k4_fwd16(const void* in16, const void* wf16, const float* bias,
  * below, bf16 NHWC [B][2 (Ho + 1)][2 (Ho + 1)][128]; out16 (same shape) = conv2d_backward_input(dout, W) where gate16 > 0, else 0. */
 int spair_conv_s2k4_dgrad16(const void* dout16, const void* wd0, const void* wd1, const void* wd2, const void* wd3, const void* gate16,
                             void* out16, int B, int Ho, void* stream);
+/* Sign-bit form of a ReLU gate (round 5): one byte per (pixel, 8 channels), [B][H][H][16], bit e = channel 8 g + e of the stored bf16
+ * activation > 0.  spair_stem_conv_fwd_mask: the stem (1 -> 128 channels, 4 x 4, stride 2, bf16 output) leaving that mask beside its output;
+ * spair_conv_s2k4_dgrad16_bits: spair_conv_s2k4_dgrad16 reading the gate from it (20 MB instead of the 321-MB activation at the benchmark
+ * shape) -- what the training step runs for conv_1's data gradient. */
+int spair_stem_conv_fwd_mask(const float* x, const float* w, const float* bias, void* out, void* mask8, int B, int I, int pad_pre, int Hin,
+                             int Hout, void* stream);
+int spair_conv_s2k4_dgrad16_bits(const void* dout16, const void* wd0, const void* wd1, const void* wd2, const void* wd3,
+                                 const void* gate_bits8, void* out16, int B, int Ho, void* stream);
 /* The bf16 step's object-decoder FORWARD (reference models.py:474-492: Linear 50->128, ReLU, Linear 128->256, ReLU, Linear 256->P*P*2, the sprite
  * scales and analytic sigmoid) as one activation-stationary kernel (csrc/dec_fused.hip).  z_attr16: bf16 [N][ld_za] (columns >= A ignored);
  * W*, b*: the fp32 parameters, row-major [out][in]; H1 / H2: bf16 [N][128] / [N][256] hidden activations (stored for the backward);

@@ -29,6 +29,7 @@ constexpr int CP_LDC = CP_C + 16;                // epilogue staging row (bf16 e
 
 struct ConvPatchArgs {
     const u16* in; const u16* wf; const float* bias; u16* out;
+    unsigned char* mask;                         // optional: sign bits of the output, one byte per (pixel, 8 channels) [M][16] (the next layer's dgrad gate)
     int B, Hin, Hout, M, K;                      // M = B * Hout * Hout, K = 16 * 128
     int tpi;                                     // 0: tiles of 256 consecutive rows of the whole batch; > 0: tiles per image (a tile never crosses an image)
 };
@@ -188,6 +189,11 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
             const int row = it * 32 + (tid >> 4), ch = (tid & 15) * 8;
             const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
             buf_store16(rout, (m0 + row) < mend ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
+            if (a.mask) {        // (uniform) post-ReLU values: a channel is on iff its 16 bits are not zero
+                auto nz2 = [](unsigned w) { return (unsigned)((w & 0xffffu) != 0u) | ((unsigned)((w >> 16) != 0u) << 1); };
+                const unsigned byte = nz2(v.x) | (nz2(v.y) << 2) | (nz2(v.z) << 4) | (nz2(v.w) << 6);
+                if ((m0 + row) < mend) a.mask[(size_t)(m0 + row) * 16 + (tid & 15)] = (unsigned char)byte;
+            }
         }
     }
 }
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
 
 // in: bf16 NHWC [B][Hin][Hin][128]; wf: bf16 [128][2048] in tap-parity K order (engine.hip fill_ktab / k_prep mode 2 with T, s set);
 // out: bf16 [B*Hout*Hout][128] = relu(conv + bias).  SPAIR_ERR_UNSUPPORTED: the caller keeps the implicit-GEMM kernel.
-int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
-                          hipStream_t s) {
+// geometry check shared by the launcher and by conv_s2k4_patch_fwd16_fits(): SPAIR_OK with the tiling, or SPAIR_ERR_UNSUPPORTED
+static int cp_plan(int B, int Hin, int Hout, int cin, int cout, int k, int s_, int& tiles_out, int& tpi_out) {
     if (cin != CP_C || cout != CP_C || k != 4 || s_ != 2 || Hin != 2 * Hout + 2 || B <= 0 || Hout <= 0) return SPAIR_ERR_UNSUPPORTED;
     const long long M = (long long)B * Hout * Hout;
     if (M * CP_C >= (1ll << 31) || (long long)B * Hin * Hin * CP_C >= (1ll << 31)) return SPAIR_ERR_UNSUPPORTED;
@@ -223,10 +229,24 @@ int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, voi
         if (worst > CP_PPX) return SPAIR_ERR_UNSUPPORTED;
         tiles = B * tpi;
     }
+    tiles_out = tiles; tpi_out = tpi;
+    return SPAIR_OK;
+}
+// does the patch-resident kernel take this layer (then it also leaves the sign-bit mask the next layer's data gradient reads)?
+bool conv_s2k4_patch_fwd16_fits(int B, int Hin, int Hout, int cin, int cout, int k, int s_) {
+    int t, p;
+    return cp_plan(B, Hin, Hout, cin, cout, k, s_, t, p) == SPAIR_OK;
+}
+int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
+                          hipStream_t s, void* mask) {
+    int tiles = 0, tpi = 0;
+    { const int rc = cp_plan(B, Hin, Hout, cin, cout, k, s_, tiles, tpi); if (rc != SPAIR_OK) return rc; }
+    const long long M = (long long)B * Hout * Hout;
     static std::atomic<unsigned long long> attr_done{0};
     if (spair_dyn_lds_once(reinterpret_cast<const void*>(&k_conv_s2k4_patch), CP_LDS, attr_done) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
     ConvPatchArgs a;
     a.in = reinterpret_cast<const u16*>(in); a.wf = reinterpret_cast<const u16*>(wf); a.bias = bias; a.out = reinterpret_cast<u16*>(out);
+    a.mask = reinterpret_cast<unsigned char*>(mask);
     a.B = B; a.Hin = Hin; a.Hout = Hout; a.M = (int)M; a.K = 16 * CP_C; a.tpi = tpi;
     hipLaunchKernelGGL(k_conv_s2k4_patch, dim3(tiles), dim3(768), CP_LDS, s, a);
     SPAIR_CHECK_LAUNCH();

@@ -32,6 +32,7 @@ constexpr int DG_STEM_FLOATS = 128 * 17;
 
 struct ConvDgradArgs {
     const u16* dout; const u16* Bz[4]; const u16* gate; u16* out;
+    const unsigned char* gbits;                  // BITS: the gate as sign bits, one byte per (pixel, 8 channels) [B][Hi][Hi][16] (the stem kernel's mask)
     int B, Ho, Hc, Hi, M;                        // d_out side, class-grid side Ho + 1, input side 2 Hc, M = B * Hc * Hc
     int tpi;                                     // 0: tiles of 128 consecutive class pixels of the whole batch; > 0: tiles per image
     // STEM (conv_1): xp = zero-padded fp32 stem input [B][stem_hin][stem_hin], stride stem_s; one [128][17] partial per workgroup
@@ -57,7 +58,7 @@ __device__ __forceinline__ bf16x8 dg_tr_frag16(const __bf16* tile, int ld, int c
     return u.v;
 }
 
-template <bool STEM>
+template <bool STEM, bool BITS>
 __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dg_sm[];
     char* bt = dg_sm;                            // [3][128 ci][64 k] bf16, chunk ^ (row & 7)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     const int wkey = (r16 & 3) | (((r16 >> 2) & 1) << 2);
     const int wrow0 = wn * 64 + (r16 >> 2) * 8 + (r16 & 3);          // + 32 (t >> 1) + 4 (t & 1)
     const int ch0 = wn * 64 + q * 8;                                  // + 32 p: the 8 channels this lane owns after tile pair p
-    const __amdgpu_buffer_rsrc_t rgate = buf_rsrc(a.gate), rout = buf_rsrc(a.out);
+    const __amdgpu_buffer_rsrc_t rgate = buf_rsrc(BITS ? reinterpret_cast<const void*>(a.gbits) : reinterpret_cast<const void*>(a.gate)), rout = buf_rsrc(a.out);
     f32x4 sacc[2][2];                            // STEM: this wave's 32 channels x (16 taps | bias | 0 ...), over the tile's 4 classes
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -223,12 +224,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // gate pieces of this class (and the stem patches) are requested at the top of the class: their latency hides behind its 8 K steps
-        uint4 gate[4][2];
+        uint4 gate[BITS ? 1 : 4][2];
+        u32x2_t gbits[4];                        // BITS: the 64 sign bits of this wave half's 64 channels of the pixel; the lane's two bytes are q and q + 4
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const unsigned pix = orow[j] + (unsigned)(py * a.Hi + px);
+            if (BITS) gbits[j] = __builtin_amdgcn_raw_buffer_load_b64(rgate, ook[j] ? (int)(pix * 16u + (unsigned)(wn * 8)) : (int)BUF_OOB, 0, 0);
+            else {
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                gate[j][p] = buf_load16(rgate, ook[j] ? ((orow[j] + (unsigned)(py * a.Hi + px)) * DG_C + ch0 + p * 32) * 2u : BUF_OOB);
+                for (int p = 0; p < 2; ++p) gate[j][p] = buf_load16(rgate, ook[j] ? (pix * DG_C + ch0 + p * 32) * 2u : BUF_OOB);
+            }
+        }
         float2 sp[4];
         bool sp_ok = false;
         if (STEM) {
@@ -276,14 +282,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                 for (int e = 0; e < 4; ++e) { v[e] = (__bf16)acc[2 * p][j][e]; v[4 + e] = (__bf16)acc[2 * p + 1][j][e]; }
                 uint4 vv;
                 __builtin_memcpy(&vv, &v, 16);
-                const unsigned vw[4] = {vv.x, vv.y, vv.z, vv.w}, gw[4] = {gate[j][p].x, gate[j][p].y, gate[j][p].z, gate[j][p].w};
+                const unsigned vw[4] = {vv.x, vv.y, vv.z, vv.w};
                 unsigned ow[4];
+                if (BITS) {
+                    const int gb = (int)((p ? gbits[j].y : gbits[j].x) >> (8 * q));      // (bits 0..7 of it are the lane's 8 channels)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned glo = gw[e] & 0xffffu, ghi = gw[e] >> 16;
-                    const unsigned mlo = ((glo & 0x8000u) == 0 && (glo & 0x7fffu) != 0) ? 0xffffu : 0u;
-                    const unsigned mhi = ((ghi & 0x8000u) == 0 && (ghi & 0x7fffu) != 0) ? 0xffff0000u : 0u;
-                    ow[e] = vw[e] & (mlo | mhi);
+                    for (int e = 0; e < 4; ++e)      // v_bfe_i32: bit -> 0 / -1
+                        ow[e] = vw[e] & (((unsigned)__builtin_amdgcn_sbfe(gb, 2 * e, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(gb, 2 * e + 1, 1) & 0xffff0000u));
+                } else {
+                    const unsigned gw[4] = {gate[BITS ? 0 : j][p].x, gate[BITS ? 0 : j][p].y, gate[BITS ? 0 : j][p].z, gate[BITS ? 0 : j][p].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned glo = gw[e] & 0xffffu, ghi = gw[e] >> 16;
+                        const unsigned mlo = ((glo & 0x8000u) == 0 && (glo & 0x7fffu) != 0) ? 0xffffu : 0u;
+                        const unsigned mhi = ((ghi & 0x8000u) == 0 && (ghi & 0x7fffu) != 0) ? 0xffff0000u : 0u;
+                        ow[e] = vw[e] & (mlo | mhi);
+                    }
                 }
                 const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 if (STEM) *reinterpret_cast<uint4*>(Gs + (wm * 64 + j * 16 + r16) * DG_LDG + ch0 + p * 32) = ook[j] ? o : make_uint4(0u, 0u, 0u, 0u);
@@ -347,7 +361,7 @@ int spair_stem_fused_reduce(float* part, int nblk, float* dw, float* db, hipStre
 // SPAIR_ERR_UNSUPPORTED: the caller keeps the implicit-GEMM kernel.
 int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void* gate, void* out, int B, int Ho, int hin, int cin, int cout, int k,
                             int s_, const float* stem_xp, int stem_hin, int stem_s, float* stem_part, long long stem_part_cap, float* stem_dw,
-                            float* stem_db, hipStream_t s) {
+                            float* stem_db, hipStream_t s, const void* gate_bits) {
     const int Hc = Ho + 1;
     if (cin != DG_C || cout != DG_C || k != 4 || s_ != 2 || hin != 2 * Hc || B <= 0 || Ho <= 0) return SPAIR_ERR_UNSUPPORTED;
     const long long M = (long long)B * Hc * Hc;
@@ -380,15 +394,19 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
     a.dout = reinterpret_cast<const u16*>(dout);
     for (int q = 0; q < 4; ++q) a.Bz[q] = reinterpret_cast<const u16*>(wd[q]);
     a.gate = reinterpret_cast<const u16*>(gate); a.out = reinterpret_cast<u16*>(out);
+    a.gbits = reinterpret_cast<const unsigned char*>(gate_bits);
     a.B = B; a.Ho = Ho; a.Hc = Hc; a.Hi = hin; a.M = (int)M; a.tpi = tpi;
     a.stem_xp = stem_xp; a.stem_part = stem_part; a.stem_hin = stem_hin; a.stem_s = stem_s;
-    static std::atomic<unsigned long long> attr_done[2];
-    {
-        const void* fn = stem ? reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true>) : reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false>);
-        if (spair_dyn_lds_once(fn, DG_LDS, attr_done[stem ? 1 : 0]) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
-    }
-    if (stem) hipLaunchKernelGGL(k_conv_s2k4_dgrad<true>, dim3(grid), dim3(512), DG_LDS, s, a);
-    else hipLaunchKernelGGL(k_conv_s2k4_dgrad<false>, dim3(grid), dim3(512), DG_LDS, s, a);
+    static std::atomic<unsigned long long> attr_done[4];
+    const bool bits = gate_bits != nullptr;
+    const int vi = (stem ? 1 : 0) + (bits ? 2 : 0);
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false, false>), reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true, false>),
+                          reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false, true>), reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true, true>)};
+    if (spair_dyn_lds_once(fns[vi], DG_LDS, attr_done[vi]) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
+    if (vi == 0) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, false>), dim3(grid), dim3(512), DG_LDS, s, a);
+    else if (vi == 1) hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, false>), dim3(grid), dim3(512), DG_LDS, s, a);
+    else if (vi == 2) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, true>), dim3(grid), dim3(512), DG_LDS, s, a);
+    else hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, true>), dim3(grid), dim3(512), DG_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
     if (stem) return spair_stem_fused_reduce(stem_part, grid, stem_dw, stem_db, s);
     return SPAIR_OK;
@@ -400,4 +418,12 @@ extern "C" int spair_conv_s2k4_dgrad16(const void* dout16, const void* wd0, cons
     const void* wd[4] = {wd0, wd1, wd2, wd3};
     return conv_s2k4_patch_dgrad16(dout16, wd, gate16, out16, B, Ho, 2 * (Ho + 1), 128, 128, 4, 2, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                    (hipStream_t)stream);
+}
+// the same with the ReLU gate given as sign bits (one byte per (pixel, 8 channels), [B][2 (Ho + 1)][2 (Ho + 1)][16]: spair_stem_conv_fwd_mask)
+extern "C" int spair_conv_s2k4_dgrad16_bits(const void* dout16, const void* wd0, const void* wd1, const void* wd2, const void* wd3,
+                                            const void* gate_bits8, void* out16, int B, int Ho, void* stream) {
+    if (!gate_bits8) return SPAIR_ERR_SHAPE;
+    const void* wd[4] = {wd0, wd1, wd2, wd3};
+    return conv_s2k4_patch_dgrad16(dout16, wd, nullptr, out16, B, Ho, 2 * (Ho + 1), 128, 128, 4, 2, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                   (hipStream_t)stream, gate_bits8);
 }

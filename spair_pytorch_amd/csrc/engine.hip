@@ -154,6 +154,8 @@ struct Ws {
     void* dec_stream;             // fused decoder forward: fragment stream of its three weight matrices (bf16 mode)
     float* xpad;
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
+    unsigned char* act0_bits;         // sign bits of act[0] (one byte per pixel and 8 channels): conv_1's data-gradient gate, written by the stem kernel
+    unsigned char* act_bits[SP_MAX_CONV + 1];      // the same for the outputs of the patch-resident strided convolutions (gates of the next layer's dgrad)
     float *feat, *dfeat;
     CellBufs cb;
     float *Za, *Hd1, *Hd2, *S, *dLog, *dHd2, *dHd1;     // Hd*, dLog, dHd*: bf16 in bf16 mode
@@ -236,6 +238,16 @@ static Ws carve(const SpairDims& d, void* base) {
         const size_t n = (size_t)d.B * cs.hout * cs.hout * cs.cout;
         w.act[i] = reinterpret_cast<float*>(c.take_bytes(n * es));      // NHWC, bf16 in bf16 mode
         w.dact[i] = reinterpret_cast<float*>(c.take_bytes(n * es));
+    }
+    {
+        const ConvSpec& c0 = PL.conv[0];
+        w.act0_bits = misc_conv0_writes_mask(d.B, c0.hin, d.C, c0.k, c0.s, c0.cout, d.dtype == SPAIR_BF16)
+                          ? c.take<unsigned char>((size_t)d.B * c0.hout * c0.hout * 16) : nullptr;
+    }
+    for (int i = 1; i < d.n_conv; ++i) {
+        const ConvSpec& cs = PL.conv[i];
+        w.act_bits[i] = (d.dtype == SPAIR_BF16 && cs.k == 4 && cs.s == 2 && cs.cin == 128 && cs.cout == 128)
+                            ? c.take<unsigned char>((size_t)d.B * cs.hout * cs.hout * 16) : nullptr;
     }
     w.ld_feat = round_up(d.F, 8);
     w.feat = c.take<float>(N * w.ld_feat);
@@ -692,7 +704,7 @@ static int backbone_stem_fwd(Ctx& c) {
     if (!misc_conv0_reads_unpadded(d.B, c0.hin, d.C, c0.k, c0.cout))
         TRY(misc_pad_input(c.x, c.w.xpad, d.B, d.C, d.I, d.pad_pre, d.I + d.pad_pre + d.pad_post, c.s));
     return misc_conv0_fwd(c.x, c.w.xpad, c.params + c0.w, c.params + c0.b, c.w.act[0], d.B, d.I, d.pad_pre, c0.hin, d.C, c0.k, c0.s, c0.hout,
-                          c0.cout, b16, c.s);
+                          c0.cout, b16, c.s, c.w.act0_bits);
 }
 static int backbone_fwd(Ctx& c) {
     const SpairDims& d = c.d;
@@ -718,7 +730,8 @@ static int backbone_fwd(Ctx& c) {
         if (b16 && !last && cs.k > 1 && conv_kperm(c, cs) && !(c.st.flags & 32)) {
             // 128 -> 128 channel 4x4 / stride-2 layers: the patch-resident kernel (conv_s2.hip), 2.3x fewer operand bytes from L2
             ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
-            const int rc = conv_s2k4_patch_fwd16(c.w.act[i - 1], c.w.conv_wf[i], c.params + cs.b, out, d.B, cs.hin, cs.hout, cs.cin, cs.cout, cs.k, cs.s, c.s);
+            const int rc = conv_s2k4_patch_fwd16(c.w.act[i - 1], c.w.conv_wf[i], c.params + cs.b, out, d.B, cs.hin, cs.hout, cs.cin, cs.cout, cs.k, cs.s, c.s,
+                                                 c.st.train ? c.w.act_bits[i] : nullptr);
             if (rc == SPAIR_OK) continue;
             if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
         }
@@ -796,13 +809,20 @@ static int backbone_bwd16(Ctx& c, float* grads) {
                 const ConvSpec& c0 = c.PL.conv[0];
                 const bool want_stem = i == 1 && c0.cin == 1 && c0.k == 4 && c0.cout == 128 && c0.hout == cs.hin && !(c.st.flags & 8);
                 const void* wd4[4] = {c.w.conv_wd[i][0], c.w.conv_wd[i][1], c.w.conv_wd[i][2], c.w.conv_wd[i][3]};
+                // conv_1's gate as the stem kernel's sign bits (20 MB instead of the 321-MB activation) whenever that kernel wrote them
+                const void* gbits = nullptr;
+                if (i == 1) { if (c0.hout == cs.hin) gbits = c.w.act0_bits; }
+                else {          // the layer below ran on the patch-resident forward kernel (same test as backbone_fwd): it left its mask
+                    const ConvSpec& lo = c.PL.conv[i - 1];
+                    if (lo.k > 1 && conv_kperm(c, lo) && conv_s2k4_patch_fwd16_fits(d.B, lo.hin, lo.hout, lo.cin, lo.cout, lo.k, lo.s)) gbits = c.w.act_bits[i - 1];
+                }
                 int rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s,
                                                  want_stem ? c.w.xpad : nullptr, c0.hin, c0.s, want_stem ? c.w.tn_part : nullptr,
-                                                 SPAIR_TN_PART_FLOATS, grads + c0.w, grads + c0.b, c.s);
+                                                 SPAIR_TN_PART_FLOATS, grads + c0.w, grads + c0.b, c.s, gbits);
                 if (rc == SPAIR_OK) { if (want_stem) stem_fused = true; continue; }
                 if (rc == SPAIR_ERR_UNSUPPORTED && want_stem) {      // the stem fusion alone was refused: same kernel, d act0 to HBM, stem wgrad below
                     rc = conv_s2k4_patch_dgrad16(dout, wd4, in, c.w.dact[i - 1], d.B, cs.hout, cs.hin, cs.cin, cs.cout, cs.k, cs.s, nullptr, 0, 0,
-                                                 nullptr, 0, nullptr, nullptr, c.s);
+                                                 nullptr, 0, nullptr, nullptr, c.s, gbits);
                     if (rc == SPAIR_OK) continue;
                 }
                 if (rc != SPAIR_ERR_UNSUPPORTED) return rc;

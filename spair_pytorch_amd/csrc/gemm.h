@@ -79,9 +79,11 @@ int spair_to_bf16(const float* src, int lds_, void* dst, int ldd, long long rows
 // conv_s2.hip: patch-resident forward of a 128 -> 128 channel 4x4 / stride-2 convolution (+ bias + relu), bf16 NHWC in / out, weights in
 // tap-parity K order; SPAIR_ERR_UNSUPPORTED when the geometry does not fit (the caller keeps the implicit-GEMM kernel)
 int conv_s2k4_patch_fwd16(const void* in, const void* wf, const float* bias, void* out, int B, int Hin, int Hout, int cin, int cout, int k, int s_,
-                          hipStream_t s);
+                          hipStream_t s, void* mask = nullptr);      // mask: optional sign bits of the output [B*Hout*Hout][16] bytes
+bool conv_s2k4_patch_fwd16_fits(int B, int Hin, int Hout, int cin, int cout, int k, int s_);
 // conv_s2_dgrad.hip: patch-resident data gradient of the same layers (all 4 output-parity classes per workgroup), ReLU gate of the layer below,
-// optionally with the stem's weight gradient fused (stem_part != nullptr: nothing is stored to `out`)
+// optionally with the stem's weight gradient fused (stem_part != nullptr: nothing is stored to `out`); gate_bits != nullptr: the gate as
+// sign bits, one byte per (pixel, 8 channels) -- what the stem kernel leaves beside act0 (misc.hip) -- instead of the activation itself
 int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void* gate, void* out, int B, int Ho, int hin, int cin, int cout, int k,
                             int s_, const float* stem_xp, int stem_hin, int stem_s, float* stem_part, long long stem_part_cap, float* stem_dw,
-                            float* stem_db, hipStream_t s);
+                            float* stem_db, hipStream_t s, const void* gate_bits = nullptr);

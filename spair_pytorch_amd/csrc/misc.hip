@@ -333,9 +333,11 @@ __device__ __forceinline__ void c0_split4(const float (&v)[4], c0_s16x4& hi, c0_
     lo = __builtin_bit_cast(c0_s16x4, l);
 }
 __host__ __device__ constexpr size_t c0_mfma_xs_bytes(int Hin) { return (((size_t)(2 * (C0_ROWS - 1) + 4) * (Hin + 2) * sizeof(float)) + 15) & ~(size_t)15; }
+// `mask` (optional): one byte per (pixel, 8 channels), [B][Hout][Hout][16], bit e = channel 8 g + e of the stored activation > 0 -- the ReLU
+// gate conv_1's data gradient needs, 16 x smaller than the activation rows it otherwise re-reads (268 MB at the benchmark shape).
 __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, __bf16* __restrict__ out, int Hin, int Hout,
-                                                             int I, int pre) {
+                                                             int I, int pre, unsigned char* __restrict__ mask) {
     extern __shared__ float xs[];    // [2 * (C0_ROWS - 1) + 4][Hin + 2]: the input rows of this workgroup's output rows; then 4 per-wave output tiles
     char* tile = reinterpret_cast<char*>(xs) + c0_mfma_xs_bytes(Hin);
     const int oy0 = blockIdx.x * C0_ROWS, b = blockIdx.y;
@@ -411,6 +413,12 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __rest
             // non-temporal: the 321 MB stream past the L2 instead of evicting it (74 -> 66 us alone; in the step conv_1's forward, which
             // reads this tensor next, went 0.231 -> 0.210 ms as well)
             if (px < npx) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8));
+            if (mask) {          // (wave-uniform)
+                const u32x4_t wv = __builtin_bit_cast(u32x4_t, o);      // post-ReLU: a channel is on iff its 16 bits are not zero
+                auto nz2 = [](unsigned v) { return (unsigned)((v & 0xffffu) != 0u) | ((unsigned)((v >> 16) != 0u) << 1); };
+                const unsigned byte = nz2(wv.x) | (nz2(wv.y) << 2) | (nz2(wv.z) << 4) | (nz2(wv.w) << 6);
+                if (px < npx) mask[(((size_t)b * Hout + oy0 + r) * Hout + ox0 + px) * 16 + m] = (unsigned char)byte;
+            }
         }
         wave_lds_fence();       // ... and the next block's writes stay behind these reads
     }
@@ -420,14 +428,17 @@ bool misc_conv0_reads_unpadded(int B, int Hin, int C, int k, int Cout) {
     return Cout % 4 == 0 && C == 1 && k == 4 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0 && B <= 65535 &&
            (size_t)(4 * (C0_ROWS - 1) + 4) * Hin * sizeof(float) <= 48 * 1024;     // stride <= 4
 }
+bool misc_conv0_writes_mask(int B, int Hin, int C, int k, int s, int Cout, int out_bf16) {
+    return misc_conv0_reads_unpadded(B, Hin, C, k, Cout) && out_bf16 && Cout == 128 && s == 2 && (Hin & 1) == 0;
+}
 int misc_conv0_fwd(const float* x, const float* xp, const float* w, const float* bias, float* out, int B, int I, int pre, int Hin, int C, int k,
-                   int s, int Hout, int Cout, int out_bf16, hipStream_t st) {
+                   int s, int Hout, int Cout, int out_bf16, hipStream_t st, unsigned char* mask) {
     if (Cout % 4) return SPAIR_ERR_ALIGN;
     if (misc_conv0_reads_unpadded(B, Hin, C, k, Cout)) {
         if (s < 1 || s > 4) return SPAIR_ERR_UNSUPPORTED;
         if (out_bf16 && Cout == 128 && s == 2 && (Hin & 1) == 0) {
             hipLaunchKernelGGL(k_conv0_fwd_c1k4_mfma, dim3((Hout + C0_ROWS - 1) / C0_ROWS, B), dim3(256), c0_mfma_xs_bytes(Hin) + 4 * 16 * C0_TP, st, x,
-                               w, bias, reinterpret_cast<__bf16*>(out), Hin, Hout, I, pre);
+                               w, bias, reinterpret_cast<__bf16*>(out), Hin, Hout, I, pre, mask);
             SPAIR_CHECK_LAUNCH();
             return SPAIR_OK;
         }
@@ -452,6 +463,15 @@ extern "C" int spair_stem_conv_fwd(const float* x, const float* w, const float* 
     if (B <= 0 || I <= 0 || stride < 1 || Hin < I + pad_pre || Hout != (Hin - 4) / stride + 1) return SPAIR_ERR_SHAPE;
     if (!misc_conv0_reads_unpadded(B, Hin, 1, 4, Cout)) return SPAIR_ERR_UNSUPPORTED;
     return misc_conv0_fwd(x, nullptr, w, bias, reinterpret_cast<float*>(out), B, I, pad_pre, Hin, 1, 4, stride, Hout, Cout, out_bf16, (hipStream_t)stream);
+}
+// the same with the sign-bit mask of the output (bf16, 128 channels, stride 2): mask8 [B][Hout][Hout][16] bytes
+extern "C" int spair_stem_conv_fwd_mask(const float* x, const float* w, const float* bias, void* out, void* mask8, int B, int I, int pad_pre, int Hin,
+                                        int Hout, void* stream) {
+    if (!x || !w || !bias || !out || !mask8) return SPAIR_ERR_SHAPE;
+    if (B <= 0 || I <= 0 || Hin < I + pad_pre || Hout != (Hin - 4) / 2 + 1) return SPAIR_ERR_SHAPE;
+    if (!misc_conv0_writes_mask(B, Hin, 1, 4, 2, 128, 1)) return SPAIR_ERR_UNSUPPORTED;
+    return misc_conv0_fwd(x, nullptr, w, bias, reinterpret_cast<float*>(out), B, I, pad_pre, Hin, 1, 4, 2, Hout, 128, 1, (hipStream_t)stream,
+                          reinterpret_cast<unsigned char*>(mask8));
 }
 
 // weight gradient: dW[co][ci][ky][kx] += sum_m dOut[m][co] * patch(m)[(ky,kx,ci)]; thread = (co, k) pairs

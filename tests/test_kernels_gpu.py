@@ -345,6 +345,14 @@ def test_stem_conv_mfma_vs_torch(B, I, pre, post):
     got, want = o16.float().cpu(), ref.bfloat16().float()
     assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
     assert (got != want).float().mean().item() < 5e-3
+    # the same kernel leaving the sign-bit mask of its output (conv_1's data-gradient gate): same output bits, byte (pixel, g) bit e = channel 8g+e > 0
+    o16m = torch.zeros(B, Hout, Hout, 128, device="cuda", dtype=torch.bfloat16)
+    mask = torch.full((B, Hout, Hout, 16), 0xAA, device="cuda", dtype=torch.uint8)
+    L.check(L.lib().spair_stem_conv_fwd_mask(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(o16m), L.ptr(mask), B, I, pre, Hin, Hout, L.stream()), "stem mask")
+    assert torch.equal(o16m, o16)
+    bits = (o16.float() > 0).view(B, Hout, Hout, 16, 8).to(torch.int32)
+    want_mask = (bits * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(mask, want_mask)
 
 
 @pytest.mark.parametrize("N", [72, 1000, 8192])
@@ -506,3 +514,9 @@ def test_conv_s2k4_patch_dgrad_vs_torch(B, Ho):
     d = (got - ref).abs()
     assert (d <= 0.0079 * ref.abs() + 2e-3).all().item(), float(d.max())
     assert ((got == 0) == (ref == 0)).float().mean().item() > 0.999                  # the gate
+    # the gate as sign bits (one byte per pixel and 8 channels: what the training step reads for conv_1): bit-identical result
+    gbits = ((gate.float() > 0).view(B, Hi, Hi, 16, 8).to(torch.int32) * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous()
+    out2 = torch.full((B * Hi * Hi + 1, C), -3.0, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().spair_conv_s2k4_dgrad16_bits(L.ptr(dd), L.ptr(wd[0]), L.ptr(wd[1]), L.ptr(wd[2]), L.ptr(wd[3]), L.ptr(gbits), L.ptr(out2), B, Ho,
+                                                 L.stream()), "conv_s2k4 dgrad bits")
+    assert torch.equal(out2, out)
