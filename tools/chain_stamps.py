@@ -18,7 +18,6 @@ for _ in range(2):
     loss.backward()
 torch.cuda.synchronize()
 e = m._last["engine"]
-_tw = ctypes.c_int(0)
 T = L.lib().spair_chain_stamp_wavefronts(ctypes.byref(e["dims"]))
 _ns, _gl, _nb = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
 L.check(L.lib().spair_chain_stamp_layout(ctypes.byref(_ns), ctypes.byref(_gl), ctypes.byref(_nb)), "stamp_layout")
