@@ -1294,17 +1294,6 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
         const u64x2_t mbo01 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4);
         const u64x2_t mbo23 = *reinterpret_cast<const u64x2_t*>(mbt + (MB_HO2 + (ho_q4 >> 2)) * 4 + 2);
-        // saved glimpse derivatives for this wave's 7 ENC0 tiles in the (transposed) MFMA output layout itself -- row lane & 15, elements
-        // tile*16 + (lane>>4)*4 .. +3: one 16-byte load per tile, and the epilogue needs no transpose through LDS any more
-        uint4 gxy_pf[7];
-        {
-            const size_t grow = (size_t)row_r[min(lane & 15, nc - 1)] * L.ld_gl;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int e0 = min((wave + NW * j) * 16 + (lane >> 4) * 4, GLN - 4);
-                gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
-            }
-        }
         // ---- B1a: gradient of each cell's record from its consumers' context columns (wavefronts t+1..t+3)
         // (branch-free: the four consumer slots are read side by side -- with a `continue` per slot the loop was twelve dependent LDS
         // round trips, 1.2 us per wavefront)
@@ -1331,6 +1320,20 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
+        // saved glimpse derivatives for this wave's 7 ENC0 tiles in the (transposed) MFMA output layout itself -- row lane & 15, elements
+        // tile*16 + (lane>>4)*4 .. +3: one 16-byte load per tile, and the epilogue needs no transpose through LDS any more.  Requested HERE,
+        // behind the first stage's barrier, not with the other prefetches at the top of the wavefront: seven more wave-loads in that burst
+        // held up the first stage's own issue (timing-only removal of these loads: 0.733 -> 0.694 ms; at the top 0.728, here 0.719, at the
+        // start of the OBJ0 stage -- whose weight stream they then compete with -- 0.757, at the depth stage 0.725)
+        uint4 gxy_pf[7];
+        {
+            const size_t grow = (size_t)row_r[min(lane & 15, nc - 1)] * L.ld_gl;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int e0 = min((wave + NW * j) * 16 + (lane >> 4) * 4, GLN - 4);
+                gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
+            }
+        }
         // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit) and, by the same lanes, the rank-1
         // data gradient of the obj net's output layer: dHo2 = dOo (x) W_out masked by relu -- every lane of a row evaluates the row's d logit
         // (the reduction leaves the KL sum in all 32), lanes 0..24 produce 4 columns each from the sign-bit words they prefetched
