@@ -1281,7 +1281,6 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
             }
         }
         lds_barrier();
-        bundle_fetch(max(t - 1, t_first));   // next wavefront's bundle: in flight for the whole step, parked in the last stage
         CB_STAMP();
         // ---- prefetch everything this step needs from HBM that does not depend on the chain: relu masks of the 7 hidden layers and
         // the saved glimpse derivatives for this wave's tiles (consumed ~40 us later: their latency is fully hidden)
@@ -1520,6 +1519,10 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }
         lds_barrier();
         CB_STAMP();
+        // next wavefront's bundle, parked in the last stage: requested here, in a stage that issues no other loads, with ~3 us to land --
+        // not in the top-of-wavefront burst, where its four loads held up the first stage (kernel 0.714 -> 0.698 ms; at the depth stage 0.704,
+        // at the attribute stage 0.709, with the glimpse derivatives behind the first barrier 0.721)
+        bundle_fetch(max(t - 1, t_first));
         // ---- box (models.py:322-381 backward); passthrough gradient -> box-net head
         for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
             const int row = idx / (NP / 4), i = (idx - row * (NP / 4)) * 4;
