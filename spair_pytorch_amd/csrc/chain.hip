@@ -618,7 +618,7 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             hw_cur[tid] = cell_hw[cp];
         }
         lds_barrier();                       // also orders park() of the previous wavefront before S0's reads
-        prefetch(min(t + 1, t_last));
+        if constexpr (!IMG) prefetch(min(t + 1, t_last));      // (see the table stage)
         CH_STAMP();
         // ---- S0: [feat | context] (models.py:71-76,292-320), 4 floats per thread, LDS only (the store wave copies the finished rows to
         // the Xb row buffer beside BOX0)
@@ -712,6 +712,10 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         }
         lds_barrier();
         CH_STAMP();
+        // next wavefront's features and noise (parked at the end of this one): requested here, in front of the table stage, rather than at the
+        // top of the wavefront in front of S0 (kernel 0.7055 -> 0.7020 ms; at the attribute stage 0.705, at the z_depth stage 0.710).  Not on images
+        // sampled from global memory: the sampling's waits for its pixels would wait for these loads too (configs[3]: 1.607 -> 1.629 ms)
+        if constexpr (IMG) prefetch(min(t + 1, t_last));
         // ---- z_what: glimpse (modules.py:216-273, border padding) + encoder MLP (models.py:383-391)
         // The source coordinates are separable: 28 column and 28 row coordinates per cell, tabulated first (one entry per thread:
         // first tap index | "second tap inside" | "not clipped", fractional weight) instead of being re-derived by every element
