@@ -1324,19 +1324,22 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         lds_barrier();
         CB_STAMP();
         // saved glimpse derivatives for this wave's 7 ENC0 tiles in the (transposed) MFMA output layout itself -- row lane & 15, elements
-        // tile*16 + (lane>>4)*4 .. +3: one 16-byte load per tile, and the epilogue needs no transpose through LDS any more.  Requested HERE,
-        // behind the first stage's barrier, not with the other prefetches at the top of the wavefront: seven more wave-loads in that burst
-        // held up the first stage's own issue (timing-only removal of these loads: 0.733 -> 0.694 ms; at the top 0.728, here 0.719, at the
-        // start of the OBJ0 stage -- whose weight stream they then compete with -- 0.757, at the depth stage 0.725)
+        // tile*16 + (lane>>4)*4 .. +3: one 16-byte load per tile, and the epilogue needs no transpose through LDS any more.  Requested in three
+        // instalments, in the stages that stream no weights -- three tiles here (behind the first stage's barrier), two at the depth stage, two at
+        // the attribute stage -- not as one burst at the top of the wavefront, where seven more wave-loads held up the first stage's own issue
+        // (timing-only removal of these loads: 0.733 -> 0.694 ms; all at the top 0.728, all here 0.719, 4 + 3 (depth) 0.690, 3 + 2 + 2: 0.686;
+        // all at the OBJ0 stage, whose weight stream they then compete with, 0.757; all at the END of this stage 0.730)
         uint4 gxy_pf[7];
-        {
+        auto gxy_fetch = [&](int j0, int j1) {
             const size_t grow = (size_t)row_r[min(lane & 15, nc - 1)] * L.ld_gl;
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int e0 = min((wave + NW * j) * 16 + (lane >> 4) * 4, GLN - 4);
-                gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
-            }
-        }
+            for (int j = 0; j < 7; ++j)
+                if (j >= j0 && j < j1) {
+                    const int e0 = min((wave + NW * j) * 16 + (lane >> 4) * 4, GLN - 4);
+                    gxy_pf[j] = CH_GLOAD16(P.gxy + grow + e0);
+                }
+        };
+        gxy_fetch(0, 3);
         // ---- B1b: presence (32 threads per row: sum of the row's Gaussian KL elements, then d logit) and, by the same lanes, the rank-1
         // data gradient of the obj net's output layer: dHo2 = dOo (x) W_out masked by relu -- every lane of a row evaluates the row's d logit
         // (the reduction leaves the KL sum in all 32), lanes 0..24 produce 4 columns each from the sign-bit words they prefetched
@@ -1395,6 +1398,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }, [&]() { pipe_fill_w<4, 7>(a.wt[CW_ZH], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
+        gxy_fetch(3, 5);
         // ---- depth (models.py:88-97 backward); passthrough gradient -> z-net head
         if (wave == 7) copy_rows_w<25, 8>(Ab, LD_H * 2, P.dHo1, (size_t)SP_LDH * 2, row_r, nc, lane);      // OBJ1's output, untouched until the ZH stage
         for (int idx = tid; idx < MT * (NP / 4); idx += NTH) {       // 4 columns per thread: one pass over the 16 rows
@@ -1460,6 +1464,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
         }, [&]() { pipe_fill_w<4, 8>(a.wt[CW_ENC2], pipe, wave, lane); });
         lds_barrier();
         CB_STAMP();
+        gxy_fetch(5, 7);
         // ---- attributes -> gradient of the encoder output
         if (wave == 7) copy_rows_w<25, 8>(Aa, LD_H * 2, P.dHz1, (size_t)SP_LDH * 2, row_r, nc, lane);      // Z1's output, untouched until the ENC2 stage
         for (int idx = tid; idx < MT * A_; idx += NTH) {
