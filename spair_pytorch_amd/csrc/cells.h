@@ -20,6 +20,8 @@ struct CellHyper {
     float max_yx, min_yx, max_hw, min_hw;
     float prior_mean[6], prior_std[6];   // cy, cx, height, width, attr, depth
     float count_prior_prob;   // sigmoid(log(v+1e-6)), models.py:186-188
+    float range_yx, range_hw; // max - min of the two box ranges (fp32 differences, formed on the host: the chain kernels take them as scalar
+                              // operands -- formed in the kernel the compiler hoists them into vector registers the forward chain does not have)
 };
 
 struct CellBufs {

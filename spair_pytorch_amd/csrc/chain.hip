@@ -373,6 +373,7 @@ constexpr int BIAS_OFF[CW_COUNT] = {0, 112, 224, 336, 592, 720, 832, 944, 1056, 
 constexpr int BIAS_CNT[CW_COUNT] = {100, 100, NP + 8, 256, 128, 2 * A_, 100, 100, NP + 2, 100, 100, 1};
 constexpr int BIAS_TOT = 1408;
 constexpr int IMG_MAX = 128;              // side of the largest image staged in LDS (fp16)
+constexpr int IMG_LD = IMG_MAX + 2;       // its row stride (65 dwords: consecutive rows start on different banks)
 
 template <bool IMG>
 __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
@@ -385,7 +386,9 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
     __shared__ unsigned short cell_hw[32 * 32];
     __shared__ float pbase_sh[32];                                         // base coordinate of glimpse index j (stn_base), no division per element
     __shared__ __attribute__((aligned(16))) unsigned long long mbf_sh[MB_TILES * 4];
-    __shared__ __attribute__((aligned(16))) _Float16 img_sh[IMG ? IMG_MAX * IMG_MAX : 8];
+    // fp16 copy of the sample's image with a ZERO guard column and row behind the last pixel (row stride IMG_LD): the second tap of a pair
+    // that falls outside reads its zero from there -- no in-range test, select or mask multiply per tap, one address per element
+    __shared__ __attribute__((aligned(16))) _Float16 img_sh[IMG ? (IMG_MAX + 1) * IMG_LD : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Xc[MT * LD_XC];
     __shared__ __attribute__((aligned(16))) __bf16 XtZ[MT * LD_XT];
     __shared__ __attribute__((aligned(16))) __bf16 XtO[MT * LD_XT];
@@ -464,11 +467,17 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
         for (int i = tid; i < span; i += NTH) bias_sh[BIAS_OFF[l] + i] = i < BIAS_CNT[l] ? a.bias[l][min(i, BIAS_CNT[l] - 1)] : 0.f;
     }
     if constexpr (IMG) {
+        for (int i = tid; i < (a.I + 1) * IMG_LD / 2; i += NTH) reinterpret_cast<unsigned*>(img_sh)[i] = 0u;      // (the guards; IMG_LD is even)
+        __syncthreads();
         const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)b * a.I * a.I);
         for (int i = tid; i < a.I * a.I / 4; i += NTH) {
             const float4 v = src[i];
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<h4*>(&img_sh[i * 4]) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const float pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = i * 4 + k, y = p / a.I;
+                img_sh[y * IMG_LD + (p - y * a.I)] = (_Float16)pv[k];
+            }
         }
     }
     __syncthreads();
@@ -695,10 +704,10 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const float sg = ch_sigmoid(clamp10(mu + sd * noise_sh[row][k]));
                 float bv, nv;                               // box_forward (cell_math.h), element by element
                 if (k < 2) {
-                    bv = (H.max_yx - H.min_yx) * sg + H.min_yx;                         // cell_y (k = 0), cell_x (k = 1)
+                    bv = H.range_yx * sg + H.min_yx;                                    // cell_y (k = 0), cell_x (k = 1)
                     nv = H.cell_over_img * (bv + (float)(k == 0 ? (hw >> 8) : (hw & 255)));      // yt, xt
                 } else {
-                    bv = (H.max_hw - H.min_hw) * sg + H.min_hw;                         // height (k = 2), width (k = 3)
+                    bv = H.range_hw * sg + H.min_hw;                                    // height (k = 2), width (k = 3)
                     nv = bv * H.anchor / H.img;                                         // ys, xs (a true division, as the reference: the sampling
                                                                                         // grid's floor() decisions downstream are sensitive to the last bit)
                 }
@@ -747,10 +756,6 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
             const float my = (ye.x & 0x20000u) ? gmult : 0.f;
             const int r0o = y0 * a.I, r1o = (yin ? y0 + 1 : y0) * a.I;
             const float* img = a.x + (size_t)b * a.I * a.I;
-            auto px = [&](int o) -> float {
-                if constexpr (IMG) return (float)img_sh[o];
-                else return img[o];
-            };
             const uint4 xa = *reinterpret_cast<const uint4*>(&gtab[row][0][j0]), xb = *reinterpret_cast<const uint4*>(&gtab[row][0][j0 + 2]);
             const unsigned xw[4] = {xa.x, xa.z, xb.x, xb.z}, xf[4] = {xa.y, xa.w, xb.y, xb.w};
             float out[4];
@@ -761,26 +766,33 @@ __global__ __launch_bounds__(NTH) void k_chain_fwd(ChainArgs a) {
                 const bool xin = (xw[q] & 0x10000u) != 0u;
                 const float mx = (xw[q] & 0x20000u) ? gmult : 0.f;
                 const float wx1 = __uint_as_float(xf[q]), wx0 = 1.f - wx1;
-                const int x1 = xin ? x0 + 1 : x0;
-                const float m1 = xin ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
                 float v00, v01, v10, v11;
                 if constexpr (IMG) {
-                    v00 = px(r0o + x0); v01 = m1 * px(r0o + x1); v10 = n1 * px(r1o + x0); v11 = m1 * n1 * px(r1o + x1);
+                    // (a tap outside reads the zero guard: the same value as the masked tap.  volatile: left alone the compiler merges the tap
+                    //  pairs into 4-byte reads at 2-byte-aligned addresses -- legal on this target and much slower: sampling stage 3.9 -> 6.2 us)
+                    typedef const volatile __attribute__((address_space(3))) _Float16* lds_tap_t;
+                    const lds_tap_t t0 = (lds_tap_t)(img_sh + (y0 * IMG_LD + x0));
+                    v00 = (float)t0[0]; v01 = (float)t0[1]; v10 = (float)t0[IMG_LD]; v11 = (float)t0[IMG_LD + 1];
                 } else {
                     // the two taps of a row as ONE 8-byte load (4-byte aligned: global memory takes it): half the loads of the stage that the
                     // vector-memory front end bounds on images too wide for the LDS copy.  At the right border (x0 = I - 1, second tap masked)
                     // the pair starts one pixel to the left.
                     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    const float m1 = xin ? 1.f : 0.f, n1 = yin ? 1.f : 0.f;
                     const int xl = min(x0, a.I - 2);
                     const f2u p0 = *reinterpret_cast<const f2u*>(img + r0o + xl), p1 = *reinterpret_cast<const f2u*>(img + r1o + xl);
                     const bool sh = x0 != xl;
                     v00 = sh ? p0.y : p0.x; v01 = m1 * p0.y;
                     v10 = n1 * (sh ? p1.y : p1.x); v11 = m1 * n1 * p1.y;
                 }
-                out[q] = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
-                // d val / d (normalised source x, y): what the backward pass needs instead of re-gathering the image
-                const float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * mx;
-                const float gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * my;
+                // nested interpolation: the row differences d0, d1 and the column difference of the two interpolated rows are also the
+                // derivatives d val / d (normalised source x, y) -- what the backward pass needs instead of re-gathering the image --
+                // (10 operations for value + both derivatives; 18 as four weighted taps + two difference sums)
+                const float d0 = v01 - v00, d1 = v11 - v10;
+                const float top = fmaf(wx1, d0, v00), bot = fmaf(wx1, d1, v10), db = bot - top;
+                out[q] = fmaf(wy1, db, top);
+                const float gx = fmaf(wy1, d1 - d0, d0) * mx;
+                const float gy = db * my;
                 union { _Float16 h[2]; unsigned int u; } pk;      // fp16 pair: |g| <= I/2 fits, 11 significant bits
                 pk.h[0] = (_Float16)gx; pk.h[1] = (_Float16)gy;
                 gxy[q] = pk.u;
@@ -1555,7 +1567,7 @@ __global__ __launch_bounds__(NTH) void k_chain_bwd(ChainArgs a) {
                 gn += bd[BD_GNB + o];
                 const float gb = grec[row][o] + tailZ[row][NP + o] + tailO[row][NP + o];
                 const float mu = st[ST_MU_BOX + k], sd = st[ST_SD_BOX + k], eps = bd[BD_EB + k], lls = bd[BD_OBL + k], zp = zp_sh[row];
-                const float gq = k < 2 ? (gb + gn * H.cell_over_img) * (H.max_yx - H.min_yx) : (gb + gn * H.anchor / H.img) * (H.max_hw - H.min_hw);
+                const float gq = k < 2 ? (gb + gn * H.cell_over_img) * H.range_yx : (gb + gn * H.anchor / H.img) * H.range_hw;
                 const float z = mu + sd * eps;
                 const float sg = ch_sigmoid(clamp10(z));
                 const float g_z = gq * sg * (1.f - sg) * in10(z);

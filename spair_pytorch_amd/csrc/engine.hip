@@ -489,6 +489,7 @@ static int make_ctx(Ctx& c, const SpairDims* d, const SpairStep* st, const float
     H.wheel = st->wheel; H.kl_scale = st->kl_scale * d->vae_beta; H.img = (float)d->I; H.anchor = d->anchor;
     H.cell_over_img = (float)((double)d->cell_px / (double)d->I);
     H.max_yx = d->max_yx; H.min_yx = d->min_yx; H.max_hw = d->max_hw; H.min_hw = d->min_hw;
+    H.range_yx = d->max_yx - d->min_yx; H.range_hw = d->max_hw - d->min_hw;
     for (int i = 0; i < 6; ++i) { H.prior_mean[i] = d->prior_mean[i]; H.prior_std[i] = d->prior_std[i]; }
     H.count_prior_prob = st->count_prior_prob;
     c.w.cb.edge = params + c.PL.edge;
