@@ -225,6 +225,14 @@ int spair_render_fwd(const float* sprites, int ld_s, const float* nbox, const fl
 int spair_render_bwd(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth,
                      const float* aux, const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth,
                      int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
+/* The same for images with C = 2 or 3 colour channels (cfg.INPUT_IMAGE_SHAPE[0], models.py:480,524; render_c.hip): sprites fp32
+ * [N][ld_s] = [P*P][C+1] (colour.., alpha) after the sigmoid, x / recon [B][C][I][I], aux B*C*I*I float2, dlogits fp32 [N][ld_s].
+ * Generic-channel kernels (correctness and run-to-run determinism; the tuned renderers are single-channel). */
+int spair_render_fwd_rgb(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth, const float* x,
+                         float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int align_corners, void* stream);
+int spair_render_bwd_rgb(const float* sprites, int ld_s, const float* nbox, const float* pres, const float* depth, const float* aux,
+                         const float* grad_loss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int B, int HW, int C, int I,
+                         int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
 /* Backbone stem alone: conv 1 -> Cout channels, 4x4, stride `stride`, no padding, + bias + relu, over the image zero-padded to Hin x Hin
  * (pad_pre pixels before; modules.py:95-104 Backbone.padding + the first Conv2d/ReLU of Backbone.net).  x [B][I][I] fp32 (unpadded),
  * w [Cout][16], out NHWC [B][Hout][Hout][Cout] fp32 or (out_bf16) bf16.  In bf16 mode with Cout = 128, stride 2 it runs on the matrix

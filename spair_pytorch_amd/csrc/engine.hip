@@ -26,6 +26,11 @@ int render_prep(const float* nbox, const float* pres, const float* depth, int ld
 int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW, int I, int P, int ac, hipStream_t s);
 int render_bwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux, const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P, int ac, float obj_scale, float alpha_scale, int g_bf16, int s_bf16, const void* rec, hipStream_t s);
 int render_prep_supported(int HW, int I, int P, int ac);
+int render_fwd_c(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x, float* recon,
+                 float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, hipStream_t s);
+int render_bwd_c(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* aux,
+                 const float* gloss, float* dlogits, float* dnbox, float* dpres, float* ddepth, int ld_g, int B, int HW, int C, int I, int P,
+                 int ac, float obj_scale, float alpha_scale, hipStream_t s);
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
@@ -108,7 +113,8 @@ enum { PS_PREP = 0, PS_BACKBONE_FWD, PS_CELLS_FWD, PS_DECODER_FWD, PS_COUNT_KL, 
 
 static int validate(const SpairDims& d) {
     if (d.B <= 0 || d.I <= 0 || d.G <= 0 || d.P <= 0 || d.A <= 0 || d.F <= 0 || d.NP <= 0) return SPAIR_ERR_SHAPE;
-    if (d.C != 1) return SPAIR_ERR_UNSUPPORTED;            // renderer / sprites: greyscale only for now
+    if (d.C < 1 || d.C > 3) return SPAIR_ERR_UNSUPPORTED;  // colour channels: 1 (every tuned kernel) .. 3 (generic-channel renderer, render_c.hip)
+    if (d.C != 1 && d.obj_conv) return SPAIR_ERR_UNSUPPORTED;      // colour images: the per-wavefront step (either dtype), MLP object nets
     if (d.n_conv < 1 || d.n_conv > SP_MAX_CONV) return SPAIR_ERR_SHAPE;
     if (d.dtype != SPAIR_F32 && d.dtype != SPAIR_BF16) return SPAIR_ERR_DTYPE;
     if ((d.F & 3) || (d.NP & 3)) return SPAIR_ERR_ALIGN;
@@ -154,6 +160,7 @@ struct Ws {
     void* dec_stream;             // fused decoder forward: fragment stream of its three weight matrices (bf16 mode)
     float* xpad;
     float *act[SP_MAX_CONV + 1], *dact[SP_MAX_CONV + 1];
+    void* dLog16;                     // bf16 copy of dLog (colour images in the bf16 step only)
     unsigned char* act0_bits;         // sign bits of act[0] (one byte per pixel and 8 channels): conv_1's data-gradient gate, written by the stem kernel
     unsigned char* act_bits[SP_MAX_CONV + 1];      // the same for the outputs of the patch-resident strided convolutions (gates of the next layer's dgrad)
     float *feat, *dfeat;
@@ -276,13 +283,16 @@ static Ws carve(const SpairDims& d, void* base) {
     b.mbits = chain_fwd_supported(d) ? c.take<unsigned long long>((size_t)d.B * nbands * (3 * d.G - 2) * 66 * 4) : nullptr;
     w.Hd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es)); w.Hd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es));
     w.S = c.take<float>(N * w.ld_s);
-    w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * (d.obj_conv ? 4 : es)));      // (the conv decoder takes fp32 sprite gradients in both modes)
+    // (the conv decoder takes fp32 sprite gradients in both modes; the generic-channel renderer of colour images writes fp32 ones, which the
+    //  bf16 step's decoder backward reads through a bf16 copy)
+    w.dLog = reinterpret_cast<float*>(c.take_bytes(N * w.ld_s * ((d.obj_conv || d.C != 1) ? 4 : es)));
+    w.dLog16 = (d.dtype == SPAIR_BF16 && d.C != 1) ? c.take_bytes(N * w.ld_s * 2) : nullptr;
     w.dHd2 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H2 * es)); w.dHd1 = reinterpret_cast<float*>(c.take_bytes(N * SP_DEC_H1 * es));
     w.Za16 = c.take_bytes(N * L.ld_rec * 2); w.dfeat16 = c.take_bytes(N * w.ld_feat * 2);
     b.Za16 = w.Za16; b.dfeat16 = w.dfeat16;
     w.tn_part = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
     w.tn_part2 = reinterpret_cast<float*>(c.take_bytes((size_t)SPAIR_TN_PART_FLOATS * 4));
-    w.aux = c.take<float>((size_t)d.B * d.I * d.I * 2);     // float2 per pixel: (dBCE/dpre / D, pre)
+    w.aux = c.take<float>((size_t)d.B * d.C * d.I * d.I * 2);     // float2 per pixel and colour channel: (dBCE/dpre / D, pre)
     w.bce_partial = c.take<float>(render_num_blocks(d.B, d.I));
     w.rrec = c.take_bytes((size_t)N * 64);                  // the renderer's per-object records (render3.hip)
     for (int i = 0; i < PL.oc_n; ++i) {
@@ -1206,7 +1216,8 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             memset(&g, 0, sizeof(g));
             g.A = c.w.Hd2; g.lda = SP_DEC_H2; g.B = c.w.lin_wf[LIN_DEC2]; g.ldb = K2; g.C = c.w.S; g.ldc = c.w.ld_s; g.M = N; g.N = per; g.K = K2;
             g.bias = params + PL.lin[LIN_DEC2].b; g.sprite_ch = d->C + 1;
-            g.c_bf16 = b16;      // bf16 step: the sprites leave as bf16 (grey, alpha) pairs -- half the bytes for the renderer, both ways
+            g.c_bf16 = b16 && d->C == 1;      // bf16 step: the sprites leave as 16-bit (grey, alpha) pairs -- half the bytes for the renderer, both
+                                              // ways (colour images: fp32 sprites for the generic-channel renderer)
             g.obj_scale = d->obj_logit_scale; g.alpha_scale = d->alpha_logit_scale; g.alpha_bias = d->alpha_logit_bias;
             if (b16) TRY(spair_gemm_nt16_impl(g, false, c.s));
             else TRY(spair_gemm_nt_impl(g, false, d->dtype, c.s));
@@ -1222,7 +1233,10 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
             rc = render_fwd_mma(c.w.S, c.w.ld_s, c.w.rrec, x, recon, st->train ? c.w.aux : nullptr, c.w.bce_partial, d->B, L.HW, d->I,
                                 d->P, d->align_corners, c.s);
         }
-        if (rc == SPAIR_ERR_UNSUPPORTED)
+        if (d->C != 1)
+            rc = render_fwd_c(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
+                              c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, c.s);
+        else if (rc == SPAIR_ERR_UNSUPPORTED)
             rc = render_fwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, x, recon, st->train ? c.w.aux : nullptr,
                             c.w.bce_partial, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->dtype == SPAIR_BF16 && !d->obj_conv, c.s);
         TRY(rc);
@@ -1380,6 +1394,11 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     const int b16 = d->dtype == SPAIR_BF16;
     {
         ProfScope ps(PS_RENDER_BWD, c.s);
+        if (d->C != 1)
+            TRY(render_bwd_c(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
+                             P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
+                             d->alpha_logit_scale, c.s));
+        else
         TRY(render_bwd(c.w.S, c.w.ld_s, P.nbox, P.rec + (L.REC - 1), P.rec + (L.REC - 2), L.ld_rec, c.w.aux, grad_loss, c.w.dLog, P.g_nbox_r,
                        P.g_pres_r, P.g_depth_r, c.w.ld_s, d->B, L.HW, d->C, d->I, d->P, d->align_corners, d->obj_logit_scale,
                        d->alpha_logit_scale, b16 && !d->obj_conv, b16 && !d->obj_conv,
@@ -1397,6 +1416,11 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     } else if (b16) {   // decoder, bf16-stored activations and gradients: the data-gradient chain stays on the caller's stream, the three
                  // weight gradients go to the helper stream and overlap with the (latency-bound) per-cell backward chain
         const LinSpec &l2 = PL.lin[LIN_DEC2], &l1 = PL.lin[LIN_DEC1], &l0 = PL.lin[LIN_DEC0];
+        float* const dlog_f32 = c.w.dLog;
+        if (d->C != 1) {      // the generic-channel renderer left fp32 sprite gradients
+            TRY(spair_to_bf16(c.w.dLog, c.w.ld_s, c.w.dLog16, c.w.ld_s, N, c.w.ld_s, c.s));
+            c.w.dLog = reinterpret_cast<float*>(c.w.dLog16);
+        }
         {
             ProfScope ps(PS_DECODER_BWD, c.s);
             // all three data gradients in one launch (dec_fused_bwd.hip); flags bit 6 / an unsupported shape: three implicit-GEMM launches
@@ -1426,6 +1450,7 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
         }
         TRY(record_ready(ev_decoder, c.s));
         if (side) { c.s = main_s; c.tn_scratch = nullptr; }
+        c.w.dLog = dlog_f32;
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
         { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(wgrad_lin(c, LIN_DEC2, c.w.dLog, c.w.ld_s, c.w.Hd2, SP_DEC_H2, grads, N)); }

@@ -123,8 +123,10 @@ def make_image(seed, B, I, max_objects, in_chan=1):
                 d = np.abs((yy - cy) * np.cos(ang) - (xx - cx) * np.sin(ang))
                 along = np.abs((yy - cy) * np.sin(ang) + (xx - cx) * np.cos(ang))
                 glyph = np.clip(1.5 - d / 1.5, 0, 1) * (along < size * 0.45)
+            # colour images: one random colour per object (drawn only then: the greyscale streams are unchanged)
+            col = rng.uniform(0.25, 1.0, in_chan).astype(np.float32) if in_chan > 1 else np.ones(1, np.float32)
             for c in range(in_chan):
-                img[b, c] = np.maximum(img[b, c], glyph.astype(np.float32))
+                img[b, c] = np.maximum(img[b, c], col[c] * glyph.astype(np.float32))
     return img
 
 
@@ -148,6 +150,19 @@ LOOKBACK_CASES = {
     "lb2_i80_b2_step1": dict(I=80, strides=(2, 2, 2, 1, 1, 1), B=2, step=1, wseed=17, wscale=1.5, max_objects=5, lookback=2),
     "lb3_c1_b3_step7001": dict(I=48, strides=(2, 2, 2, 1, 1, 1), B=3, step=7001, wseed=18, wscale=1.0, max_objects=3, lookback=3),
 }
+# colour images (config.py:4 INPUT_IMAGE_SHAPE[0] = 3; models.py:150,163,480,524, modules.py:24,239): the fp32 per-wavefront step with the
+# generic-channel renderer (tests/test_rgb_gpu.py)
+RGB_CASES = {
+    "rgb_c1_b4_step1001": dict(I=48, strides=(2, 2, 2, 1, 1, 1), B=4, step=1001, wseed=21, wscale=1.0, max_objects=3, in_chan=3),
+    "rgb_i80_b2_step1": dict(I=80, strides=(2, 2, 2, 1, 1, 1), B=2, step=1, wseed=22, wscale=1.5, max_objects=5, in_chan=3),
+}
+
+
+def all_cases():
+    d = dict(CASES)
+    d.update(LOOKBACK_CASES)
+    d.update(RGB_CASES)
+    return d
 
 
 def grid_side(I, strides, kernels=(4, 4, 4, 1, 1, 1)):

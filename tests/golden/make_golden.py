@@ -32,7 +32,7 @@ REF = "/root/reference"
 SMALL = 4096  # tensors up to this many elements get their full gradient stored
 
 
-def _import_reference(I, strides, B, G, lookback=1):
+def _import_reference(I, strides, B, G, lookback=1, in_chan=1):
     import matplotlib
     matplotlib.use("Agg")
     tb = types.ModuleType("tensorboardX")
@@ -49,7 +49,7 @@ def _import_reference(I, strides, B, G, lookback=1):
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
     from spair import config as cfg
-    cfg.INPUT_IMAGE_SHAPE[:] = [1, I, I]
+    cfg.INPUT_IMAGE_SHAPE[:] = [in_chan, I, I]
     cfg.BATCH_SIZE = B
     cfg.N_LOOKBACK = lookback
     for layer, s in zip(cfg.DEFAULT_BACKBONE_TOPOLOGY, strides):
@@ -61,18 +61,19 @@ def _import_reference(I, strides, B, G, lookback=1):
 
 def run_case(name):
     import torch
-    case = gi.CASES[name] if name in gi.CASES else gi.LOOKBACK_CASES[name]
+    case = gi.all_cases()[name]
+    in_chan = case.get("in_chan", 1)
     I, strides, B, step = case["I"], case["strides"], case["B"], case["step"]
     G = gi.grid_side(I, strides)
-    cfg, models, modules, SummaryWriter = _import_reference(I, strides, B, G, case.get("lookback", 1))
+    cfg, models, modules, SummaryWriter = _import_reference(I, strides, B, G, case.get("lookback", 1), in_chan)
     torch.manual_seed(3)
     with contextlib.redirect_stdout(io.StringIO()):
         m = models.SPAIR(cfg.INPUT_IMAGE_SHAPE, SummaryWriter(), torch.device("cpu"))
     assert tuple(m.feature_space_dim) == (100, G, G), m.feature_space_dim
-    w = gi.make_weights(case["wseed"], case["wscale"], lookback=case.get("lookback", 1))
+    w = gi.make_weights(case["wseed"], case["wscale"], in_chan=in_chan, lookback=case.get("lookback", 1))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
 
-    x = gi.make_image(100 + case["wseed"], B, I, case["max_objects"])
+    x = gi.make_image(100 + case["wseed"], B, I, case["max_objects"], in_chan=in_chan)
     noise = gi.make_noise(200 + case["wseed"], B, G)
 
     # ---- inject the noise in the reference's draw order (models.py:333-336,84,95,402-403)
@@ -236,7 +237,7 @@ if __name__ == "__main__":
         run_init_hashes()
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for nm in list(gi.CASES) + list(gi.LOOKBACK_CASES):
+        for nm in gi.all_cases():
             subprocess.check_call([sys.executable, __file__, "--case", nm], env=env)
         subprocess.check_call([sys.executable, __file__, "--units"], env=env)
         subprocess.check_call([sys.executable, __file__, "--init"], env=env)

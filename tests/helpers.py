@@ -12,16 +12,15 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def load_case(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    case = gi.CASES[name] if name in gi.CASES else gi.LOOKBACK_CASES[name]
-    return z, case
+    return z, gi.all_cases()[name]
 
 
 def oracle_cfg(case, **kw):
-    return orc.OracleConfig(image_shape=(1, case["I"], case["I"]), conv_strides=tuple(case["strides"]), n_lookback=case.get("lookback", 1), **kw)
+    return orc.OracleConfig(image_shape=(case.get("in_chan", 1), case["I"], case["I"]), conv_strides=tuple(case["strides"]), n_lookback=case.get("lookback", 1), **kw)
 
 
 def case_weights(case, requires_grad=False):
-    w = gi.make_weights(case["wseed"], case["wscale"], lookback=case.get("lookback", 1))
+    w = gi.make_weights(case["wseed"], case["wscale"], in_chan=case.get("in_chan", 1), lookback=case.get("lookback", 1))
     return {k: torch.from_numpy(v).clone().requires_grad_(requires_grad and not k.startswith("attn."))
             for k, v in w.items()}
 

@@ -87,8 +87,40 @@ def test_flat_layout_matches_module():
     assert lib.spair_param_total(ctypes.byref(d)) >= end
     lib.spair_workspace_bytes.restype = ctypes.c_int64
     assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
-    d.C = 3   # RGB sprites are not implemented: must be refused, not silently mis-rendered
+    d.C = 4   # more than three colour channels: refused, not silently mis-rendered (1..3 are served: tests/test_rgb_gpu.py)
     assert lib.spair_workspace_bytes(ctypes.byref(d)) < 0
+
+
+def test_flat_layout_of_colour_images():
+    """cfg.INPUT_IMAGE_SHAPE[0] = 3 (config.py:4; models.py:150,163,480,524): the stem takes 3 input channels, the object encoder 3 x 28 x 28
+    inputs, the decoder emits 4 channels per sprite texel -- every module parameter has a slot of its shape."""
+    _fresh_cfg()
+    from spair_pytorch_amd import _lib as L, config as cfg
+    from spair_pytorch_amd.models import SPAIR, make_dims
+    old = list(cfg.INPUT_IMAGE_SHAPE)
+    try:
+        cfg.INPUT_IMAGE_SHAPE[0] = 3
+        m = SPAIR([3, 128, 128], None, torch.device("cpu"))
+        d = make_dims(4, [3, 128, 128], m.backbone.topology, "f32")
+        assert d.C == 3
+        lib = L.lib()
+        named = dict(m.named_parameters())
+        assert tuple(named["backbone.net.conv_0.weight"].shape) == (128, 3, 4, 4)
+        assert tuple(named["object_encoder.dense0.weight"].shape) == (256, 3 * 28 * 28)
+        assert tuple(named["object_decoder.out.weight"].shape) == (4 * 28 * 28, 256)
+        n = lib.spair_param_count(ctypes.byref(d))
+        assert n == len(named) == 56
+        name = ctypes.create_string_buffer(128)
+        off, ndim, shape = ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i in range(n):
+            assert lib.spair_param_info(ctypes.byref(d), i, name, 128, ctypes.byref(off), shape, ctypes.byref(ndim)) == 0
+            assert tuple(named[name.value.decode()].shape) == tuple(shape[k] for k in range(ndim.value))
+        lib.spair_workspace_bytes.restype = ctypes.c_int64
+        assert lib.spair_workspace_bytes(ctypes.byref(d)) > 0
+        for dt in ("f32", "bf16"):
+            assert lib.spair_workspace_bytes(ctypes.byref(make_dims(4, [3, 128, 128], m.backbone.topology, dt))) > 0
+    finally:
+        cfg.INPUT_IMAGE_SHAPE[:] = old
 
 
 def test_flat_layout_of_the_conv_object_variant():

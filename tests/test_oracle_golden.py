@@ -9,7 +9,8 @@ from helpers import KL_NAMES, case_noise, case_weights, load_case, oracle_cfg
 from oracle import spair_oracle as orc
 
 # c4 (32x32 grid, 1024 sequential cells) is the slow one: ~1 min
-CASES = list(gi.CASES) + list(gi.LOOKBACK_CASES)      # (the N_LOOKBACK = 2 fixtures pin the generalised context gather)
+# (the N_LOOKBACK = 2 / 3 fixtures pin the generalised context gather, the rgb_* ones the C = 3 channel plumbing)
+CASES = list(gi.CASES) + list(gi.LOOKBACK_CASES) + list(gi.RGB_CASES)
 
 
 def rel(a, b):
