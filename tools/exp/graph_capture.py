@@ -8,13 +8,14 @@ from spair_pytorch_amd.models import SPAIR
 from spair_pytorch_amd.optim import FusedAdam
 from spair_pytorch_amd import _lib as L
 
-B, I = int(os.environ.get("GB", 256)), 128
+B, I, C = int(os.environ.get("GB", 256)), 128, int(os.environ.get("GC", 1))      # GC=3: the colour-image variant (per-wavefront launches)
 cfg.set_grid(I, (2, 2, 2, 1, 1, 1))
+cfg.INPUT_IMAGE_SHAPE[0] = C
 torch.manual_seed(3)
 dev = torch.device("cuda:0")
-model = SPAIR([1, I, I], None, dev, compute_dtype="bf16").to(dev)
+model = SPAIR([C, I, I], None, dev, compute_dtype="bf16").to(dev)
 opt = FusedAdam(model, lr=1e-4)
-x = (torch.rand(B, 1, I, I, device=dev) > 0.9).float()
+x = (torch.rand(B, C, I, I, device=dev) > 0.9).float()
 L.lib().spair_init()
 def step():
     loss, recon, zw, zp = model(x, 2000)
