@@ -29,7 +29,8 @@ extern "C" {
 
 /* Hyper-parameters = /root/reference/spair/config.py:3-76 plus the batch geometry. */
 typedef struct SpairDims {
-    int B, C, I, G;            /* batch, image channels, image side, grid side */
+    int B, C, I, G;            /* batch, image channels (config.py:4 INPUT_IMAGE_SHAPE[0]: 1 = the benchmarked fused kernels; 2, 3 = colour
+                                * images on the per-wavefront launches with the generic-channel renderer, either dtype), image side, grid side */
     int P, A, F, NP;           /* OBJECT_SHAPE[0], N_ATTRIBUTES, N_BACKBONE_FEATURES, N_PASSTHROUGH_FEATURES */
     int n_conv;                /* backbone conv layers before conv_out (config.py:7-14) */
     int conv_k[8], conv_s[8], conv_c[8];
