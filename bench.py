@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the bounded BASELINE configs[3] sub-record (256x256, 32x32 grid, batch 64) of the default single-GPU line")
     ap.add_argument("--config3-steps", type=int, default=20)
+    ap.add_argument("--dense-input", action="store_true", help="diagnostic: uniform-noise images (no zero pixels) instead of scattered digits; "
+                                                                "config.workload says so")
     ap.add_argument("--repeat", type=int, default=3, help="repeat the K-step timed region this many times; the MEDIAN repeat is reported")
     ap.add_argument("--prof-every", type=int, default=4, help="record the per-kernel HIP event pairs on every n-th timed step")
     ap.add_argument("--prof-mask", type=lambda v: int(v, 0), default=-1, help="bit mask of the engine's event-pair slots to record (-1 = all)")
@@ -399,6 +401,8 @@ def main():
     opt = FusedAdam(model, lr=1e-4)
     B = args.batch
     x = torch.from_numpy(scattered_digits(1234 + rank, B, args.image, 11)[0]).to(dev)   # resident in HBM
+    if args.dense_input:      # diagnostic: images without a single zero pixel (what the kernels do on data that is not scattered digits on black)
+        x = torch.rand(x.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank)) * 0.9 + 0.05
     torch.manual_seed(7 + rank)                            # noise seed, per rank
     gstep = [args.global_step]
     last = {}
@@ -494,6 +498,8 @@ def main():
         which = "BASELINE configs[3] (STN gather stress)"
     else:
         which = "custom (not a BASELINE config)"
+    if args.dense_input:
+        which = "custom (not a BASELINE config; --dense-input: uniform-noise images without zero pixels)"
     workload = ("%s: %dx%d synthetic scattered digits (<=11), %dx%d grid, batch %d/GPU, fwd+bwd+Adam, global_step %d+ (wheel %s)"
                 % (which, args.image, args.image, d.G, d.G, B, args.global_step, "off" if args.global_step >= 1000 else "on"))
     out = dict(metric="SPAIR train images/sec + ELBO, 128x128 scattered-MNIST, batch 256", value=world * B * K / dt, unit="images/sec",
@@ -507,7 +513,7 @@ def main():
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
     if ddp_rec is not None:
         out["ddp"] = ddp_rec
-    default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16"
+    default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16" and not args.dense_input
     if world == 1 and not args.no_sweep and (args.sweep or default_workload):
         # BASELINE configs[4] on one GPU: "z_pres discovery-prior curriculum sweep (max_objects 1 -> 11) ... sequential compositing kernel
         # under varying active-cell density".  Three axes, every point from the same model and optimizer state:
