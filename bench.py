@@ -331,7 +331,8 @@ def config3_record(dev, args, strides):
                ms_per_step=dt / K * 1e3, images_per_sec=B * K / dt, steps=K, warmup=5, elbo=float(loss.item()),
                kernels={k: {f: v for f, v in kernels[k].items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "stage_ms", "l2_stream")}
                         for k in keep if k in kernels},
-               step_breakdown_ms=per_step)
+               step_breakdown_ms=per_step,
+               chain_status=model.chain_status())      # band-split hand-offs: 0 = all arrived, 1 = a wait timed out (then the ELBO above is NaN)
     cfg.set_grid(args.image, strides)
     return rec
 
@@ -626,6 +627,9 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if out.get("config3", {}).get("chain_status") == 1:      # a band-split hand-off timed out: that sub-record is not a measurement
+        sys.stderr.write("bench.py: the configs[3] sub-record's per-cell chain reported a hand-off time-out (chain_status 1)\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":
