@@ -13,6 +13,7 @@ global_step >= 2000 (training wheel off: every gradient path live, nothing skipp
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -332,7 +333,9 @@ def config3_record(dev, args, strides):
                kernels={k: {f: v for f, v in kernels[k].items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "stage_ms", "l2_stream")}
                         for k in keep if k in kernels},
                step_breakdown_ms=per_step,
-               chain_status=model.chain_status())      # band-split hand-offs: 0 = all arrived, 1 = a wait timed out (then the ELBO above is NaN)
+               chain_status=model.chain_status(),      # band-split hand-offs: 0 = all arrived, 1 = a wait timed out (then the ELBO above is NaN)
+               step_status=model.step_status())        # sticky bits over all its steps: 1 = hand-off time-out, 2 = a loss term was NaN / inf
+    rec["finite"] = bool(rec["step_status"] == 0 and math.isfinite(rec["elbo"]))
     cfg.set_grid(args.image, strides)
     return rec
 
@@ -413,6 +416,7 @@ def main():
         loss, recon, z_where, z_pres = model(x, gstep[0])
         last["z_pres"] = z_pres
         last["z_where"] = z_where
+        last["loss"] = loss
         loss.backward()
         if world > 1:
             if bwd_end[0] is not None:
@@ -512,6 +516,9 @@ def main():
                ms_per_step_note="ms_per_step / value = the MEDIAN of the repeats",
                elbo=float(terms[0].item()), elbo_terms=[float(v) for v in terms[:9].tolist()],
                roofline=roof, kernels=kernels, step_breakdown_ms=per_step_ms)
+    # SpairStep.status: sticky bits over every step this model ran (1 = a band-split hand-off timed out, 2 = a loss term was NaN / inf)
+    out["step_status"] = model.step_status()
+    out["finite"] = bool(out["step_status"] == 0 and all(math.isfinite(v) for v in out["elbo_terms"]))
     if ddp_rec is not None:
         out["ddp"] = ddp_rec
     default_workload = args.image == 128 and B == 256 and d.G == 16 and args.dtype == "bf16" and not args.dense_input
@@ -533,7 +540,10 @@ def main():
         nsl = len(SLOT_NAMES)
         R_F, R_B = SLOT_NAMES.index("render_fwd"), SLOT_NAMES.index("render_bwd")
 
+        model.raise_on_nonfinite = False                   # a dead point is RECORDED (finite: false, sweep_ok: false, exit code 4), not raised
+
         def restore():
+            model.clear_step_status()
             model.flat_parameters().copy_(snap[0])         # every point starts from the same model and optimizer state ...
             opt.load_state_dict(snap[1])
             opt.lr = 0.0                                   # ... and keeps it: the step runs whole (fwd + bwd + the Adam kernel), the
@@ -566,11 +576,17 @@ def main():
             ms_s = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
             st_ = step_scalars(gs, B)
             zp, zw = last["z_pres"], last["z_where"]
+            # a point that went non-finite is not a measurement: the last step's loss, the model's sticky status word over the point's steps
+            # (SpairStep.status: bit 1 = a loss term was NaN / inf) and the parameters themselves
+            status = model.step_status()
+            loss_v = float(last["loss"].item())
+            finite = bool(status == 0 and math.isfinite(loss_v) and torch.isfinite(model.flat_parameters()).all().item()
+                          and torch.isfinite(zw).all().item())
             side_px = float(zw[:, 2:4].mean().item()) * args.image       # z_where = (xt, yt, xs, ys) in image units (models.py:375-381)
             # presence-weighted footprint: what the compositing kernels walk
             rec = dict(axis=label, global_step=gs, count_prior_prob=float(st_.count_prior_prob), wheel=float(st_.wheel), ms_per_step=ms_s,
                        ms_per_step_wall_mean=wall_ms, ms_per_step_max=per[-1], images_per_sec=B / ms_s * 1e3,
-                       mean_z_pres=float(zp.mean().item()), mean_box_side_px=side_px,
+                       mean_z_pres=float(zp.mean().item()), mean_box_side_px=side_px, loss=loss_v, finite=finite, step_status=status,
                        render_fwd_ms=pm[R_F] / max(pc[R_F], 1), render_bwd_ms=pm[R_B] / max(pc[R_B], 1))
             x = x_main
             return rec
@@ -609,11 +625,16 @@ def main():
                 r = time_point(args.global_step, x_main, "density")
                 r["target_mean_z_pres"] = target_pres
                 r["box_size_logit_bias"] = size_bias
+                # the calibration must have landed: the timed steps' mean presence (fresh noise per step) within 10 % of the target
+                r["presence_miss"] = abs(r["mean_z_pres"] - target_pres) / target_pres
+                r["on_target"] = bool(r["finite"] and r["presence_miss"] <= 0.10)
                 sweep.append(r)
         restore()
+        model.raise_on_nonfinite = True
         opt.lr = float(snap[1]["lr"])
         lib.spair_prof_select(ctypes.c_ulonglong(args.prof_mask & 0xFFFFFFFFFFFFFFFF))
         out["sweep"] = sweep
+        out["sweep_ok"] = bool(all(r["finite"] and r.get("on_target", True) and r["mean_box_side_px"] > 1.0 for r in sweep))
         out["sweep_note"] = ("BASELINE configs[4] on ONE GPU (the 8-GPU form is the driver's): schedule / object-count / density axes, %d timed steps per "
                              "point behind 2 warm steps, every point from the same model and optimizer state with the learning rate at 0 (whole "
                              "steps, frozen parameters: a point measures the state it names); ms_per_step = median of the per-step "
@@ -627,6 +648,17 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not out["finite"]:
+        sys.stderr.write("bench.py: the timed steps produced a non-finite loss (step_status %d): not a measurement\n" % out["step_status"])
+        sys.exit(5)
+    if out.get("sweep_ok") is False:      # a sweep point went non-finite or missed the state it names: the record says which, the exit code says so
+        dead = [(r["axis"], r.get("global_step"), r.get("target_mean_z_pres"), r.get("box_size_logit_bias")) for r in out["sweep"]
+                if not (r["finite"] and r.get("on_target", True) and r["mean_box_side_px"] > 1.0)]
+        sys.stderr.write("bench.py: configs[4] sweep points non-finite or off their target state: %s\n" % dead)
+        sys.exit(4)
+    if out.get("config3", {}).get("finite") is False and out["config3"].get("chain_status") != 1:
+        sys.stderr.write("bench.py: the configs[3] sub-record's steps produced a non-finite loss\n")
+        sys.exit(5)
     if out.get("config3", {}).get("chain_status") == 1:      # a band-split hand-off timed out: that sub-record is not a measurement
         sys.stderr.write("bench.py: the configs[3] sub-record's per-cell chain reported a hand-off time-out (chain_status 1)\n")
         sys.exit(3)

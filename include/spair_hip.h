@@ -74,6 +74,15 @@ typedef struct SpairStep {
     int draw_noise;            /* spair_forward only: 1 = fill eps_box/eps_attr/eps_depth/u_pres from noise_seed first (what spair_noise_fill
                                 * does, but on the helper stream beside the backbone); the buffers must be writable */
     unsigned long long noise_seed;
+    /* Non-finite / failed steps made loud without a host synchronisation (the reference RAISES on any NaN in its forward:
+     * spair/debug_tools.py:245-271, called at models.py:65,108,245).  spair_forward's loss kernel evaluates
+     *   bits = 1 * (a band-split hand-off of the per-cell chain ever timed out on this workspace) | 2 * (a loss term of THIS forward is NaN / inf)
+     * and, where the pointers are non-null, writes
+     *   status[0] |= bits (sticky), status[1] = bits (this step; spair_adam_guarded's skip word)   -- two ints in device memory, caller-owned;
+     *   *status_host = bits, only when bits != 0   -- one int of host memory the device can write (spair_host_word_alloc), so that the
+     *   caller can poll it with a plain load at any later point (a normal step never touches it).  Both may be NULL. */
+    int* status;
+    int* status_host;
 } SpairStep;
 
 /* Optional: create the current device's helper stream now (otherwise on the first spair_forward / spair_backward). */
@@ -88,7 +97,8 @@ int64_t spair_workspace_bytes(const SpairDims* d);
 
 /* ---- the training step ---------------------------------------------------------------------
  * forward  == SPAIR.forward (models.py:35-131): backbone -> per-cell loop -> KL -> render -> loss.
- *   loss_out[0]=total, [1]=BCE sum, [2..8]=KL cy,cx,height,width,attr,depth,pres (batch means).
+ *   loss_out (>= 10 floats): [0]=total, [1]=BCE sum, [2..8]=KL cy,cx,height,width,attr,depth,pres (batch means), [9]=total again (a
+ *   second copy for a host layer that hands the loss out as a view: an in-place op on it then leaves the logged terms [0..8] alone).
  * backward == loss.backward() (train.py:66): accumulates into `grads` (same layout as params).
  * Noise maps are NCHW: eps_box[B,4,G,G] (cy,cx,height,width), eps_attr[B,A,G,G],
  * eps_depth[B,1,G,G], u_pres[B,1,G,G]. */
@@ -110,6 +120,16 @@ int spair_backward_ev(const SpairDims* d, const SpairStep* st, const float* para
 /* torch.optim.Adam(lr) defaults (train.py:44) on flat buffers, one launch. */
 int spair_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                float beta1, float beta2, float eps, int step, void* stream);
+/* The same update, guarded: if `skip` (device int, e.g. SpairStep.status + 1) is non-zero the whole step is left out -- parameters and
+ * both moments untouched -- and counters[0] is incremented; an element whose gradient is NaN / inf is left out on its own and counters[1]
+ * is set to 1.  lr * NaN never reaches a parameter.  `counters`: two device ints, caller-owned and caller-zeroed; the caller decrements its
+ * bias-correction step for a skipped step if it wants torch's numbers after a recovery (FusedAdam reads the counter where it
+ * synchronises anyway).  skip may be NULL (element guard only). */
+int spair_adam_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, int step, const int* skip, int* counters, void* stream);
+/* One int of host memory that kernels can store to (hipHostMalloc, mapped + coherent), zero-initialised: SpairStep.status_host. */
+int spair_host_word_alloc(int** out);
+int spair_host_word_free(int* word);
 /* Copy a per-row quantity of the last forward into an NCHW map [B,ch,G,G].
  * which: 0 z_attr, 1 z_depth, 2..7 mean of cy,cx,height,width,attr,depth, 8..13 their sigma, 14 count-prior p_z;
  * after a backward, its per-cell latent gradients: 100 d box head latents [8] (mean 4 | log-std 4), 101 d encoder output [2A], 102 d depth

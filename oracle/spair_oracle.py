@@ -311,8 +311,9 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
     return to_map(z_where), to_map(z_attr), to_map(z_depth), to_map(z_pres), dist
 
 
-def compute_kl(dist, z_pres, global_step, cfg: OracleConfig):
-    """models.py:169-262."""
+def compute_kl(dist, z_pres, global_step, cfg: OracleConfig, p_z_out: Optional[list] = None):
+    """models.py:169-262.  ``p_z_out`` (a list) receives the [B,1,G,G] map of p(z_pres = 1 | counts so far) (models.py:217), which the
+    reference does not keep: the count-prior tests compare the kernel's saved map with it cell by cell."""
     B, _, G, _ = z_pres.shape
     HW = G * G
     KL = {}
@@ -321,18 +322,19 @@ def compute_kl(dist, z_pres, global_step, cfg: OracleConfig):
         var_ratio = (sigma / s) ** 2
         t1 = ((mu - m) / s) ** 2
         KL[name] = z_pres * (0.5 * (var_ratio + t1 - 1 - var_ratio.log()))
-    support = torch.arange(HW + 1, dtype=torch.float32)
+    support = torch.arange(HW + 1, dtype=z_pres.dtype)      # (fp32 as the reference; a float64 z_pres runs the recursion in float64)
     log_odds = exponential_decay(global_step, **cfg.count_prior)
     prob = 1 / ((-log_odds).exp() + 1)
     cd = (1 - prob) * (prob ** support)
     cd = (cd / cd.sum()).repeat(B, 1)
-    count = torch.zeros(B, 1)
-    cells = []
+    count = torch.zeros(B, 1, dtype=z_pres.dtype)
+    cells, pzs = [], []
     zp = z_pres.reshape(B, HW)
     for i in range(HW):
         q = torch.clamp(support - count, min=0.0, max=float(HW - i)) / (HW - i)
         p_z = (cd * q).sum(1, keepdim=True)
         pr = zp[:, i:i + 1]
+        pzs.append(p_z.detach())
         cells.append(pr * (torch.log(pr + 1e-9) - torch.log(p_z + 1e-9))
                      + (1 - pr) * (torch.log(1 - pr + 1e-9) - torch.log(1 - p_z + 1e-9)))
         s = torch.round(pr.detach())
@@ -340,6 +342,8 @@ def compute_kl(dist, z_pres, global_step, cfg: OracleConfig):
         cd = cd1 / cd1.sum(1, keepdim=True).clamp(min=1e-6)
         count = count + s
     KL["pres_dist"] = torch.cat(cells, 1).view(B, 1, G, G)
+    if p_z_out is not None:
+        p_z_out.append(torch.cat(pzs, 1).view(B, 1, G, G))
     return KL
 
 

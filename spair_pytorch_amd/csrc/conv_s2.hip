@@ -190,7 +190,7 @@ __global__ __launch_bounds__(768, 3) void k_conv_s2k4_patch(ConvPatchArgs a) {
             const uint4 v = *reinterpret_cast<const uint4*>(cs + row * CP_LDC + ch);
             buf_store16(rout, (m0 + row) < mend ? ((unsigned)(m0 + row) * CP_C + ch) * 2u : BUF_OOB, v);
             if (a.mask) {        // (uniform) post-ReLU values: a channel is on iff its 16 bits are not zero
-                auto nz2 = [](unsigned w) { return (unsigned)((w & 0xffffu) != 0u) | ((unsigned)((w >> 16) != 0u) << 1); };
+                auto nz2 = [](unsigned w) { return (unsigned)((int)(w << 16) > 0) | ((unsigned)((int)w >> 16 > 0) << 1); };      // as a signed 16-bit value > 0: the gate `activation > 0` exactly (-0.0 and NaN stay off)
                 const unsigned byte = nz2(v.x) | (nz2(v.y) << 2) | (nz2(v.z) << 4) | (nz2(v.w) << 6);
                 if ((m0 + row) < mend) a.mask[(size_t)(m0 + row) * 16 + (tid & 15)] = (unsigned char)byte;
             }

@@ -34,7 +34,7 @@ int render_bwd_c(const float* S, int ld_s, const float* nbox, const float* pres,
 int loss_count_kl(const CellLayout& L, const CellBufs& P, float prior_prob, float* klp, hipStream_t s);
 int loss_gauss_kl_blocks(const CellLayout& L);
 int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, float* partial, hipStream_t s);
-int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale, float beta, float* loss_out, const int* failed, hipStream_t s);
+int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale, float beta, float* loss_out, const int* failed, int* status, int* status_host, hipStream_t s);
 
 #define TRY(expr)                      \
     do {                               \
@@ -127,6 +127,7 @@ static int validate(const SpairDims& d) {
     }
     if (h != d.G) return SPAIR_ERR_SHAPE;
     if (d.G * d.G + 1 > 1025) return SPAIR_ERR_UNSUPPORTED;
+    if (d.A + 5 > 64) return SPAIR_ERR_UNSUPPORTED;        // k_gauss_kl (loss.hip): one lane per latent element of a cell (A attributes + 4 box + 1 depth)
     if (d.lookback < 0 || d.lookback > 3) return SPAIR_ERR_UNSUPPORTED;
     if (d.lookback > 1 && d.G > 32) return SPAIR_ERR_UNSUPPORTED;
     if (d.obj_conv) {   // convolutional object encoder / decoder variant: per-wavefront launches, the convolutions themselves in fp32 (objconv.hip)
@@ -742,7 +743,7 @@ static int backbone_fwd(Ctx& c) {
             // 128 -> 128 channel 4x4 / stride-2 layers: the patch-resident kernel (conv_s2.hip), 2.3x fewer operand bytes from L2
             ProfScope ps(i == 1 ? PS_CONV1_FWD : -1, c.s);
             const int rc = conv_s2k4_patch_fwd16(c.w.act[i - 1], c.w.conv_wf[i], c.params + cs.b, out, d.B, cs.hin, cs.hout, cs.cin, cs.cout, cs.k, cs.s, c.s,
-                                                 c.st.train ? c.w.act_bits[i] : nullptr);
+                                                 c.w.act_bits[i]);      // (also with train = 0: the backward picks its gate from the geometry alone)
             if (rc == SPAIR_OK) continue;
             if (rc != SPAIR_ERR_UNSUPPORTED) return rc;
         }
@@ -1245,7 +1246,8 @@ extern "C" int spair_forward(const SpairDims* d, const SpairStep* st, const floa
     ProfScope psl(PS_LOSS, c.s);
     TRY(loss_finalize(c.w.bce_partial, render_num_blocks(d->B, d->I), c.w.kl_partial, loss_gauss_kl_blocks(L), c.w.klp, d->B,
                       st->kl_scale, d->vae_beta, loss_out,
-                      c.use_chain && c.w.chain_sync ? c.w.chain_sync + CHAIN_SYNC_STICKY(d->B, chain_bands(*d)) : nullptr, c.s));
+                      c.use_chain && c.w.chain_sync ? c.w.chain_sync + CHAIN_SYNC_STICKY(d->B, chain_bands(*d)) : nullptr, st->status,
+                      st->status_host, c.s));
     return SPAIR_OK;
 }
 

@@ -38,7 +38,10 @@ __device__ __forceinline__ float kl_wave_sum(float v) {
 //     phases with NA = NBR, NBR - 1, ..., 1 active registers, each compiled for its own NA -- half the bin work on average, no branches.
 // (Absolute bins with clamps cost 9 instructions per pair of bins on all NBR registers of every step: 0.46 ms at 32 x 32 cells, where this
 //  kernel is exposed behind the chain)  The bins run as PAIRS on the packed fp32 pipe; only the last active register can hold
-// bins past `rem` (residues of 1 - rem * (1 / rem) ~ 1e-7): its factor is clamped to 1 so that they cannot grow.
+// bins past `rem`: its factor is clamped to 1, and 1 / rem is rounded so that the bin AT `rem` gets exactly 1 (kl_step) -- bins past `rem` stay
+// exactly empty.  (Round 5's form left residues of 1 - rem * (1 / rem) there and, in the phases with an odd register count, ran the dropped
+// register through the packed arithmetic unclamped: the residues grew geometrically through runs of present cells -- NaN loss at mean
+// z_pres ~ 0.7.  kl_phase also empties the dropped register at every hand-over.)
 // WPB waves (= samples) per workgroup.  The kernel runs on the helper stream beside the decoder and the forward renderer; its waves are single
 // dependent chains that take issue slots from whatever shares their SIMD.  Four per workgroup (one per SIMD of a quarter of the CUs) is the
 // measured optimum at 16 x 16 cells, B = 256: 16 / 8 / 4 / 2 / 1 waves per workgroup = step 3.289 / 3.246 / 3.221 / 3.274 / 3.336 ms -- packed, the
@@ -51,7 +54,12 @@ __device__ __forceinline__ void kl_step(kl_f2 (&c2)[NP], const kl_f2 (&e2)[NP], 
     constexpr int PA = (NA + 1) / 2;                 // active pairs
     const float z = znext;
     znext = zs[min(i + 1, HW - 1)];
-    const float rem = (float)(HW - i), inv_rem = kl_rcp(rem);      // x * (1/r) is within 1-2 ulp of x / r
+    // q_j = j * (1 / rem) is within 1-2 ulp of j / rem.  The one bin where that matters is j = rem: the reference's rem / rem is EXACTLY 1, so
+    // a cell that is off empties that bin (factor 1 - 1) and a cell that is on keeps it whole.  1 / rem is therefore rounded UP when
+    // rem * (1 / rem) < 1 (exact test through the fma): the product is then >= 1 and the clamp below makes it 1 -- no residue is ever
+    // left in a bin past `rem` (before: ~1e-7 of the largest bin per absent cell, re-normalised upwards to ~1e-5 of p_z in dense grids).
+    const float rem = (float)(HW - i), r0 = kl_rcp(rem);
+    const float inv_rem = fmaf(rem, r0, -1.f) < 0.f ? __builtin_bit_cast(float, __builtin_bit_cast(int, r0) + 1) : r0;
     const bool on = rintf(z) != 0.f;                 // torch.round: half to even
     // the factor of c: q where the cell is on, 1 - q where it is off = sa * q + sb with wave-uniform (sa, sb) -- exact either way
     const float sa = on ? 1.f : -1.f, sb = on ? 0.f : 1.f;
@@ -90,6 +98,11 @@ __device__ __forceinline__ void kl_step(kl_f2 (&c2)[NP], const kl_f2 (&e2)[NP], 
 template <int NA, int NP>
 __device__ __forceinline__ void kl_phase(kl_f2 (&c2)[NP], const kl_f2 (&e2)[NP], const float* zs, float* pzs, int HW, int lane, float& znext) {
     // steps with floor((HW - i) / 64) + 1 == NA
+    // Register NA dropped out at this phase change (its bins are all past `rem` now: no mass, but a residue of 1 - rem * (1 / rem) may sit
+    // in it).  In an odd phase it is the upper half of the last PAIR and still runs through the packed arithmetic with q = j / rem > 1:
+    // left alone, the residue is multiplied by q on every present cell, is never shifted out, and is summed into p_z and the normaliser
+    // -- it grows geometrically through runs of present cells until p_z > 1 (NaN loss at mean z_pres ~ 0.7).  Empty it here: 0 * q stays 0.
+    if constexpr (NA & 1) c2[NA / 2].y = 0.f;
     const int lo = max(0, HW - 64 * NA + 1), hi = min(HW - 1, HW - 64 * (NA - 1));
     for (int i = lo; i <= hi; ++i) kl_step<NA, NP>(c2, e2, zs, pzs, i, HW, lane, znext);
     if constexpr (NA > 1) kl_phase<NA - 1, NP>(c2, e2, zs, pzs, HW, lane, znext);
@@ -180,7 +193,8 @@ __global__ __launch_bounds__(256) void k_gauss_kl(CellLayout L, CellBufs P, Cell
 // loss_out[0]=total, [1]=BCE, [2..7]=Gaussian KLs * kl_scale, [8]=presence KL * kl_scale
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ bce_partial, int n_bce, const float* __restrict__ kl_partial,
                                                        int n_kl, const float* __restrict__ klp, int B, float kl_scale, float beta,
-                                                       float* __restrict__ loss_out, const int* __restrict__ failed) {
+                                                       float* __restrict__ loss_out, const int* __restrict__ failed,
+                                                       int* __restrict__ status, int* __restrict__ status_host) {
     // all eight sums in one pass: every load of a thread is issued before the first add, one LDS reduction for the lot
     // (eight block reductions in sequence, each behind its own dependent loads, took 23 us between the renderer's two passes)
     __shared__ float red[4][8];
@@ -223,7 +237,14 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
         for (int k = 0; k < 7; ++k) { loss_out[2 + k] = kls[k]; kl_total += kls[k]; }
         loss_out[1] = bce;
         // `failed`: the band-split chain's sticky time-out word (chain.h) -- a step whose hand-off timed out announces itself as a NaN loss
-        loss_out[0] = (failed && *failed) ? __builtin_nanf("") : bce + beta * kl_total;
+        const int timed_out = (failed && *failed) ? 1 : 0;
+        const float total = bce + beta * kl_total;
+        loss_out[0] = loss_out[9] = timed_out ? __builtin_nanf("") : total;
+        // SpairStep.status / status_host (include/spair_hip.h): a failed or non-finite step announces itself without a host synchronisation
+        // (every loss term feeds `total`, so one test covers the nine)
+        const int bits = timed_out | (fabsf(total) <= 3.402823466e38f ? 0 : 2);
+        if (status) { status[1] = bits; if (bits) status[0] |= bits; }
+        if (status_host && bits) *(volatile int*)status_host = bits;
     }
 }
 
@@ -252,8 +273,9 @@ int loss_gauss_kl(const CellLayout& L, const CellBufs& P, const CellHyper& H, fl
     return SPAIR_OK;
 }
 int loss_finalize(const float* bce_partial, int n_bce, const float* kl_partial, int n_kl, const float* klp, int B, float kl_scale,
-                  float beta, float* loss_out, const int* failed, hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, bce_partial, n_bce, kl_partial, n_kl, klp, B, kl_scale, beta, loss_out, failed);
+                  float beta, float* loss_out, const int* failed, int* status, int* status_host, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, bce_partial, n_bce, kl_partial, n_kl, klp, B, kl_scale, beta, loss_out, failed,
+                       status, status_host);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
 }

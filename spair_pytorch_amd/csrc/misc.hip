@@ -1,6 +1,7 @@
 // Small utility kernels: fused Adam (K9), counter-based noise, input padding, weight preparation,
 // per-row -> NCHW map export, and the direct first backbone layer (Cin = image channels).
 #include <cstdlib>
+#include <cstring>
 #include "cells.h"
 #include "misc.h"
 
@@ -28,6 +29,51 @@ extern "C" int spair_adam(float* params, const float* grads, float* exp_avg, flo
                        exp_avg_sq, (long long)n, lr, beta1, beta2, eps, bc1, sqrt_bc2);
     SPAIR_CHECK_LAUNCH();
     return SPAIR_OK;
+}
+
+// The guarded form (include/spair_hip.h): a step whose forward flagged a non-finite loss is left out whole, an element with a non-finite
+// gradient on its own -- lr * NaN never reaches a parameter (the reference raises before its optimizer step: debug_tools.py:245-271).
+__global__ __launch_bounds__(256) void k_adam_guarded(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                      float bc1, float sqrt_bc2, const int* __restrict__ skip, int* __restrict__ counters) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (skip && *skip) {
+        if (i == 0) counters[0] += 1;
+        return;
+    }
+    if (i >= n) return;
+    const float gi = g[i];
+    if (!(fabsf(gi) <= 3.402823466e38f)) { counters[1] = 1; return; }      // NaN or inf
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+extern "C" int spair_adam_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, int step, const int* skip, int* counters, void* stream) {
+    if (n <= 0 || step < 1 || !counters) return SPAIR_ERR_SHAPE;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float sqrt_bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(k_adam_guarded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, (long long)n, lr, beta1, beta2, eps, bc1, sqrt_bc2, skip, counters);
+    SPAIR_CHECK_LAUNCH();
+    return SPAIR_OK;
+}
+
+extern "C" int spair_host_word_alloc(int** out) {
+    if (!out) return SPAIR_ERR_SHAPE;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return SPAIR_ERR_LAUNCH;
+    memset(p, 0, 64);
+    *out = reinterpret_cast<int*>(p);
+    return SPAIR_OK;
+}
+extern "C" int spair_host_word_free(int* word) {
+    if (!word) return SPAIR_OK;
+    return hipHostFree(word) == hipSuccess ? SPAIR_OK : SPAIR_ERR_LAUNCH;
 }
 
 // ---- noise: Philox4x32-10, Box-Muller; one counter per output element ---------------------------
@@ -415,7 +461,7 @@ __global__ __launch_bounds__(256) void k_conv0_fwd_c1k4_mfma(const float* __rest
             if (px < npx) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(drow + px * 128 + m * 8));
             if (mask) {          // (wave-uniform)
                 const u32x4_t wv = __builtin_bit_cast(u32x4_t, o);      // post-ReLU: a channel is on iff its 16 bits are not zero
-                auto nz2 = [](unsigned v) { return (unsigned)((v & 0xffffu) != 0u) | ((unsigned)((v >> 16) != 0u) << 1); };
+                auto nz2 = [](unsigned v) { return (unsigned)((int)(v << 16) > 0) | ((unsigned)((int)v >> 16 > 0) << 1); };      // as a signed 16-bit value > 0: the gate `activation > 0` exactly (-0.0 and NaN stay off)
                 const unsigned byte = nz2(wv.x) | (nz2(wv.y) << 2) | (nz2(wv.z) << 4) | (nz2(wv.w) << 6);
                 if (px < npx) mask[(((size_t)b * Hout + oy0 + r) * Hout + ox0 + px) * 16 + m] = (unsigned char)byte;
             }

@@ -47,7 +47,8 @@ class SpairDims(ctypes.Structure):
 class SpairStep(ctypes.Structure):
     """include/spair_hip.h :: SpairStep"""
     _fields_ = [("wheel", ctypes.c_float), ("count_prior_prob", ctypes.c_float), ("kl_scale", ctypes.c_float),
-                ("train", ctypes.c_int), ("flags", ctypes.c_int), ("draw_noise", ctypes.c_int), ("noise_seed", ctypes.c_uint64)]
+                ("train", ctypes.c_int), ("flags", ctypes.c_int), ("draw_noise", ctypes.c_int), ("noise_seed", ctypes.c_uint64),
+                ("status", ctypes.c_void_p), ("status_host", ctypes.c_void_p)]
 
 
 # bit 0: disable the fused persistent per-cell kernels (tests compare both paths); bit 1: stage stamps; bit 2: no helper stream
@@ -128,8 +129,9 @@ class _StepFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # otherwise autograd zero-fills a gradient for each non-differentiable output (17 MB per step)
         model._loss_terms = loss_terms
         # a view, not a copy: `loss_terms` is a fresh buffer of this forward (a device copy here is 6 us + a launch gap between the loss
-        # kernel and the backward's first kernel)
-        return loss_terms[0], recon, z_where, z_pres
+        # kernel and the backward's first kernel).  Slot 9 is the kernel's SECOND copy of the total: an in-place op on the returned loss
+        # (`loss /= accum_steps`) does not change what loss_terms() and the logging helpers report (slots 0..8)
+        return loss_terms[9], recon, z_where, z_pres
 
     @staticmethod
     def backward(ctx, g_loss, g_recon, g_zw, g_zp):
@@ -179,6 +181,11 @@ class SPAIR(nn.Module):
         self._grad_buckets = None    # set by spair_pytorch_amd.ddp.attach: readiness events for the overlapped all-reduce
         self._anchor = None
         self._loss_terms = None
+        # failed / non-finite steps (SpairStep.status, status_host): two device ints [sticky bits, this step's bits] and one host word the
+        # loss kernel stores to when a step fails -- owned by the model, so they outlive a workspace that is evicted or re-zeroed
+        self._status_dev = None
+        self._status_host = None
+        self.raise_on_nonfinite = True     # forward() raises if an EARLIER step's loss was non-finite (no synchronisation: a host load)
         self.dist_param, self.dist = {}, {}
         self.training_wheel = None
         self.global_step = 0
@@ -258,6 +265,12 @@ class SPAIR(nn.Module):
         self._params_by_key = named
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         self._engines = {}
+        self._status_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        if self._status_host is None:
+            word = ctypes.POINTER(ctypes.c_int)()
+            L.check(lib.spair_host_word_alloc(ctypes.byref(word)), "spair_host_word_alloc")
+            self._status_host = word
+            weakref.finalize(self, lib.spair_host_word_free, word)
 
     def _apply(self, fn, recurse=True):
         # .to(device)/.cuda()/.float(): let nn.Module move the tensors, then re-flatten on the new device
@@ -372,6 +385,8 @@ class SPAIR(nn.Module):
         st = step_scalars(step, B, self.world_size, train)
         if noise.get('_seed') is not None:
             st.draw_noise, st.noise_seed = 1, int(noise['_seed'])
+        st.status = self._status_dev.data_ptr()
+        st.status_host = ctypes.cast(self._status_host, ctypes.c_void_p).value
         e["generation"] += 1              # whatever this workspace held for an earlier forward is gone now
         self._last = dict(engine=e, st=st)
         L.check(L.lib().spair_forward(ctypes.byref(d), ctypes.byref(st), L.ptr(self._flat), L.ptr(x), L.ptr(noise['eps_box']),
@@ -403,6 +418,8 @@ class SPAIR(nn.Module):
         x = x.contiguous().float()
         if list(x.shape[1:]) != list(self.image_shape):
             raise AssertionError("expected input [B,%s], got %s" % (self.image_shape, tuple(x.shape)))
+        if self.raise_on_nonfinite and self._status_host[0] != 0:
+            raise L.SpairHipError(self._status_text(self._status_host[0]) + " -- seen by a later forward(); clear_step_status() to go on")
         self.global_step = global_step
         self.batch_size = x.shape[0]
         e = self._engine(x.shape[0])
@@ -442,6 +459,39 @@ class SPAIR(nn.Module):
             raise L.SpairHipError("no live forward pass: the model has not run yet, or the workspace of its latest forward was evicted by a "
                                   "forward of another batch size (max_engines)")
         return last['engine']
+
+    # ---- failed / non-finite steps -------------------------------------------------------------------------
+    @staticmethod
+    def _status_text(bits):
+        what = []
+        if bits & 2:
+            what.append("a training step produced a non-finite loss (NaN / inf in a loss term; the reference raises at that point: "
+                        "debug_tools.py:245-271)")
+        if bits & 1:
+            what.append("a band-split hand-off of the per-cell chain timed out (preempted / oversubscribed GPU?): the results of that "
+                        "workspace are not to be used -- restart the process, do not retry in place")
+        return "; ".join(what) or "ok"
+
+    def step_status(self):
+        """Bits of every forward of this model so far (sticky): 1 = a band-split hand-off timed out, 2 = a loss term was non-finite; 0 = clean.
+        SYNCHRONISES -- call it where the host waits anyway (after ``loss.item()``, at the end of an epoch).  The same word is also
+        kept in host memory the loss kernel writes to: ``forward()`` looks at it (a host load, no synchronisation) and raises once a
+        failed step has completed, unless ``raise_on_nonfinite`` is off.  ``FusedAdam`` leaves a flagged step out (no NaN parameters)."""
+        self._ensure_ready()
+        return int(self._status_dev[0].item())
+
+    def check_step_status(self):
+        bits = self.step_status()
+        if bits:
+            raise L.SpairHipError(self._status_text(bits))
+
+    def clear_step_status(self):
+        """After a non-finite step that the caller has dealt with (the guarded optimizer skipped it): forget it.  A time-out (bit 1) stays in
+        the workspace that saw it and comes back with its next forward."""
+        self._ensure_ready()
+        self._status_dev.zero_()
+        torch.cuda.current_stream().synchronize()
+        self._status_host[0] = 0
 
     def chain_status(self):
         """Band-split hand-off status of the latest forward's workspace (grids wider than 16 cells): -1 where the chain runs unsplit, 0 = every

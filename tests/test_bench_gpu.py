@@ -33,10 +33,18 @@ def test_default_bench_line_has_every_sub_record():
     assert [p["global_step"] for p in sw if p["axis"] == "schedule"] == [0, 2000, 4000, 6000, 7000, 8000, 10000]
     assert [p["max_objects"] for p in sw if p["axis"] == "objects"] == [1, 3, 6, 11]
     dens = [p for p in sw if p["axis"] == "density"]
-    assert len(dens) == 9 and all(p["render_fwd_ms"] > 0 and p["render_bwd_ms"] > 0 and p["mean_box_side_px"] > 0 for p in sw)
+    # no dead points: every point finite with boxes of at least a pixel (a collapsed state reads sigmoid(-10) * 48 = 0.002 px), the
+    # nine density points each within 10 % of the mean presence they name (round 5's count-prior KL went NaN on the 0.7 row and the
+    # line printed it)
+    assert rec["finite"] is True and rec["step_status"] == 0 and rec["sweep_ok"] is True
+    assert len(dens) == 9 and all(p["render_fwd_ms"] > 0 and p["render_bwd_ms"] > 0 and p["mean_box_side_px"] > 1.0 and p["finite"] for p in sw)
+    assert sorted(set(p["target_mean_z_pres"] for p in dens)) == [0.05, 0.3, 0.7]
+    for p in dens:
+        assert abs(p["mean_z_pres"] - p["target_mean_z_pres"]) <= 0.10 * p["target_mean_z_pres"] and p["on_target"], p
     # the density axis moves what it is named for: presence and object size
     assert max(p["mean_z_pres"] for p in dens) > 3 * min(p["mean_z_pres"] for p in dens)
     assert max(p["mean_box_side_px"] for p in dens) > 1.5 * min(p["mean_box_side_px"] for p in dens)
     assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= max(rec["ms_per_step_repeats"])
     c3 = rec["config3"]
     assert "configs[3]" in c3["workload"] and c3["ms_per_step"] > 0 and "stn_fwd" in c3["kernels"]
+    assert c3["finite"] is True and c3["chain_status"] == 0
