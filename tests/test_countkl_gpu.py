@@ -193,7 +193,7 @@ def test_dense_presence_step_vs_oracle(pres_bias, lo, hi):
                 if k.startswith("attn."):
                     continue
                 g, r = pt.grad.double().cpu().flatten(), p[k].grad.double().flatten()
-                tol = 1e-2 if k.split(".")[-2] in ("conv_0", "conv_1", "conv_2") else 2e-3
+                tol = 1e-2 if k.startswith(("backbone.net.conv_0.", "backbone.net.conv_1.", "backbone.net.conv_2.")) else 2e-3
                 err = (g - r).abs().max().item() / (r.abs().max().item() + 1e-30)
                 cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
                 if err > tol or cos < 0.99999:
