@@ -317,14 +317,6 @@ int spair_render_fwd16m(const void* sprites_f16, int ld_s, const void* records, 
 int spair_render_bwd16r(const void* sprites_f16, int ld_s, const float* nbox, const float* pres, const float* depth, const void* records,
                         const float* aux, const float* grad_loss, void* dlogits_bf16, float* dnbox, float* dpres, float* ddepth,
                         int B, int HW, int C, int I, int P, int align_corners, float obj_scale, float alpha_scale, void* stream);
-/* The backward of spair_render_fwd16m with EVERYTHING on the matrix cores (csrc/render3b.hip): one wave per object, the three sampled
- * channels, their x / y derivatives and the transposed sampling of the adjoints as MFMA products on the fp16 sprite rows and the records.
- * Unit-level entry: the training step runs spair_render_bwd16r's kernel (same speed; csrc/render3b.hip's header has the comparison).  Same
- * outputs as spair_render_bwd16 up to the sampling's rounding: d-logits 1e-2 of the largest element (bf16), d z_where 1e-3, d pres /
- * d depth 1e-2.  SPAIR_ERR_UNSUPPORTED where the records are (P != 28, align_corners, HW > 1024). */
-int spair_render_bwd16m(const void* sprites_f16, int ld_s, const void* records, const float* aux, const float* grad_loss,
-                        void* dlogits_bf16, float* dnbox, float* dpres, float* ddepth, int B, int HW, int C, int I, int P, int align_corners,
-                        float obj_scale, float alpha_scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result", "-Wno-pass-failed"]
 # per-file additions.  render3.hip: MFMA results in VGPRs (they feed VALU at once: the AGPR form costs a v_accvgpr_read per element)
-FILE_FLAGS = {"render3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "render3b.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"render3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():

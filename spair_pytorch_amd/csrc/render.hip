@@ -440,9 +440,6 @@ int render_prep(const float* nbox, const float* pres, const float* depth, int ld
                 hipStream_t s);
 int render_fwd_mma(const void* S16, int ld_s, const void* rec, const float* x, float* recon, float* aux, float* bce_partial, int B, int HW,
                    int I, int P, int ac, hipStream_t s);
-int render_bwd_mma(const void* S16, int ld_s, const void* rec, const float* aux, const float* gloss, void* dlogits16, float* dnbox,
-                   float* dpres, float* ddepth, int ld_g, int B, int HW, int I, int P, int ac, float obj_scale, float alpha_scale,
-                   hipStream_t s);
 // s_bf16: sprites are bf16 (grey, alpha) pairs; ld_s stays in ELEMENTS of that type.  aux: B*I*I float2 (dBCE/dpre / D, pre).
 int render_fwd(const float* S, int ld_s, const float* nbox, const float* pres, const float* depth, int ld_pd, const float* x,
                float* recon, float* aux, float* bce_partial, int B, int HW, int C, int I, int P, int ac, int s_bf16, hipStream_t s) {
@@ -541,13 +538,4 @@ extern "C" int spair_render_bwd16r(const void* sprites_f16, int ld_s, const floa
     return render_bwd(reinterpret_cast<const float*>(sprites_f16), ld_s, nbox, pres, depth, 1, aux, grad_loss,
                       reinterpret_cast<float*>(dlogits_bf16), dnbox, dpres, ddepth, ld_s, B, HW, C, I, P, align_corners, obj_scale,
                       alpha_scale, 1, 1, records, (hipStream_t)stream);
-}
-// The all-matrix-core backward (render3b.hip): unit-level entry, not used by the training step (see the file's header).
-extern "C" int spair_render_bwd16m(const void* sprites_f16, int ld_s, const void* records, const float* aux, const float* grad_loss,
-                                   void* dlogits_bf16, float* dnbox, float* dpres, float* ddepth, int B, int HW, int C, int I, int P,
-                                   int align_corners, float obj_scale, float alpha_scale, void* stream) {
-    if (C != 1) return SPAIR_ERR_UNSUPPORTED;
-    if (B <= 0 || HW <= 0 || I <= 0) return SPAIR_ERR_SHAPE;
-    return render_bwd_mma(sprites_f16, ld_s, records, aux, grad_loss, dlogits_bf16, dnbox, dpres, ddepth, ld_s, B, HW, I, P, align_corners,
-                          obj_scale, alpha_scale, (hipStream_t)stream);
 }

@@ -1,4 +1,4 @@
-// Shared pieces of the matrix-core renderer kernels (render3.hip: records + forward, render3b.hip: backward).
+// Shared pieces of the matrix-core renderer kernels (render3.hip: records + forward; tools/exp/render3b.hip: the all-matrix-core backward that was measured and not shipped).
 #pragma once
 #include "render_common.h"
 
