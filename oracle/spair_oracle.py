@@ -241,8 +241,11 @@ def stn(image: torch.Tensor, z_where: torch.Tensor, out_hw: Tuple[int, int], inv
 # --------------------------------------------------------------------------------------
 # The model
 # --------------------------------------------------------------------------------------
-def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
-    """Sequential per-cell loop, models.py:68-117 with helpers :292-450."""
+def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False, taps: Optional[dict] = None):
+    """Sequential per-cell loop, models.py:68-117 with helpers :292-450.  ``taps`` (a dict) receives, per name, the list over cells (row-major)
+    of the four networks' RAW outputs with ``retain_grad()`` set -- ``box_lat`` [B,8], ``enc_out`` [B,2A], ``depth_lat`` [B,2], ``pres_logit``
+    [B,1] -- so that a test can read the reference's per-cell latent gradients after ``loss.backward()`` (the HIP backward keeps the same
+    quantities per cell in its row buffers: spair_export_map 100.. / 200..)."""
     B = x.shape[0]
     _, I_h, I_w = cfg.image_shape
     G = feat.shape[-1]
@@ -265,6 +268,8 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
                              for dh in range(-Lb, 1) for dw in range(-Lb, (Lb if dh else -1) + 1)], dim=-1)
             # --- z_where (models.py:76-79,322-381)
             lat, passthru = _mlp(p, "box_network", torch.cat([cell_feat, ctx], -1), multi=True)
+            if taps is not None and lat.requires_grad:
+                lat.retain_grad(); taps.setdefault("box_lat", []).append(lat)
             mean, std = latent_to_mean_std(lat)
             mean, std = freeze(wheel, mean, std)
             eps = noise["eps_box"][:, :, h, w]
@@ -285,11 +290,15 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
             glimpse = stn(x, nbox, tuple(cfg.object_shape), inverse=False,
                           align_corners=cfg.align_corners, fast=fast)
             enc = object_encoder(p, glimpse, cfg)
+            if taps is not None and enc.requires_grad:
+                enc.retain_grad(); taps.setdefault("enc_out", []).append(enc)
             a_mean, a_std = latent_to_mean_std(enc)
             attr = a_mean + a_std * noise["eps_attr"][:, :, h, w]
             means["attr"][ci], sigmas["attr"][ci] = a_mean, a_std
             # --- z_depth (models.py:88-97)
             dlat, passthru = _mlp(p, "z_network", torch.cat([cell_feat, ctx, passthru, box, attr], 1), multi=True)
+            if taps is not None and dlat.requires_grad:
+                dlat.retain_grad(); taps.setdefault("depth_lat", []).append(dlat)
             d_mean, d_std = latent_to_mean_std(dlat)
             d_mean, d_std = freeze(wheel, d_mean, d_std)
             d_logit = d_mean + d_std * noise["eps_depth"][:, :, h, w]
@@ -297,6 +306,8 @@ def encode_cells(p, x, feat, noise, wheel, cfg: OracleConfig, fast=False):
             depth = 4 * clamped_sigmoid(d_logit)
             # --- z_pres (models.py:100-102,393-411)
             logit = _mlp(p, "obj_network", torch.cat([cell_feat, ctx, passthru, box, attr, depth], 1))
+            if taps is not None and logit.requires_grad:
+                logit.retain_grad(); taps.setdefault("pres_logit", []).append(logit)
             logit = freeze(wheel, logit)
             log_odds = torch.clamp(logit, -10.0, 10.0)
             u = noise["u_pres"][:, :, h, w]
@@ -377,13 +388,13 @@ def render(p, z_attr, z_where, z_depth, z_pres, cfg: OracleConfig, fast=False):
 
 def forward(p: Dict[str, torch.Tensor], x: torch.Tensor, global_step: int,
             noise: Dict[str, torch.Tensor], cfg: OracleConfig, fast: bool = False,
-            kl_scale: Optional[float] = None):
+            kl_scale: Optional[float] = None, taps: Optional[dict] = None):
     """models.py:35-131 + _build_loss :544-563.  ``kl_scale`` (default 1/B) is the factor
     on the summed KL maps -- 1/(B*world_size) reproduces the sharded loss of SURVEY §8(e)."""
     B = x.shape[0]
     feat = backbone_forward(p, x, cfg)
     wheel = exponential_decay(global_step, **cfg.wheel)
-    z_where, z_attr, z_depth, z_pres, dist = encode_cells(p, x, feat, noise, wheel, cfg, fast=fast)
+    z_where, z_attr, z_depth, z_pres, dist = encode_cells(p, x, feat, noise, wheel, cfg, fast=fast, taps=taps)
     kl = compute_kl(dist, z_pres, global_step, cfg)
     recon = render(p, z_attr, z_where, z_depth, z_pres, cfg, fast=fast)
     recon_loss = F.binary_cross_entropy(recon, x, reduction="sum")

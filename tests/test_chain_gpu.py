@@ -177,3 +177,51 @@ def test_fused_backward_equals_per_wavefront_path_cell_by_cell(I, B, strides):
         worst = (err / bound).max().item()
         print("%s: worst cell at %.2f of its bound; median relative error %.2e" % (names[k], worst, (err / (ref + 1e-30)).median().item()))
         assert worst <= 1.0, (names[k], worst)
+
+
+@pytest.mark.parametrize("I,B,strides", [(48, 4, (2, 2, 2, 1, 1, 1)), (128, 2, (2, 2, 2, 1, 1, 1)), (128, 2, (3, 2, 2, 1, 1, 1))])
+def test_per_cell_latent_gradients_vs_oracle(I, B, strides):
+    """The backward chain against the REFERENCE's autograd, cell by cell (the test above compares the two HIP paths with each other).  The
+    oracle (pinned to the reference's fixtures) keeps the four networks' raw outputs of every cell with retain_grad(): d loss / d (box head
+    latents [8], encoder output [2A], depth latents [2], presence logit [1]) -- exactly what the HIP backward leaves per cell in its row
+    buffers (spair_export_map 100.. for the per-wavefront launches, 200.. for the fused kernel).  fp32 mode: every cell's vector within 2e-3 of
+    its own norm (+ 1e-4 of the largest cell's); observed: whole maps 2e-7 .. 1.3e-5, worst cell 5 % of that bound.  bf16 mode (the fused
+    k_chain_bwd behind k_render_bwd2 / k_dec_bwd): within 15 % of the cell's norm + 0.5 % of the largest cell's -- the bound the two HIP paths
+    hold against each other -- and 3 % over the whole map; for the encoder output, whose gradient arrives through the bf16 d-logits of 1,568
+    sprite texels per cell and the bf16 decoder weights, 30 % and 6 % (observed: median cell 0.9-2.0 %, worst cell 24 %, whole map 1.6-4.6 %;
+    box / depth / presence: median 0.1-0.2 %, whole maps 0.2-0.6 %)."""
+    from oracle import spair_oracle as orc
+    from spair_pytorch_amd import config as cfg
+    from spair_pytorch_amd import models
+    from spair_pytorch_amd.data import scattered_digits
+    cfg.set_grid(I, strides)
+    G = gi.grid_side(I, strides)
+    gs = 2500
+    w = gi.make_weights(21, 1.0)
+    x = scattered_digits(7 + B, B, I, 9)[0]
+    noise = gi.make_noise(3 + B, B, G)
+    p = {k: torch.from_numpy(v).clone().requires_grad_(not k.startswith("attn.")) for k, v in w.items()}
+    ocfg = orc.OracleConfig(image_shape=(1, I, I), conv_strides=tuple(strides), inverse_mode="closed")
+    taps = {}
+    ref = orc.forward(p, torch.from_numpy(x), gs, {k: torch.from_numpy(v) for k, v in noise.items()}, ocfg, fast=True, taps=taps)
+    ref["loss"].backward()
+    names = ["box_lat", "enc_out", "depth_lat", "pres_logit"]
+    want = [torch.stack([t.grad for t in taps[n]], dim=-1).view(B, -1, G, G).double() for n in names]      # cells row-major -> [B, ch, G, G]
+    for dtype, base, cell_tol, floor_tol, map_tol in (("f32", 100, 2e-3, 1e-4, 1e-3), ("bf16", 200, 0.15, 5e-3, 0.03)):
+        m = models.SPAIR([1, I, I], None, torch.device("cuda"), compute_dtype=dtype).to("cuda")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        m.zero_grad()
+        loss = m(torch.from_numpy(x).cuda(), gs, noise={k: torch.from_numpy(v).cuda() for k, v in noise.items()})[0]
+        loss.backward()
+        assert abs(loss.item() - ref["loss"].item()) <= (2e-5 if dtype == "f32" else 2.5e-4) * abs(ref["loss"].item())
+        for k, n in enumerate(names):
+            got = m.export_map(base + k).double().cpu()
+            r = want[k]
+            assert got.shape == r.shape, (n, got.shape, r.shape)
+            err, rn = (got - r).norm(dim=1), r.norm(dim=1)
+            assert rn.max().item() > 0, n
+            ct, mt = (2 * cell_tol, 2 * map_tol) if (dtype == "bf16" and n == "enc_out") else (cell_tol, map_tol)
+            worst = (err / (ct * rn + floor_tol * rn.max())).max().item()
+            whole = (got - r).norm().item() / r.norm().item()
+            print("%s %s: worst cell at %.2f of its bound, whole map %.2e, median cell %.2e" % (dtype, n, worst, whole, (err / (rn + 1e-30)).median().item()))
+            assert worst <= 1.0 and whole <= mt, (dtype, n, worst, whole)
