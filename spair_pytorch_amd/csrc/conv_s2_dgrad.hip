@@ -9,7 +9,8 @@
 // patch of its 128 class pixels ONCE (both 64-channel halves, <= 7 rows x 36 pixels x 256 B at conv_1) and runs the 16 (class, tap) products
 // -- 32 K steps of 64 -- out of it: the gathered operand costs 64 KB per tile instead of 4 x 128 KB through the implicit-GEMM kernel, which was
 // bound by exactly those bytes (conv_1's data gradient: 0.31 ms for 155 GFLOP).  Only the 16 KB weight tile of each K step streams (ring of 3).
-// Wave roles as in conv_s2.hip: 4 computing waves (2 x 2, 64 x 64 each) + 4 loader waves that issue every LDS-DMA behind counted waits.
+// Wave roles as in conv_s2.hip: 8 computing waves (a 64-channel x 32-pixel block of the transposed tile each, two per SIMD; round 6 -- 4 waves of
+// 64 x 64, one per SIMD, before) + 4 loader waves that issue every LDS-DMA behind counted waits.
 // Per class an epilogue on the computing waves: accumulators -> bf16 tile in LDS -> whole 256-byte rows: ReLU gate (the stored activation of the
 // layer below > 0), then either the row-mapped store of d act or (STEM) the gated tile x the 4x4 input patches on the matrix cores, summed
 // over the tile's 4 classes and left as ONE [128][17] partial per workgroup.
@@ -59,7 +60,7 @@ __device__ __forceinline__ bf16x8 dg_tr_frag16(const __bf16* tile, int ld, int c
 }
 
 template <bool STEM, bool BITS>
-__global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
+__global__ __launch_bounds__(768, 3) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dg_sm[];
     char* bt = dg_sm;                            // [3][128 ci][64 k] bf16, chunk ^ (row & 7)
     char* patch = dg_sm + DG_OFF_PATCH;          // [2 halves][DG_PPX][64 ch] bf16, chunk ^ (pixel & 7)
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         L0 = (g0 + g0 / Hc) * Wp + (m0 - g0 * Hc);
         npx = (g1 + g1 / Hc + 1) * Wp + (mlast - g1 * Hc) + 1 - L0 + 1;      // <= DG_PPX (checked by the launcher)
     };
-    const bool loader = wave >= 4;
+    // 8 computing waves (two per SIMD: one's LDS round trips and class epilogue meet the other's MFMAs -- with one per SIMD every
+    // fragment-read latency and the whole register epilogue of a class were exposed: MFMA pipe 0.33 busy) + 4 loader waves (one per SIMD)
+    const bool loader = wave >= 8;
     const int lw = wave & 3;
 
     if (loader) {
@@ -154,20 +157,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         return;
     }
 
-    // ---------------------------------------------------------------- computing waves (tid 0 .. 255)
+    // ---------------------------------------------------------------- computing waves (tid 0 .. 511)
     // The products are computed TRANSPOSED, C'[ci][pixel] = sum_k W[ci][k] . patch[pixel][k] (weights = A operand, patch = B operand): a lane of the
     // accumulator then holds 4 consecutive channels of ONE pixel, and with the weight rows of a tile pair read in the order n(T, m) above 8
     // consecutive ones -- exactly a 16-byte piece of the pixel's NHWC row.  The ReLU gate and the store (or the write of the gated tile for the
     // stem product) work on registers: no staging of the accumulators through LDS, no epilogue barrier in the plain kernel (staged through a
     // bf16 tile with 2-byte LDS writes the epilogue of a class took 4,500 cycles, as long as 4 of its 8 K steps, and stalled the loaders).
-    const int wm = wave >> 1, wn = wave & 1;
-    int pbase[4];                                // patch pixel of (pixel tile j, pixel r16) at tap (0, 0)
-    unsigned orow[4];                            // its output pixel of class (0, 0)
-    bool ook[4];
+    // wave -> (channel half wn, pixel half wm, 32-pixel quarter wp): a 64-channel x 32-pixel block of the transposed tile per wave
+    const int wn = wave & 1, wm = (wave >> 1) & 1, wp = wave >> 2;
+    const int prow0 = wm * 64 + wp * 32;         // the wave's first tile pixel
+    int pbase[2];                                // patch pixel of (pixel tile j, pixel r16) at tap (0, 0)
+    unsigned orow[2];                            // its output pixel of class (0, 0)
+    bool ook[2];
     auto set_rows = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + r16;
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + prow0 + j * 16 + r16;
             ook[j] = m < mend;
             const int mc = min(m, mend - 1);
             const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
@@ -180,15 +185,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
     const int wrow0 = wn * 64 + (r16 >> 2) * 8 + (r16 & 3);          // + 32 (t >> 1) + 4 (t & 1)
     const int ch0 = wn * 64 + q * 8;                                  // + 32 p: the 8 channels this lane owns after tile pair p
     const __amdgpu_buffer_rsrc_t rgate = buf_rsrc(BITS ? reinterpret_cast<const void*>(a.gbits) : reinterpret_cast<const void*>(a.gate)), rout = buf_rsrc(a.out);
-    f32x4 sacc[2][2];                            // STEM: this wave's 32 channels x (16 taps | bias | 0 ...), over the tile's 4 classes
+    f32x4 sacc[2];                               // STEM: this wave's 16 channels x (16 taps | bias | 0 ...), over the tile's 4 classes
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) sacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[4][4];                             // [channel tile t][pixel tile j]
-    bf16x8 wfA[4], pfA[4], wfB[4], pfB[4];
-    auto read_frags = [&](int kt, int half, int tap, int ks, bf16x8 (&wf)[4], bf16x8 (&pf)[4]) {
+    f32x4 acc[4][2];                             // [channel tile t][pixel tile j]
+    bf16x8 wfA[4], pfA[2], wfB[4], pfB[2];
+    auto read_frags = [&](int kt, int half, int tap, int ks, bf16x8 (&wf)[4], bf16x8 (&pf)[2]) {
         const char* bs = bt + (kt % 3) * DG_BT_B;
         const char* pb = patch + half * DG_PATCH_B;
         const int toff = -((tap >> 1) * Wp + (tap & 1));
@@ -199,16 +202,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
             wf[t] = *reinterpret_cast<const bf16x8*>(bs + n * 128 + ((c ^ wkey) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int pp = pbase[j] + toff;
             pf[j] = *reinterpret_cast<const bf16x8*>(pb + pp * 128 + ((c ^ (pp & 7)) << 4));
         }
     };
-    auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&pf)[4]) {
+    auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&pf)[2]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], pf[j], acc[t][j], 0, 0, 0);
     };
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -222,12 +225,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // gate pieces of this class (and the stem patches) are requested at the top of the class: their latency hides behind its 8 K steps
-        uint4 gate[BITS ? 1 : 4][2];
-        u32x2_t gbits[4];                        // BITS: the 64 sign bits of this wave half's 64 channels of the pixel; the lane's two bytes are q and q + 4
+        uint4 gate[BITS ? 1 : 2][2];
+        u32x2_t gbits[2];                        // BITS: the 64 sign bits of this wave half's 64 channels of the pixel; the lane's two bytes are q and q + 4
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const unsigned pix = orow[j] + (unsigned)(py * a.Hi + px);
             if (BITS) gbits[j] = __builtin_amdgcn_raw_buffer_load_b64(rgate, ook[j] ? (int)(pix * 16u + (unsigned)(wn * 8)) : (int)BUF_OOB, 0, 0);
             else {
@@ -235,20 +238,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                 for (int p = 0; p < 2; ++p) gate[j][p] = buf_load16(rgate, ook[j] ? (pix * DG_C + ch0 + p * 32) * 2u : BUF_OOB);
             }
         }
-        float2 sp[4];
+        float2 sp[2];
         bool sp_ok = false;
-        if (STEM) {
-            const int prow = tid >> 1, hf = tid & 1;
+        if (STEM) {                              // thread (tile pixel prow, kernel row kr): the four stem taps of that row
+            const int prow = tid >> 2, kr = tid & 3;
             const int m = m0 + prow;
             sp_ok = m < mend;
             const int mc = min(m, mend - 1);
             const int g = mc / Hc, x = mc - g * Hc, b = g / Hc, y = g - b * Hc;
             const int yy = 2 * y + py, xx = 2 * x + px;
-            const float* src = a.stem_xp + ((size_t)b * a.stem_hin + yy * a.stem_s + 2 * hf) * a.stem_hin + xx * a.stem_s;
+            const float* src = a.stem_xp + ((size_t)b * a.stem_hin + yy * a.stem_s + kr) * a.stem_hin + xx * a.stem_s;
             sp[0] = *reinterpret_cast<const float2*>(src);
             sp[1] = *reinterpret_cast<const float2*>(src + 2);
-            sp[2] = *reinterpret_cast<const float2*>(src + a.stem_hin);
-            sp[3] = *reinterpret_cast<const float2*>(src + a.stem_hin + 2);
         }
         // K steps of the class, software-pipelined across the workgroup barriers: the fragments of (kt, ks 1) are read while the MFMAs of
         // (kt, ks 0) run, those of (kt + 1, ks 0) -- right behind barrier(kt + 1), which certifies that tile -- while the MFMAs of (kt, ks 1)
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         }
         // ---- class epilogue on registers: gate = stored activation of the layer below > 0 (bf16 sign / zero test), 8 channels of one pixel per lane
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 bf16x8 v;
@@ -300,32 +301,29 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
                     }
                 }
                 const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                if (STEM) *reinterpret_cast<uint4*>(Gs + (wm * 64 + j * 16 + r16) * DG_LDG + ch0 + p * 32) = ook[j] ? o : make_uint4(0u, 0u, 0u, 0u);
+                if (STEM) *reinterpret_cast<uint4*>(Gs + (prow0 + j * 16 + r16) * DG_LDG + ch0 + p * 32) = ook[j] ? o : make_uint4(0u, 0u, 0u, 0u);
                 else buf_store16(rout, ook[j] ? ((orow[j] + (unsigned)(py * a.Hi + px)) * DG_C + ch0 + p * 32) * 2u : BUF_OOB, o);
             }
         if (STEM) {
-            const int prow = tid >> 1, hf = tid & 1;
-            bf16x8 o, one;
-            const float pv[8] = {sp[0].x, sp[0].y, sp[1].x, sp[1].y, sp[2].x, sp[2].y, sp[3].x, sp[3].y};
+            const int prow = tid >> 2, kr = tid & 3;
+            bf16x4 o, one;
+            const float pv[4] = {sp[0].x, sp[0].y, sp[1].x, sp[1].y};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { o[e] = (__bf16)(sp_ok ? pv[e] : 0.f); one[e] = (__bf16)0.f; }
-            one[0] = (__bf16)((sp_ok && hf == 0) ? 1.f : 0.f);
-            *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + hf * 8]) = o;
-            *reinterpret_cast<bf16x8*>(&Ps[prow * DG_LDP + 16 + hf * 8]) = one;
+            for (int e = 0; e < 4; ++e) { o[e] = (__bf16)(sp_ok ? pv[e] : 0.f); one[e] = (__bf16)0.f; }
+            one[0] = (__bf16)((sp_ok && kr == 0) ? 1.f : 0.f);
+            *reinterpret_cast<bf16x4*>(&Ps[prow * DG_LDP + kr * 4]) = o;
+            *reinterpret_cast<bf16x4*>(&Ps[prow * DG_LDP + 16 + kr * 4]) = one;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();        // E: the gated tile and the patches are written
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < DG_BM / 32; ++ks) {
-                bf16x8 af[2], bfr[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = dg_tr_frag16(Gs + ks * 32 * DG_LDG, DG_LDG, wave * 32 + i * 16, lane);
+                bf16x8 bfr[2];
+                const bf16x8 af = dg_tr_frag16(Gs + ks * 32 * DG_LDG, DG_LDG, wave * 16, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bfr[j] = dg_tr_frag16(Ps + ks * 32 * DG_LDP, DG_LDP, j * 16, lane);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], sacc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], sacc[j], 0, 0, 0);
             }
             // (the next class overwrites the tile / patches only behind its 8 K-step barriers)
         }
@@ -336,18 +334,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_s2k4_dgrad(ConvDgradArgs a) {
         float* Ws = reinterpret_cast<float*>(Gs);            // [128 ch][17]
         const int col_l = lane & 15, rgrp = (lane >> 4) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = wave * 32 + i * 16 + rgrp + r;
-                Ws[ch * 17 + col_l] = sacc[i][0][r];
-                if (col_l == 0) Ws[ch * 17 + 16] = sacc[i][1][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int ch = wave * 16 + rgrp + r;
+            Ws[ch * 17 + col_l] = sacc[0][r];
+            if (col_l == 0) Ws[ch * 17 + 16] = sacc[1][r];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         float4* pt = reinterpret_cast<float4*>(a.stem_part + (size_t)blockIdx.x * DG_STEM_FLOATS);
-        for (int qq = tid; qq < DG_STEM_FLOATS / 4; qq += 256) pt[qq] = reinterpret_cast<const float4*>(Ws)[qq];
+        for (int qq = tid; qq < DG_STEM_FLOATS / 4; qq += 512) pt[qq] = reinterpret_cast<const float4*>(Ws)[qq];
     }
 }
 
@@ -403,10 +399,10 @@ int conv_s2k4_patch_dgrad16(const void* dout, const void* const* wd, const void*
     const void* fns[4] = {reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false, false>), reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true, false>),
                           reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<false, true>), reinterpret_cast<const void*>(&k_conv_s2k4_dgrad<true, true>)};
     if (spair_dyn_lds_once(fns[vi], DG_LDS, attr_done[vi]) != SPAIR_OK) return SPAIR_ERR_LAUNCH;
-    if (vi == 0) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, false>), dim3(grid), dim3(512), DG_LDS, s, a);
-    else if (vi == 1) hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, false>), dim3(grid), dim3(512), DG_LDS, s, a);
-    else if (vi == 2) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, true>), dim3(grid), dim3(512), DG_LDS, s, a);
-    else hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, true>), dim3(grid), dim3(512), DG_LDS, s, a);
+    if (vi == 0) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, false>), dim3(grid), dim3(768), DG_LDS, s, a);
+    else if (vi == 1) hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, false>), dim3(grid), dim3(768), DG_LDS, s, a);
+    else if (vi == 2) hipLaunchKernelGGL((k_conv_s2k4_dgrad<false, true>), dim3(grid), dim3(768), DG_LDS, s, a);
+    else hipLaunchKernelGGL((k_conv_s2k4_dgrad<true, true>), dim3(grid), dim3(768), DG_LDS, s, a);
     SPAIR_CHECK_LAUNCH();
     if (stem) return spair_stem_fused_reduce(stem_part, grid, stem_dw, stem_db, s);
     return SPAIR_OK;
