@@ -25,8 +25,9 @@ for I, strides, B in T.DENSE_GEOMS:
             o32, o64 = [], []
             orc.compute_kl({}, z, step, ocfg, p_z_out=o32); orc.compute_kl({}, z.double(), step, ocfg, p_z_out=o64)
             r32, r64 = o32[0].double().flatten(1), o64[0].flatten(1)
+            e32 = (pz - r32).abs().max().item()          # against the fp32 oracle = the reference's arithmetic (what the test bounds)
             e = (pz - r64).abs()
             b, i = divmod(int(e.argmax()), HW)
-            print("G=%2d %-7s step %5d: kernel-f64 max %.2e at sample %3d cell %4d (p_z %.6f, %d on before, density %.2f); oracle32-f64 there %.2e, max %.2e; rel err max %.2e"
-                  % (G, kind, step, e.max().item(), b, i, r64[b, i].item(), int(on[b, :i].sum()), on[b].mean(), abs(r32[b, i] - r64[b, i]).item(),
+            print("G=%2d %-7s step %5d: kernel-oracle32 max %.2e | kernel-f64 max %.2e at sample %3d cell %4d (p_z %.6f, %d on before, density %.2f); oracle32-f64 there %.2e, max %.2e; rel err max %.2e"
+                  % (G, kind, step, e32, e.max().item(), b, i, r64[b, i].item(), int(on[b, :i].sum()), on[b].mean(), abs(r32[b, i] - r64[b, i]).item(),
                      (r32 - r64).abs().max().item(), (e / r64.clamp(min=1e-12)).max().item()), flush=True)
