@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <mutex>
+#include <functional>
 #include <vector>
 
 #include "cells.h"
@@ -1411,6 +1412,7 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     std::unique_lock<std::mutex> enq_lock;
     if (side) enq_lock = std::unique_lock<std::mutex>(side->enq_mu);
     hipStream_t const main_s = c.s;
+    std::function<int()> dec_wgrads;
     if (PL.oc_n) {
         ProfScope ps(PS_DECODER_BWD, c.s);
         TRY(oc_decoder_bwd(c, grads));
@@ -1441,17 +1443,26 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
             TRY(nt16(c, c.w.dHd1, SP_DEC_H1, c.w.lin_wt[LIN_DEC0], SP_DEC_H1, P.g_attr_r, L.ld_rec, 0, N, l0.in, SP_DEC_H1, nullptr, nullptr, 0, 0));
             }
         }
-        if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; c.tn_scratch = c.w.tn_part2; }
-        { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, c.w.dLog, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
-        {
+        // The decoder's three weight gradients (helper stream).  With the fused chain they are issued BEHIND the chain backward's launch (round 6):
+        // its 256 LDS-exclusive workgroups leave them no CU before they retire anyway, but issued in front of it they were eligible the moment
+        // the first chain workgroup left -- and took the machine from the 1x1 stack's data gradient, the head of the backbone backward's
+        // critical path, which only becomes eligible when the LAST chain workgroup has left.
+        float* const dlog_w = c.w.dLog;
+        dec_wgrads = [&c, &l2, &l1, &l0, &L, grads, N, dlog_w, ev_decoder]() -> int {
+            { ProfScope p2(PS_DEC2_WGRAD, c.s); TRY(tn16(c, dlog_w, c.w.ld_s, l2.out, c.w.Hd2, SP_DEC_H2, l2.in, true, grads + l2.w, l2.in, N, grads + l2.b)); }
             const int rc_g = decoder_small_wgrad_grouped(c, grads, N);
             if (rc_g == SPAIR_ERR_UNSUPPORTED) {
                 TRY(tn16(c, c.w.dHd2, SP_DEC_H2, l1.out, c.w.Hd1, SP_DEC_H1, l1.in, true, grads + l1.w, l1.in, N, grads + l1.b));
                 TRY(tn16(c, c.w.dHd1, SP_DEC_H1, l0.out, c.w.Za16, L.ld_rec, l0.in, true, grads + l0.w, l0.in, N, grads + l0.b));
             } else if (rc_g != SPAIR_OK) return rc_g;
+            return record_ready(ev_decoder, c.s);
+        };
+        if (!(side && c.use_chain)) {          // no helper stream / per-wavefront launches: where they always were
+            if (side) { TRY(stream_link(main_s, side->s, side->ev[0])); c.s = side->s; c.tn_scratch = c.w.tn_part2; }
+            TRY(dec_wgrads());
+            dec_wgrads = nullptr;
+            if (side) { c.s = main_s; c.tn_scratch = nullptr; }
         }
-        TRY(record_ready(ev_decoder, c.s));
-        if (side) { c.s = main_s; c.tn_scratch = nullptr; }
         c.w.dLog = dlog_f32;
     } else {   // decoder
         ProfScope ps(PS_DECODER_BWD, c.s);
@@ -1508,6 +1519,11 @@ extern "C" int spair_backward_ev(const SpairDims* d, const SpairStep* st, const 
     prof_end(ps_cells, c.s);
     // the per-cell weight gradients (helper stream) and the backbone backward (caller's stream) both hang off the chain only
     if (side) { TRY(stream_link(main_s, side->s, side->ev[2])); c.s = side->s; }
+    if (dec_wgrads) {                          // (deferred: see the decoder block)
+        c.tn_scratch = c.w.tn_part2;
+        TRY(dec_wgrads());
+        c.tn_scratch = nullptr;
+    }
     const int ps_wg = prof_begin(PS_CELLS_WGRAD, c.s);
     // weight gradients of the per-cell nets: long-K GEMMs over all N rows
     if (c.use_chain) {
