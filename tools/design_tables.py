@@ -41,7 +41,7 @@ ROWS = [
     ("`k_tn_ring<256,true,3>` conv_2 wgrad", "autograd of conv_2", "k_tn_ring<256, true, 3>", "min", None, "mfma", 34.4e9),
     ("`k_tn_ring<128,false,3>` per-cell wgrads, grouped (13 layers)", "autograd of modules.py:124-165", "k_tn_ring<128, false, 3>", 98304, None, "mfma", 29.0e9),
     ("`k_tn_ring<256,false,3>` encoder layer 0 wgrad", "autograd of object_encoder.dense0", "k_tn_ring<256, false, 3>", 131072, None, "mfma", 26.8e9),
-    ("`k_tn_ring<256,false,3>` decoder.out wgrad (beside `k_chain_bwd`)", "autograd of object_decoder.out", "k_tn_ring<256, false, 3>", 106496, None, "mfma", 52.6e9),
+    ("`k_tn_ring<256,false,3>` decoder.out wgrad (behind `k_chain_bwd` since round 6)", "autograd of object_decoder.out", "k_tn_ring<256, false, 3>", 106496, None, "mfma", 52.6e9),
     ("`k_pw_stack<false>` 1x1 stack forward", "modules.py:59-64 (conv_3..out)", "k_pw_stack<false>", None, None, "mfma", 8.4e9),
     ("`k_pw_stack<true>` 1x1 stack dgrad", "autograd of the same", "k_pw_stack<true>", None, None, "mfma", 8.4e9),
     ("`k_count_kl<5,4>` (K8, beside decoder + renderer)", "models.py:186-257", "k_count_kl<5, 4>", None, None, "latency", 0.0),
